@@ -1,0 +1,189 @@
+/* mgs.h -- C ABI of the MI355X-native 3D Gaussian Splatting render path (libmgs.so).
+ *
+ * Drop-in boundary.  The reference (Maxwell-Zhao/RoboSimGS) has no FFI or operator
+ * interface of its own for this path: it delegates 3DGS to Nerfstudio in prose
+ * (/root/reference/README.md:75) and has not released the stage that renders the
+ * exported .ply (README.md:29, :84-85).  The interface a maintainer would bind is
+ * therefore the operator set of the rasteriser nerfstudio's `splatfacto` calls
+ * (gsplat 1.x).  Each entry point below names the
+ * operator it stands in for.  The camera convention at the boundary (OpenCV
+ * world-to-camera `viewmat`, pixel-unit `K`) is the one the reference's
+ * Articulation/utils/nerf2physic_utils.py:10-23 (`project_3d_to_2d`) encodes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 / int32 / int64 data, contiguous,
+ *    row-major, unless marked "host";
+ *  - the caller owns every buffer, workspace included; nothing is allocated, freed or
+ *    retained by the library;
+ *  - all work is enqueued on `stream` (a hipStream_t); no entry point synchronises,
+ *    so every call is capturable in a hipGraph;
+ *  - return value: 0 ok, <0 MGS_ERR_*, >0 a hipError_t from a launch;
+ *  - data-dependent sizes (the number of tile intersections) stay on the device:
+ *    `n_isect` is a device scalar and buffers are sized by a caller-chosen capacity;
+ *    overflow raises bit MGS_STATUS_ISECT_OVERFLOW in the device `status` word and the
+ *    frame must be re-rendered with a larger capacity (nothing is written out of
+ *    bounds);
+ *  - stateless and re-entrant; one process per GPU or several host threads with their
+ *    own streams are both fine.
+ */
+#ifndef MGS_H_
+#define MGS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGS_VERSION 100 /* 0.1.0 */
+
+#define MGS_OK 0
+#define MGS_ERR_INVALID_ARGUMENT (-1)
+#define MGS_ERR_WORKSPACE_TOO_SMALL (-2)
+#define MGS_ERR_UNSUPPORTED (-3)
+
+#define MGS_STATUS_ISECT_OVERFLOW 1u
+
+#define MGS_TILE_SIZE 16
+#define MGS_MAX_CHANNELS 32
+
+typedef void *mgs_stream_t; /* hipStream_t */
+
+int mgs_version(void);
+/* Thread-local, human-readable description of the last non-zero return value. */
+const char *mgs_last_error_string(void);
+
+/* -------------------------------------------------------------------------------------
+ * Projection  (gsplat `fully_fused_projection` forward, packed=False, one camera)
+ *   means[N,3] quats[N,4] (wxyz, normalised inside) scales[N,3] (post-exp)
+ *   viewmat[4,4] K[3,3]: device pointers, row-major.
+ *   out: radii[N] i32 (0 = culled), means2d[N,2], depths[N], conics[N,3],
+ *        compensations[N] (nullable; sqrt(max(0, det_orig/det_blur))).
+ *   Culled Gaussians get zeros in every output.
+ * ----------------------------------------------------------------------------------- */
+int mgs_projection_fwd(int n, const float *means, const float *quats, const float *scales,
+                       const float *viewmat, const float *K, int width, int height,
+                       float eps2d, float near_plane, float far_plane, float radius_clip,
+                       int32_t *radii, float *means2d, float *depths, float *conics,
+                       float *compensations, mgs_stream_t stream);
+
+/* Projection backward (gsplat `fully_fused_projection` backward).
+ *   v_means2d[N,2] v_depths[N] v_conics[N,3] v_compensations[N] (nullable) are the
+ *   incoming cotangents; v_means[N,3] v_quats[N,4] v_scales[N,3] are ACCUMULATED into
+ *   (+=) so several cameras can be summed; pass zeroed buffers for a single camera.
+ *   v_viewmat[16] (nullable) is accumulated with atomics. */
+int mgs_projection_bwd(int n, const float *means, const float *quats, const float *scales,
+                       const float *viewmat, const float *K, int width, int height,
+                       float eps2d, const int32_t *radii, const float *conics,
+                       const float *compensations, const float *v_means2d,
+                       const float *v_depths, const float *v_conics,
+                       const float *v_compensations, float *v_means, float *v_quats,
+                       float *v_scales, float *v_viewmat, mgs_stream_t stream);
+
+/* -------------------------------------------------------------------------------------
+ * Spherical harmonics  (gsplat `spherical_harmonics` forward / backward)
+ *   dirs[N,3] (un-normalised), coeffs[N,K,3] with K = coeff_stride >= (degree+1)^2,
+ *   masks[N] (nullable, uint8/bool: 0 = skip and write zeros), colors[N,3] = sum_k Y_k c_k
+ *   (no +0.5, no clamp: the caller applies them, as splatfacto does).
+ * ----------------------------------------------------------------------------------- */
+int mgs_sh_fwd(int n, int degree, int coeff_stride, const float *dirs, const float *coeffs,
+               const uint8_t *masks, float *colors, mgs_stream_t stream);
+/* v_coeffs[N,K,3] is written (zeros beyond the active degree and for masked rows);
+ * v_dirs[N,3] nullable, written. */
+int mgs_sh_bwd(int n, int degree, int coeff_stride, const float *dirs, const float *coeffs,
+               const uint8_t *masks, const float *v_colors, float *v_coeffs, float *v_dirs,
+               mgs_stream_t stream);
+
+/* -------------------------------------------------------------------------------------
+ * Fused projection + view-dependent colour (the render path's first kernel).
+ * Equivalent to mgs_projection_fwd, then dirs = means - campos, mgs_sh_fwd masked by
+ * radii > 0, then feat = max(colour + 0.5, 0); SH coefficients of culled Gaussians are
+ * never read.  feats[N,feat_stride]: channels 0..2 rgb; if feat_stride == 4 channel 3
+ * receives the camera-space depth (the "RGB+D"/"RGB+ED" layout).  If `opac_out` is
+ * non-null it receives opacities * compensation (rasterize_mode="antialiased").
+ * ----------------------------------------------------------------------------------- */
+int mgs_project_color_fwd(int n, const float *means, const float *quats, const float *scales,
+                          const float *opacities, int sh_degree, int coeff_stride,
+                          const float *sh_coeffs, const float *viewmat, const float *K,
+                          int width, int height, float eps2d, float near_plane,
+                          float far_plane, float radius_clip, int32_t *radii, float *means2d,
+                          float *depths, float *conics, float *opac_out, int feat_stride,
+                          float *feats, mgs_stream_t stream);
+
+/* -------------------------------------------------------------------------------------
+ * Tile binning  (gsplat `isect_tiles` with sort=True + `isect_offset_encode`, one camera)
+ *
+ * Produces the depth-ordered per-tile lists: flatten_ids[n_isect] (Gaussian index),
+ * tile_ids[n_isect] (ty*tile_w+tx, ascending) and tile_offsets[n_tiles+1] (first sorted
+ * index of each tile, last entry = n_isect).  Ordering is identical to a stable sort of
+ * the 64-bit keys (tile << 32 | float_bits(depth)) emitted in Gaussian-index order.
+ * isect_ids[capacity] (nullable) receives those int64 keys, with `cam_id` folded in above
+ * the tile bits exactly as gsplat encodes them.
+ *
+ * Internally: 32-bit radix sort of the Gaussians by depth, an exclusive scan of tile
+ * counts in that order, a load-balanced emit, and a radix sort on the tile bits only.
+ *
+ * Workspace: call with workspace == NULL to get the byte count in *workspace_bytes.
+ * tiles_per_gauss[N] nullable.  n_isect, status: device uint32 scalars (status is OR-ed,
+ * never cleared, by the library).
+ * ----------------------------------------------------------------------------------- */
+int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const float *depths,
+                    int tile_size, int tile_w, int tile_h, int cam_id, int n_cams,
+                    uint32_t isect_capacity, int32_t *tiles_per_gauss, uint32_t *n_isect,
+                    uint32_t *tile_ids, int32_t *flatten_ids, int64_t *isect_ids,
+                    int32_t *tile_offsets, uint32_t *status, void *workspace,
+                    size_t *workspace_bytes, mgs_stream_t stream);
+
+/* gsplat `isect_offset_encode`: first sorted index per (cam, tile) from sorted int64 keys.
+ * n_isect is a HOST value here (the operator takes a materialised key tensor).
+ * offsets[n_cams*tile_h*tile_w]. */
+int mgs_isect_offset_encode(uint32_t n_isect, const int64_t *isect_ids, int n_cams,
+                            int tile_w, int tile_h, int32_t *offsets, mgs_stream_t stream);
+
+/* -------------------------------------------------------------------------------------
+ * Tile raster  (gsplat `rasterize_to_pixels` forward / backward, one camera, tile 16)
+ *   means2d[N,2] conics[N,3] feats[N,channels] opacities[N]; background[channels]
+ *   nullable; tile_offsets[tile_h*tile_w + 1]; flatten_ids[n_isect].
+ *   out: render[H,W,channels], alphas[H,W], last_ids[H,W] i32 (sorted-list index of the
+ *   last Gaussian blended into the pixel; needed by the backward).
+ *   channels in 1..MGS_MAX_CHANNELS.
+ * ----------------------------------------------------------------------------------- */
+int mgs_rasterize_fwd(int n, const float *means2d, const float *conics, const float *feats,
+                      const float *opacities, const float *background, int channels,
+                      int width, int height, int tile_w, int tile_h,
+                      const int32_t *tile_offsets, const int32_t *flatten_ids, float *render,
+                      float *alphas, int32_t *last_ids, mgs_stream_t stream);
+
+/*   v_render[H,W,channels], v_alphas[H,W] incoming; v_means2d[N,2] v_conics[N,3]
+ *   v_feats[N,channels] v_opacities[N] are ACCUMULATED into with float atomics
+ *   (zero them first); v_means2d_abs[N,2] nullable (absgrad). */
+int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const float *feats,
+                      const float *opacities, const float *background, int channels,
+                      int width, int height, int tile_w, int tile_h,
+                      const int32_t *tile_offsets, const int32_t *flatten_ids,
+                      const float *alphas, const int32_t *last_ids, const float *v_render,
+                      const float *v_alphas, float *v_means2d, float *v_means2d_abs,
+                      float *v_conics, float *v_feats, float *v_opacities,
+                      mgs_stream_t stream);
+
+/* Fused-colour backward: chain rule of mgs_project_color_fwd.
+ *   v_feats[N,feat_stride] (channel 3, if present, is d/d depth), v_means2d, v_conics,
+ *   v_opac_out (nullable; cotangent of opacities*compensation) ->
+ *   v_means, v_quats, v_scales (+=), v_sh_coeffs[N,K,3] (+= on the active degree),
+ *   v_opacities (+=, nullable). */
+int mgs_project_color_bwd(int n, const float *means, const float *quats, const float *scales,
+                          const float *opacities, int sh_degree, int coeff_stride,
+                          const float *sh_coeffs, const float *viewmat, const float *K,
+                          int width, int height, float eps2d, const int32_t *radii,
+                          const float *conics, int antialiased, int feat_stride,
+                          const float *feats, const float *v_feats, const float *v_means2d,
+                          const float *v_conics, const float *v_depths,
+                          const float *v_opac_out, float *v_means, float *v_quats,
+                          float *v_scales, float *v_sh_coeffs, float *v_opacities,
+                          mgs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGS_H_ */

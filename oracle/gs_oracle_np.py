@@ -1,0 +1,382 @@
+"""NumPy oracle for the 3DGS background-render hot path (TEST INFRASTRUCTURE ONLY).
+
+PARITY UNPINNED.  The reference checkout (/root/reference, Maxwell-Zhao/RoboSimGS @
+2025-10-17) contains no Gaussian-splatting renderer: README.md:75 delegates scene
+reconstruction to Nerfstudio, README.md:29 / :84-85 say the stage that renders the
+exported .ply is unreleased, and nerfstudio / gsplat are neither vendored nor pinned
+(Articulation/requirements.txt:1-18).  This file therefore restates the *published*
+algorithm of the third-party dependency the reference names (nerfstudio `splatfacto` ->
+gsplat 1.x "classic" rasterisation) and is validated
+independently of itself by closed-form cases in tests/test_oracle_closed_form.py.  The
+only reference-pinned piece is the camera convention, `viewmat_from_c2w_opengl`, which
+follows Articulation/utils/nerf2physic_utils.py:10-23 (`project_3d_to_2d`: negate cam-Y
+and cam-Z of w2c) and is checked against vectors generated from that function
+(tests/golden/make_camera_golden.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (robosimgs_amd/) never does.
+
+All functions take a `dtype` (np.float64 for the reference answer, np.float32 to mimic
+device rounding op-by-op without FMA contraction).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ALPHA_MIN = 1.0 / 255.0
+ALPHA_MAX = 0.999
+T_STOP = 1e-4
+
+SH_C0 = 0.2820947917738781
+SH_C1 = 0.48860251190292
+SH_C2 = (0.5462742152960395, -1.092548430592079, 0.9461746957575601,
+         0.3153915652525201)
+SH_C3 = (-0.5900435899266435, 1.445305721320277, -2.285228997322329,
+         0.4570457994644658, 1.865881662950577, 1.119528997770346)
+
+
+# --------------------------------------------------------------------------------------
+# camera convention (the only reference-pinned part)
+# --------------------------------------------------------------------------------------
+def viewmat_from_c2w_opengl(c2w):
+    """OpenGL camera-to-world (nerfstudio `transform_matrix`) -> OpenCV world-to-camera.
+
+    Follows /root/reference/Articulation/utils/nerf2physic_utils.py:14-16: apply
+    inv(c2w) then negate camera Y and Z.  Equivalent to nerfstudio's get_viewmat:
+    R' = R_c2w * diag(1,-1,-1); viewmat = [[R'^T, -R'^T t],[0, 1]].
+    """
+    c2w = np.asarray(c2w, dtype=np.float64)
+    w2c = np.linalg.inv(c2w)
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    return flip @ w2c
+
+
+# --------------------------------------------------------------------------------------
+# A.2 step 1-5: projection
+# --------------------------------------------------------------------------------------
+def quat_to_rotmat(quats, dtype=np.float64):
+    """wxyz quaternion (un-normalised) -> rotation matrix [N,3,3].  A.2 step 1."""
+    q = np.asarray(quats, dtype=dtype)
+    inv_norm = dtype(1.0) / np.sqrt(q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]
+                                    + q[:, 2] * q[:, 2] + q[:, 3] * q[:, 3])
+    w, x, y, z = (q[:, i] * inv_norm for i in range(4))
+    x2, y2, z2 = x * x, y * y, z * z
+    xy, xz, yz = x * y, x * z, y * z
+    wx, wy, wz = w * x, w * y, w * z
+    one, two = dtype(1.0), dtype(2.0)
+    R = np.empty((q.shape[0], 3, 3), dtype=dtype)
+    R[:, 0, 0] = one - two * (y2 + z2)
+    R[:, 0, 1] = two * (xy - wz)
+    R[:, 0, 2] = two * (xz + wy)
+    R[:, 1, 0] = two * (xy + wz)
+    R[:, 1, 1] = one - two * (x2 + z2)
+    R[:, 1, 2] = two * (yz - wx)
+    R[:, 2, 0] = two * (xz - wy)
+    R[:, 2, 1] = two * (yz + wx)
+    R[:, 2, 2] = one - two * (x2 + y2)
+    return R
+
+
+def covar_world(quats, scales, dtype=np.float64):
+    """Sigma = (R S)(R S)^T.  A.2 step 1."""
+    R = quat_to_rotmat(quats, dtype)
+    M = R * np.asarray(scales, dtype=dtype)[:, None, :]
+    return M @ np.swapaxes(M, 1, 2)
+
+
+def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3,
+            near_plane=0.01, far_plane=1e10, radius_clip=0.0, dtype=np.float64):
+    """A.2 steps 1-5 for one camera.
+
+    Returns dict(radii[N] int32, means2d[N,2], depths[N], conics[N,3],
+    compensations[N]); culled Gaussians have radii 0 and zeros elsewhere.
+    """
+    means = np.asarray(means, dtype=dtype)
+    viewmat = np.asarray(viewmat, dtype=dtype)
+    K = np.asarray(K, dtype=dtype)
+    N = means.shape[0]
+    Rcw, tcw = viewmat[:3, :3], viewmat[:3, 3]
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    W, H = dtype(width), dtype(height)
+
+    pc = means @ Rcw.T + tcw                                     # step 2
+    x, y, z = pc[:, 0], pc[:, 1], pc[:, 2]
+    valid = (z >= dtype(near_plane)) & (z <= dtype(far_plane))
+    zs = np.where(valid, z, dtype(1.0))
+
+    cov = covar_world(quats, scales, dtype)
+    cov_c = Rcw[None] @ cov @ Rcw.T[None]
+
+    tanx, tany = dtype(0.5) * W / fx, dtype(0.5) * H / fy        # step 3
+    k03 = dtype(0.3)
+    lim_xp, lim_xn = (W - cx) / fx + k03 * tanx, cx / fx + k03 * tanx
+    lim_yp, lim_yn = (H - cy) / fy + k03 * tany, cy / fy + k03 * tany
+    rz = dtype(1.0) / zs
+    rz2 = rz * rz
+    tx = zs * np.minimum(lim_xp, np.maximum(-lim_xn, x * rz))
+    ty = zs * np.minimum(lim_yp, np.maximum(-lim_yn, y * rz))
+    J = np.zeros((N, 2, 3), dtype=dtype)
+    J[:, 0, 0] = fx * rz
+    J[:, 0, 2] = -fx * tx * rz2
+    J[:, 1, 1] = fy * rz
+    J[:, 1, 2] = -fy * ty * rz2
+    cov2 = J @ cov_c @ np.swapaxes(J, 1, 2)
+    mu = np.stack([fx * x * rz + cx, fy * y * rz + cy], axis=-1)
+
+    a, b, c = cov2[:, 0, 0], cov2[:, 0, 1], cov2[:, 1, 1]       # step 4
+    det0 = a * c - b * b
+    a = a + dtype(eps2d)
+    c = c + dtype(eps2d)
+    det = a * c - b * b
+    valid &= det > 0
+    dets = np.where(det > 0, det, dtype(1.0))
+    comp = np.sqrt(np.maximum(dtype(0.0), det0 / dets))
+    conic = np.stack([c / dets, -b / dets, a / dets], axis=-1)
+
+    m = dtype(0.5) * (a + c)                                     # step 5
+    lam = m + np.sqrt(np.maximum(dtype(0.01), m * m - dets))
+    radius = np.ceil(dtype(3.0) * np.sqrt(lam))
+    valid &= radius > dtype(radius_clip)
+    valid &= ~((mu[:, 0] + radius <= 0) | (mu[:, 0] - radius >= W)
+               | (mu[:, 1] + radius <= 0) | (mu[:, 1] - radius >= H))
+
+    out = {
+        "radii": np.where(valid, radius, 0).astype(np.int32),
+        "means2d": np.where(valid[:, None], mu, 0),
+        "depths": np.where(valid, z, 0),
+        "conics": np.where(valid[:, None], conic, 0),
+        "compensations": np.where(valid, comp, 0),
+    }
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# A.2 step 6: spherical harmonics
+# --------------------------------------------------------------------------------------
+def sh_basis(degree, dirs, dtype=np.float64):
+    """Real SH basis Y_k(d) for unit dirs [N,3] -> [N,(degree+1)^2].  A.2 step 6."""
+    d = np.asarray(dirs, dtype=dtype)
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    K = (degree + 1) ** 2
+    Y = np.empty((d.shape[0], K), dtype=dtype)
+    Y[:, 0] = dtype(SH_C0)
+    if degree >= 1:
+        Y[:, 1] = -dtype(SH_C1) * y
+        Y[:, 2] = dtype(SH_C1) * z
+        Y[:, 3] = -dtype(SH_C1) * x
+    if degree >= 2:
+        z2 = z * z
+        fC1 = x * x - y * y
+        fS1 = dtype(2.0) * x * y
+        t = dtype(SH_C2[1]) * z
+        Y[:, 4] = dtype(SH_C2[0]) * fS1
+        Y[:, 5] = t * y
+        Y[:, 6] = dtype(SH_C2[2]) * z2 - dtype(SH_C2[3])
+        Y[:, 7] = t * x
+        Y[:, 8] = dtype(SH_C2[0]) * fC1
+    if degree >= 3:
+        u = dtype(SH_C3[2]) * z2 + dtype(SH_C3[3])
+        w = dtype(SH_C3[1]) * z
+        fC2 = x * fC1 - y * fS1
+        fS2 = x * fS1 + y * fC1
+        Y[:, 9] = dtype(SH_C3[0]) * fS2
+        Y[:, 10] = w * fS1
+        Y[:, 11] = u * y
+        Y[:, 12] = z * (dtype(SH_C3[4]) * z2 - dtype(SH_C3[5]))
+        Y[:, 13] = u * x
+        Y[:, 14] = w * fC1
+        Y[:, 15] = dtype(SH_C3[0]) * fC2
+    return Y
+
+
+def sh_colors(degree, means, campos, coeffs, dtype=np.float64):
+    """rgb = max(0, 0.5 + sum_k Y_k(normalize(mean - campos)) coeff_k).  coeffs [N,K,3]."""
+    dirs = np.asarray(means, dtype=dtype) - np.asarray(campos, dtype=dtype)[None]
+    n = np.sqrt((dirs * dirs).sum(-1, keepdims=True))
+    dirs = dirs / np.where(n > 0, n, dtype(1.0))
+    Y = sh_basis(degree, dirs, dtype)
+    K = (degree + 1) ** 2
+    col = np.einsum("nk,nkc->nc", Y, np.asarray(coeffs, dtype=dtype)[:, :K, :])
+    return np.maximum(col + dtype(0.5), dtype(0.0))
+
+
+def campos_from_viewmat(viewmat):
+    """Camera centre in world space = (viewmat^-1)[:3,3]."""
+    v = np.asarray(viewmat, dtype=np.float64)
+    return -v[:3, :3].T @ v[:3, 3]
+
+
+# --------------------------------------------------------------------------------------
+# A.2 steps 7-8: tile intersection, sort, ranges
+# --------------------------------------------------------------------------------------
+def tile_rects(means2d, radii, tile_size, tile_w, tile_h, dtype=np.float64):
+    """Per-Gaussian tile rectangle [x0,x1) x [y0,y1) (A.2 step 7)."""
+    mu = np.asarray(means2d, dtype=dtype)
+    r = np.asarray(radii).astype(dtype)
+    ts = dtype(tile_size)
+    tr = r / ts
+    txc, tyc = mu[:, 0] / ts, mu[:, 1] / ts
+    x0 = np.clip(np.floor(txc - tr), 0, tile_w).astype(np.int64)
+    x1 = np.clip(np.ceil(txc + tr), 0, tile_w).astype(np.int64)
+    y0 = np.clip(np.floor(tyc - tr), 0, tile_h).astype(np.int64)
+    y1 = np.clip(np.ceil(tyc + tr), 0, tile_h).astype(np.int64)
+    vis = np.asarray(radii) > 0
+    x0, x1, y0, y1 = (np.where(vis, v, 0) for v in (x0, x1, y0, y1))
+    return x0, x1, y0, y1
+
+
+def isect_tiles(means2d, radii, depths, tile_size, tile_w, tile_h, cam=0,
+                n_cams=1, dtype=np.float64):
+    """A.2 steps 7-8 for one camera: returns (tiles_per_gauss, isect_ids_sorted int64,
+    flatten_ids_sorted int32).  Depth bits come from the float32 value of `depths`."""
+    x0, x1, y0, y1 = tile_rects(means2d, radii, tile_size, tile_w, tile_h, dtype)
+    tpg = ((x1 - x0) * (y1 - y0)).astype(np.int32)
+    n_tiles = tile_w * tile_h
+    tile_bits = int(np.floor(np.log2(n_tiles))) + 1 if n_tiles > 0 else 0
+    dbits = np.asarray(depths, dtype=np.float32).view(np.uint32).astype(np.int64)
+    # emit in Gaussian-index order, row-major (y outer, x inner) inside each rectangle
+    cnt = tpg.astype(np.int64)
+    total = int(cnt.sum())
+    vals = np.repeat(np.arange(len(cnt), dtype=np.int64), cnt)
+    start = np.cumsum(cnt) - cnt
+    local = np.arange(total, dtype=np.int64) - np.repeat(start, cnt)
+    wrect = np.maximum(x1 - x0, 1)
+    tid = (y0[vals] + local // wrect[vals]) * tile_w + x0[vals] + local % wrect[vals]
+    keys = (((np.int64(cam) << tile_bits) | tid) << 32) | dbits[vals]
+    order = np.argsort(keys, kind="stable")
+    return tpg, keys[order], vals[order].astype(np.int32)
+
+
+def isect_offsets(isect_ids, n_cams, tile_w, tile_h):
+    """First sorted index of each (cam, tile) -> int32 [C, th, tw].  A.2 step 8."""
+    n_tiles = tile_w * tile_h
+    tile_bits = int(np.floor(np.log2(n_tiles))) + 1
+    tid = (np.asarray(isect_ids, dtype=np.int64) >> 32)
+    cam = tid >> tile_bits
+    flat = cam * n_tiles + (tid & ((1 << tile_bits) - 1))
+    offs = np.searchsorted(flat, np.arange(n_cams * n_tiles), side="left")
+    return offs.astype(np.int32).reshape(n_cams, tile_h, tile_w)
+
+
+# --------------------------------------------------------------------------------------
+# A.2 step 9: forward blend (literal sequential loop; small cases only)
+# --------------------------------------------------------------------------------------
+def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, height,
+              tile_size=16, background=None, dtype=np.float64, exp=None):
+    """Per-tile front-to-back alpha compositing for ONE camera.
+
+    colors [N,D]; offsets [th,tw] int32 (first sorted index per tile); the range of
+    tile t ends at offsets.flat[t+1] (or n_isect for the last tile).
+    Returns (image[H,W,D], alpha[H,W], last_ids[H,W] int32, stats dict).
+    `last_ids` is the sorted-list index of the last Gaussian that contributed (0-based,
+    global index into flatten_ids); pixels with no contribution hold range_start - 1 ...
+    they hold the value `range_start` is NOT touched: we use 0 like an all-zero init.
+    """
+    if exp is None:
+        exp = np.exp
+    mu = np.asarray(means2d, dtype=dtype)
+    con = np.asarray(conics, dtype=dtype)
+    col = np.asarray(colors, dtype=dtype)
+    opa = np.asarray(opacities, dtype=dtype)
+    D = col.shape[1]
+    th, tw = offsets.shape
+    n_isect = len(flatten_ids)
+    flat_offs = np.concatenate([offsets.reshape(-1), [n_isect]]).astype(np.int64)
+    img = np.zeros((height, width, D), dtype=dtype)
+    alpha_img = np.zeros((height, width), dtype=dtype)
+    last = np.zeros((height, width), dtype=np.int32)
+    n_eval = 0
+    n_contrib = 0
+    half, one = dtype(0.5), dtype(1.0)
+    for ty in range(th):
+        for tx in range(tw):
+            s, e = flat_offs[ty * tw + tx], flat_offs[ty * tw + tx + 1]
+            y_lo, y_hi = ty * tile_size, min((ty + 1) * tile_size, height)
+            x_lo, x_hi = tx * tile_size, min((tx + 1) * tile_size, width)
+            if y_lo >= y_hi or x_lo >= x_hi:
+                continue
+            py, px = np.meshgrid(np.arange(y_lo, y_hi, dtype=dtype) + half,
+                                 np.arange(x_lo, x_hi, dtype=dtype) + half,
+                                 indexing="ij")
+            T = np.ones_like(px)
+            C = np.zeros(px.shape + (D,), dtype=dtype)
+            done = np.zeros(px.shape, dtype=bool)
+            cur_last = np.zeros(px.shape, dtype=np.int32)
+            for i in range(s, e):
+                if done.all():
+                    break
+                g = flatten_ids[i]
+                dx = mu[g, 0] - px
+                dy = mu[g, 1] - py
+                sigma = half * (con[g, 0] * dx * dx + con[g, 2] * dy * dy) \
+                    + con[g, 1] * dx * dy
+                a = np.minimum(dtype(ALPHA_MAX), opa[g] * exp(-sigma))
+                ok = (~done) & (sigma >= 0) & (a >= dtype(ALPHA_MIN))
+                n_eval += int((~done).sum())
+                Tn = T * (one - a)
+                stop = ok & (Tn <= dtype(T_STOP))
+                done |= stop
+                acc = ok & ~stop
+                w = np.where(acc, a * T, 0)
+                C += w[..., None] * col[g][None, None, :]
+                T = np.where(acc, Tn, T)
+                cur_last = np.where(acc, np.int32(i), cur_last)
+                n_contrib += int(acc.sum())
+            if background is not None:
+                C = C + T[..., None] * np.asarray(background, dtype=dtype)[None, None]
+            img[y_lo:y_hi, x_lo:x_hi] = C
+            alpha_img[y_lo:y_hi, x_lo:x_hi] = one - T
+            last[y_lo:y_hi, x_lo:x_hi] = cur_last
+    return img, alpha_img, last, {"pair_evals": n_eval, "contribs": n_contrib}
+
+
+# --------------------------------------------------------------------------------------
+# whole frame
+# --------------------------------------------------------------------------------------
+def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, height,
+           sh_degree=None, tile_size=16, render_mode="RGB", eps2d=0.3,
+           near_plane=0.01, far_plane=1e10, radius_clip=0.0, background=None,
+           rasterize_mode="classic", dtype=np.float64):
+    """Full single-camera frame following SURVEY.md A.1/A.2.  Inputs are post-activation
+    (scales = exp(log_s), opacities = sigmoid(logit)).  Returns (colors[H,W,D],
+    alpha[H,W,1], meta)."""
+    tile_w = -(-width // tile_size)
+    tile_h = -(-height // tile_size)
+    p = project(means, quats, scales, viewmat, K, width, height, eps2d, near_plane,
+                far_plane, radius_clip, dtype)
+    opac = np.asarray(opacities, dtype=dtype)
+    if rasterize_mode == "antialiased":
+        opac = opac * p["compensations"]
+    if sh_degree is None:
+        rgb = np.asarray(sh_or_colors, dtype=dtype)
+    else:
+        rgb = sh_colors(sh_degree, means, campos_from_viewmat(viewmat), sh_or_colors,
+                        dtype)
+        rgb = np.where((p["radii"] > 0)[:, None], rgb, 0)
+    depth = p["depths"][:, None]
+    if render_mode in ("RGB",):
+        feats = rgb
+    elif render_mode in ("D", "ED"):
+        feats = depth
+    elif render_mode in ("RGB+D", "RGB+ED"):
+        feats = np.concatenate([rgb, depth], axis=-1)
+    else:
+        raise ValueError(render_mode)
+    tpg, isect_ids, flatten_ids = isect_tiles(p["means2d"], p["radii"], p["depths"],
+                                              tile_size, tile_w, tile_h, dtype=dtype)
+    offs = isect_offsets(isect_ids, 1, tile_w, tile_h)[0]
+    bg = None
+    if background is not None:
+        bg = np.asarray(background, dtype=dtype)
+    img, alpha, last, stats = rasterize(p["means2d"], p["conics"], feats, opac,
+                                        flatten_ids, offs, width, height, tile_size,
+                                        bg, dtype)
+    if render_mode in ("ED", "RGB+ED"):
+        img = img.copy()
+        img[..., -1] = img[..., -1] / np.maximum(alpha, dtype(1e-10))
+    meta = dict(p)
+    meta.update(tiles_per_gauss=tpg, isect_ids=isect_ids, flatten_ids=flatten_ids,
+                isect_offsets=offs, last_ids=last, colors=rgb, opacities=opac,
+                tile_width=tile_w, tile_height=tile_h, n_isect=len(flatten_ids),
+                n_vis=int((p["radii"] > 0).sum()), **stats)
+    return img, alpha[..., None], meta

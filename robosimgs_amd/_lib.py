@@ -1,0 +1,90 @@
+"""ctypes binding of libmgs.so (the C ABI declared in include/mgs.h).
+
+There is no fallback: if the shared library is missing or fails to load, importing the ops
+raises.  torch is imported first so that libmgs.so binds to the HIP runtime torch already
+loaded (same soname, libamdhip64.so.7) and shares its streams and allocations.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p, POINTER
+
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmgs.so")
+
+MGS_STATUS_ISECT_OVERFLOW = 1
+
+
+class MgsError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise MgsError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no "
+            "CPU or PyTorch fallback for the render path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    p, i, f, u32 = c_void_p, c_int, c_float, c_uint32
+    sig = {
+        "mgs_version": ([], c_int),
+        "mgs_last_error_string": ([], c_char_p),
+        "mgs_projection_fwd": ([i, p, p, p, p, p, i, i, f, f, f, f, p, p, p, p, p, p], c_int),
+        "mgs_projection_bwd": ([i, p, p, p, p, p, i, i, f, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
+        "mgs_sh_fwd": ([i, i, i, p, p, p, p, p], c_int),
+        "mgs_sh_bwd": ([i, i, i, p, p, p, p, p, p, p], c_int),
+        "mgs_project_color_fwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, f, f, f, p, p, p, p, p, i, p, p], c_int),
+        "mgs_project_color_bwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
+        "mgs_isect_tiles": ([i, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
+        "mgs_rasterize_fwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p], c_int),
+        "mgs_rasterize_bwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_projection_fwd", "mgs_projection_bwd",
+           "mgs_sh_fwd", "mgs_sh_bwd", "mgs_project_color_fwd", "mgs_project_color_bwd",
+           "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd"]
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mgs_last_error_string().decode("utf-8", "replace")
+        raise MgsError(f"{what} failed with status {rc}: {msg}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_handle() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MgsError("the render path runs on the GPU only: got a CPU tensor "
+                           "(there is no CPU fallback; see oracle/ for the test-only checker)")

@@ -1,0 +1,55 @@
+// mgs_common.h -- host-side plumbing shared by the libmgs.so translation units.
+#ifndef MGS_COMMON_H_
+#define MGS_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mgs.h"
+
+namespace mgs {
+
+// thread-local last-error text behind mgs_last_error_string()
+char* error_buffer();
+int set_error(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return set_error((int)e, "%s: launch failed: %s", what, hipGetErrorString(e));
+  return MGS_OK;
+}
+
+inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define MGS_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return ::mgs::set_error(MGS_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+  } while (0)
+
+// ---- wave64 helpers -----------------------------------------------------------------
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ unsigned mask_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+#endif
+
+// ---- internal launchers shared between translation units ---------------------------------
+// Radix sort of (key, value) uint32 pairs on bits [0, key_bits) with the element count read
+// from device memory.  Buffers a/b alternate; the sorted result ends in (keys_out, vals_out).
+// temp: radix_sort_temp_bytes(capacity).
+size_t radix_sort_temp_bytes(uint32_t capacity);
+int radix_sort_pairs(const uint32_t* n_dev, uint32_t capacity, int key_bits, uint32_t* keys_in,
+                     uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, void* temp,
+                     hipStream_t stream);
+
+}  // namespace mgs
+#endif

@@ -1,0 +1,94 @@
+// raster_common.h -- pieces shared by the forward and backward tile raster kernels.
+//
+// Geometry.  One wave64 owns one 16x16 tile.  Lane l holds FOUR pixels, one in each 8x8
+// quadrant k of the tile: (x, y) = (8*(k&1) + (l&7), 8*(k>>1) + (l>>3)).  A Gaussian's
+// parameters are therefore fetched once per 256 pixel evaluations, the four per-lane pixel
+// chains give the VALU independent work, and a quadrant whose 64 pixels cannot be touched
+// by a Gaussian (or are all finished) is skipped with a scalar branch.
+//
+// Queue.  The tile's depth-ordered list is consumed in batches of 64 (one Gaussian per
+// lane).  Each lane tests its Gaussian against the four quadrants with an EXACT minimum of
+// the conic's quadratic form over the quadrant's pixel-centre rectangle; Gaussians that
+// cannot reach alpha >= 1/255 anywhere in the tile are dropped, survivors are compacted
+// into a wave-private LDS queue with ballot + mbcnt, and the wave then walks the queue with
+// broadcast ds_read_b128.  Dropping a Gaussian never changes a pixel: every pixel it would
+// have evaluated fails the alpha >= 1/255 test of A.2 step 9.  No workgroup barrier exists
+// anywhere in the kernel.
+#ifndef MGS_RASTER_COMMON_H_
+#define MGS_RASTER_COMMON_H_
+
+#include "mgs_common.h"
+
+namespace mgs {
+
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kAlphaMax = 0.999f;
+constexpr float kTStop = 1e-4f;
+constexpr int kQueue = 64;
+
+struct QuadRect { float x0, x1, y0, y1; };   // pixel-centre extents of an 8x8 quadrant
+
+// 1D clamped minimum of the quadratic along one rectangle edge.
+//   fixed offset e (edge coordinate - mean) on the "u" axis with weight wu,
+//   free offset in [lo, hi] on the "v" axis with weight wv, cross term b.
+__device__ __forceinline__ float edge_min_sigma(float e, float wu, float wv, float b,
+                                                float inv_wv, float lo, float hi) {
+  float v = fminf(fmaxf(-b * e * inv_wv, lo), hi);
+  return 0.5f * (wu * e * e + wv * v * v) + b * e * v;
+}
+
+// min over the rectangle of 0.5*(a dx^2 + c dy^2) + b dx dy, (dx,dy) = p - mean.
+__device__ __forceinline__ float rect_min_sigma(float mx, float my, float a, float b, float c,
+                                                float inv_a, float inv_c, const QuadRect& r) {
+  float lx = r.x0 - mx, hx = r.x1 - mx, ly = r.y0 - my, hy = r.y1 - my;
+  if (lx <= 0.f && hx >= 0.f && ly <= 0.f && hy >= 0.f) return 0.f;
+  float s0 = edge_min_sigma(lx, a, c, b, inv_c, ly, hy);
+  float s1 = edge_min_sigma(hx, a, c, b, inv_c, ly, hy);
+  float s2 = edge_min_sigma(ly, c, a, b, inv_a, lx, hx);
+  float s3 = edge_min_sigma(hy, c, a, b, inv_a, lx, hx);
+  return fminf(fminf(s0, s1), fminf(s2, s3));
+}
+
+// Bit k set <=> the Gaussian may reach alpha >= 1/255 at some pixel centre of quadrant k.
+// Conservative by `slack` (fp32 rounding of both this test and the per-pixel sigma).
+__device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float a, float b, float c,
+                                                  float opac, float tile_x, float tile_y) {
+  if (!(opac >= kAlphaMin)) return 0u;           // alpha <= opac < 1/255 everywhere
+  float thr = __logf(255.0f * opac);
+  float inv_a = 1.0f / a, inv_c = 1.0f / c;
+  float fx = fmaxf(fabsf(tile_x - mx), fabsf(tile_x + 16.f - mx));
+  float fy = fmaxf(fabsf(tile_y - my), fabsf(tile_y + 16.f - my));
+  float slack = 0.05f + 4e-6f * (fabsf(a) + fabsf(c) + 2.f * fabsf(b)) * (fx * fx + fy * fy);
+  float lim = thr + slack;
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    QuadRect r;
+    r.x0 = tile_x + 8.f * (k & 1) + 0.5f;
+    r.x1 = r.x0 + 7.f;
+    r.y0 = tile_y + 8.f * (k >> 1) + 0.5f;
+    r.y1 = r.y0 + 7.f;
+    float s = rect_min_sigma(mx, my, a, b, c, inv_a, inv_c, r);
+    if (!(s > lim)) m |= 1u << k;                // NaN keeps the quadrant
+  }
+  return m;
+}
+
+// full-wave sum: result valid in lane 63
+__device__ __forceinline__ float wave_reduce_to_lane63(float v) {
+  int i;
+#define MGS_DPP_ADD(CTRL, RMASK)                                                               \
+  i = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RMASK, 0xf, false);              \
+  v += __int_as_float(i);
+  MGS_DPP_ADD(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  MGS_DPP_ADD(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  MGS_DPP_ADD(0x141, 0xf)   // row_half_mirror
+  MGS_DPP_ADD(0x140, 0xf)   // row_mirror
+  MGS_DPP_ADD(0x142, 0xa)   // row_bcast15 -> rows 1,3
+  MGS_DPP_ADD(0x143, 0xc)   // row_bcast31 -> rows 2,3
+#undef MGS_DPP_ADD
+  return v;
+}
+
+}  // namespace mgs
+#endif

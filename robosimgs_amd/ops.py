@@ -1,0 +1,413 @@
+"""Stage operators of the render path, gsplat-1.x-compatible signatures (SURVEY.md 8(b),
+Appendix A.1), each a thin torch wrapper over one C-ABI entry point of libmgs.so.
+
+    fully_fused_projection   -> mgs_projection_fwd / mgs_projection_bwd
+    spherical_harmonics      -> mgs_sh_fwd / mgs_sh_bwd
+    isect_tiles              -> mgs_isect_tiles
+    isect_offset_encode      -> mgs_isect_offset_encode
+    rasterize_to_pixels      -> mgs_rasterize_fwd / mgs_rasterize_bwd
+
+Inputs are post-activation fp32 CUDA(HIP) tensors; ids are int32, keys int64.  All kernels
+are enqueued on torch's current stream.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import check, ptr, require_device, stream_handle
+
+TILE_SIZE = 16
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ======================================================================================
+# single-camera raw calls (no autograd); used by the operators below and by rendering.py
+# ======================================================================================
+def projection_fwd_raw(means, quats, scales, viewmat, K, width, height, eps2d, near_plane,
+                       far_plane, radius_clip, calc_compensations):
+    n = means.shape[0]
+    dev = means.device
+    radii = torch.empty(n, dtype=torch.int32, device=dev)
+    means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    depths = torch.empty(n, dtype=torch.float32, device=dev)
+    conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    comp = torch.empty(n, dtype=torch.float32, device=dev) if calc_compensations else None
+    check(_lib.lib().mgs_projection_fwd(n, ptr(means), ptr(quats), ptr(scales), ptr(viewmat),
+                                        ptr(K), width, height, eps2d, near_plane, far_plane,
+                                        radius_clip, ptr(radii), ptr(means2d), ptr(depths),
+                                        ptr(conics), ptr(comp), stream_handle()),
+          "mgs_projection_fwd")
+    return radii, means2d, depths, conics, comp
+
+
+def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmat, K,
+                          width, height, eps2d, near_plane, far_plane, radius_clip,
+                          antialiased, with_depth):
+    n = means.shape[0]
+    dev = means.device
+    radii = torch.empty(n, dtype=torch.int32, device=dev)
+    means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    depths = torch.empty(n, dtype=torch.float32, device=dev)
+    conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    opac = torch.empty(n, dtype=torch.float32, device=dev) if antialiased else None
+    stride = 4 if with_depth else 3
+    feats = torch.empty(n, stride, dtype=torch.float32, device=dev)
+    check(_lib.lib().mgs_project_color_fwd(
+        n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), sh_degree, sh_coeffs.shape[1],
+        ptr(sh_coeffs), ptr(viewmat), ptr(K), width, height, eps2d, near_plane, far_plane,
+        radius_clip, ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(opac), stride,
+        ptr(feats), stream_handle()), "mgs_project_color_fwd")
+    return radii, means2d, depths, conics, opac, feats
+
+
+class TileLists:
+    """Depth-ordered per-tile lists of one camera (device resident, capacity sized)."""
+    __slots__ = ("n_isect", "tile_ids", "flatten_ids", "tile_offsets", "tiles_per_gauss",
+                 "isect_ids", "status", "capacity")
+
+
+_workspaces: dict = {}
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    """One growing scratch tensor per (device, stream).  Stream-ordered reuse is safe because
+    every consumer is enqueued on the same stream."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream,
+           torch.cuda.is_current_stream_capturing())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_id=0, n_cams=1,
+                    want_isect_ids=False, want_tiles_per_gauss=True) -> TileLists:
+    n = means2d.shape[0]
+    dev = means2d.device
+    L = _lib.lib()
+    out = TileLists()
+    out.capacity = int(capacity)
+    out.n_isect = torch.empty(1, dtype=torch.int32, device=dev)
+    out.status = torch.zeros(1, dtype=torch.int32, device=dev)
+    out.tile_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
+    out.flatten_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
+    out.tile_offsets = torch.empty(tile_w * tile_h + 1, dtype=torch.int32, device=dev)
+    out.tiles_per_gauss = (torch.empty(n, dtype=torch.int32, device=dev)
+                           if want_tiles_per_gauss else None)
+    out.isect_ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_isect_ids else None
+    nbytes = ctypes.c_size_t(0)
+    args = [n, ptr(means2d), ptr(radii), ptr(depths), TILE_SIZE, tile_w, tile_h, cam_id, n_cams,
+            capacity, ptr(out.tiles_per_gauss), ptr(out.n_isect), ptr(out.tile_ids),
+            ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.status)]
+    check(L.mgs_isect_tiles(*args, None, ctypes.byref(nbytes), stream_handle()),
+          "mgs_isect_tiles(size query)")
+    ws = _workspace(nbytes.value, dev)
+    nbytes = ctypes.c_size_t(ws.numel())
+    check(L.mgs_isect_tiles(*args, ptr(ws), ctypes.byref(nbytes), stream_handle()),
+          "mgs_isect_tiles")
+    return out
+
+
+def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
+                      tile_h, tile_offsets, flatten_ids, out=None):
+    n = means2d.shape[0]
+    ch = feats.shape[-1]
+    dev = means2d.device
+    if out is None:
+        render = torch.empty(height, width, ch, dtype=torch.float32, device=dev)
+        alphas = torch.empty(height, width, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+    else:
+        render, alphas, last_ids = out
+    check(_lib.lib().mgs_rasterize_fwd(n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities),
+                                       ptr(background), ch, width, height, tile_w, tile_h,
+                                       ptr(tile_offsets), ptr(flatten_ids), ptr(render),
+                                       ptr(alphas), ptr(last_ids), stream_handle()),
+          "mgs_rasterize_fwd")
+    return render, alphas, last_ids
+
+
+def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
+                      tile_h, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas,
+                      absgrad=False, accum=None):
+    """Returns (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None).  `accum`
+    supplies pre-zeroed / partially accumulated output buffers (float atomics add into them)."""
+    n = means2d.shape[0]
+    ch = feats.shape[-1]
+    dev = means2d.device
+    if accum is None:
+        v_means2d = torch.zeros(n, 2, dtype=torch.float32, device=dev)
+        v_conics = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        v_feats = torch.zeros(n, ch, dtype=torch.float32, device=dev)
+        v_opac = torch.zeros(n, dtype=torch.float32, device=dev)
+        v_abs = torch.zeros(n, 2, dtype=torch.float32, device=dev) if absgrad else None
+    else:
+        v_means2d, v_conics, v_feats, v_opac, v_abs = accum
+    check(_lib.lib().mgs_rasterize_bwd(
+        n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities), ptr(background), ch, width,
+        height, tile_w, tile_h, ptr(tile_offsets), ptr(flatten_ids), ptr(alphas), ptr(last_ids),
+        ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats),
+        ptr(v_opac), stream_handle()), "mgs_rasterize_bwd")
+    return v_means2d, v_conics, v_feats, v_opac, v_abs
+
+
+# ======================================================================================
+# gsplat-compatible operators (multi-camera, autograd)
+# ======================================================================================
+class _Projection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, calc_compensations):
+        C = viewmats.shape[0]
+        outs = [projection_fwd_raw(means, quats, scales, viewmats[c], Ks[c], width, height,
+                                   eps2d, near_plane, far_plane, radius_clip,
+                                   calc_compensations) for c in range(C)]
+        radii = torch.stack([o[0] for o in outs])
+        means2d = torch.stack([o[1] for o in outs])
+        depths = torch.stack([o[2] for o in outs])
+        conics = torch.stack([o[3] for o in outs])
+        comps = torch.stack([o[4] for o in outs]) if calc_compensations else None
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics, comps)
+        ctx.dims = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics, comps
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps):
+        means, quats, scales, viewmats, Ks, radii, conics, comps = ctx.saved_tensors
+        width, height, eps2d = ctx.dims
+        n, C = means.shape[0], viewmats.shape[0]
+        v_means = torch.zeros_like(means)
+        v_quats = torch.zeros_like(quats)
+        v_scales = torch.zeros_like(scales)
+        want_view = ctx.needs_input_grad[3]
+        v_viewmats = torch.zeros_like(viewmats) if want_view else None
+        v_means2d, v_depths, v_conics = _f32c(v_means2d), _f32c(v_depths), _f32c(v_conics)
+        v_comps = _f32c(v_comps) if comps is not None else None
+        for c in range(C):
+            check(_lib.lib().mgs_projection_bwd(
+                n, ptr(means), ptr(quats), ptr(scales), ptr(viewmats[c]), ptr(Ks[c]), width,
+                height, eps2d, ptr(radii[c]), ptr(conics[c]),
+                ptr(comps[c]) if comps is not None else None,
+                ptr(v_means2d[c]), ptr(v_depths[c]), ptr(v_conics[c]),
+                ptr(v_comps[c]) if v_comps is not None else None, ptr(v_means), ptr(v_quats),
+                ptr(v_scales), ptr(v_viewmats[c]) if want_view else None, stream_handle()),
+                "mgs_projection_bwd")
+        return (v_means, v_quats, v_scales, v_viewmats, None, None, None, None, None, None,
+                None, None)
+
+
+def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Tensor,
+                           scales: Tensor, viewmats: Tensor, Ks: Tensor, width: int,
+                           height: int, eps2d: float = 0.3, near_plane: float = 0.01,
+                           far_plane: float = 1e10, radius_clip: float = 0.0,
+                           packed: bool = False, sparse_grad: bool = False,
+                           calc_compensations: bool = False
+                           ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """World -> screen EWA projection of N Gaussians for C cameras.
+    Returns radii [C,N] i32, means2d [C,N,2], depths [C,N], conics [C,N,3],
+    compensations [C,N] | None."""
+    if covars is not None:
+        raise NotImplementedError("precomputed covariances are not supported; pass quats+scales")
+    if packed:
+        raise NotImplementedError("packed=True is not supported (nerfstudio uses packed=False)")
+    require_device(means, quats, scales, viewmats, Ks)
+    means, quats, scales = _f32c(means), _f32c(quats), _f32c(scales)
+    viewmats, Ks = _f32c(viewmats), _f32c(Ks)
+    if means.dim() != 2 or means.shape[1] != 3 or quats.shape != (means.shape[0], 4) \
+            or scales.shape != means.shape:
+        raise ValueError("expected means [N,3], quats [N,4], scales [N,3]")
+    if viewmats.dim() != 3 or viewmats.shape[1:] != (4, 4) or Ks.shape != (viewmats.shape[0], 3, 3):
+        raise ValueError("expected viewmats [C,4,4], Ks [C,3,3]")
+    return _Projection.apply(means, quats, scales, viewmats, Ks, int(width), int(height),
+                             float(eps2d), float(near_plane), float(far_plane),
+                             float(radius_clip), bool(calc_compensations))
+
+
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, dirs, coeffs, masks):
+        n = dirs.shape[0]
+        colors = torch.empty(n, 3, dtype=torch.float32, device=dirs.device)
+        check(_lib.lib().mgs_sh_fwd(n, degree, coeffs.shape[1], ptr(dirs), ptr(coeffs), ptr(masks),
+                                    ptr(colors), stream_handle()), "mgs_sh_fwd")
+        ctx.save_for_backward(dirs, coeffs, masks)
+        ctx.degree = degree
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        dirs, coeffs, masks = ctx.saved_tensors
+        n = dirs.shape[0]
+        v_coeffs = torch.empty_like(coeffs)
+        v_dirs = torch.empty_like(dirs) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().mgs_sh_bwd(n, ctx.degree, coeffs.shape[1], ptr(dirs), ptr(coeffs),
+                                    ptr(masks), ptr(_f32c(v_colors)), ptr(v_coeffs), ptr(v_dirs),
+                                    stream_handle()), "mgs_sh_bwd")
+        return None, v_dirs, v_coeffs, None
+
+
+def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
+                        masks: Optional[Tensor] = None) -> Tensor:
+    """colors[...,3] = sum_k Y_k(normalize(dirs)) coeffs[...,k,:] for k < (degrees_to_use+1)^2."""
+    require_device(dirs, coeffs, masks)
+    if not 0 <= degrees_to_use <= 3:
+        raise ValueError(f"degrees_to_use={degrees_to_use} outside 0..3")
+    if coeffs.shape[-2] < (degrees_to_use + 1) ** 2:
+        raise ValueError("coeffs holds fewer than (degrees_to_use+1)^2 coefficients")
+    if dirs.shape[:-1] != coeffs.shape[:-2] or dirs.shape[-1] != 3 or coeffs.shape[-1] != 3:
+        raise ValueError("expected dirs [...,3] and coeffs [...,K,3] with equal batch dims")
+    batch = dirs.shape[:-1]
+    d = _f32c(dirs).reshape(-1, 3)
+    c = _f32c(coeffs).reshape(-1, coeffs.shape[-2], 3)
+    m = None
+    if masks is not None:
+        m = masks.reshape(-1).to(torch.uint8).contiguous()
+    return _SphericalHarmonics.apply(int(degrees_to_use), d, c, m).reshape(*batch, 3)
+
+
+@torch.no_grad()
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
+                tile_width: int, tile_height: int, sort: bool = True, packed: bool = False,
+                n_cameras: Optional[int] = None, camera_ids: Optional[Tensor] = None,
+                gaussian_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """Tile intersection + sort.  Returns tiles_per_gauss [C,N] i32, isect_ids [n_isects] i64
+    (cam | tile | depth bits, ascending), flatten_ids [n_isects] i32 (cam*N + gaussian).
+    Reads the intersection count back to size the outputs (one sync, as the reference
+    operator does); the render path in rendering.py avoids that with a capacity."""
+    if packed or not sort:
+        raise NotImplementedError("only packed=False, sort=True is supported")
+    if tile_size != TILE_SIZE:
+        raise NotImplementedError(f"tile_size must be {TILE_SIZE}")
+    require_device(means2d, radii, depths)
+    C, N = means2d.shape[0], means2d.shape[1]
+    means2d, depths = _f32c(means2d), _f32c(depths)
+    radii = radii.to(torch.int32).contiguous()
+    tpg, keys, ids = [], [], []
+    for c in range(C):
+        cap = max(1, int(_upper_bound_isects(radii[c], tile_width, tile_height)))
+        tl = isect_tiles_raw(means2d[c], radii[c], depths[c], tile_width, tile_height, cap, c, C,
+                             want_isect_ids=True)
+        n = int(tl.n_isect.item())
+        tpg.append(tl.tiles_per_gauss)
+        keys.append(tl.isect_ids[:n])
+        ids.append(tl.flatten_ids[:n] + c * N if c else tl.flatten_ids[:n])
+    return torch.stack(tpg), torch.cat(keys), torch.cat(ids)
+
+
+def _upper_bound_isects(radii_c: Tensor, tile_w: int, tile_h: int) -> int:
+    """Cheap device-side bound: sum over visible Gaussians of min((2r/16+2)^2, tiles)."""
+    r = radii_c.clamp_min(0).to(torch.float32)
+    side = torch.floor(2.0 * r / TILE_SIZE) + 2.0
+    per = torch.minimum(side.clamp_max(tile_w) * side.clamp_max(tile_h),
+                        torch.tensor(float(tile_w * tile_h), device=r.device))
+    return int(torch.where(radii_c > 0, per, torch.zeros_like(per)).sum().item())
+
+
+@torch.no_grad()
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int,
+                        tile_height: int) -> Tensor:
+    """First sorted index of every (camera, tile): int32 [C, tile_height, tile_width]."""
+    require_device(isect_ids)
+    isect_ids = isect_ids.contiguous()
+    out = torch.empty(n_cameras, tile_height, tile_width, dtype=torch.int32,
+                      device=isect_ids.device)
+    check(_lib.lib().mgs_isect_offset_encode(isect_ids.numel(), ptr(isect_ids), n_cameras,
+                                             tile_width, tile_height, ptr(out), stream_handle()),
+          "mgs_isect_offset_encode")
+    return out
+
+
+class _RasterizeToPixels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height,
+                offsets_ext, flatten_ids, absgrad):
+        C, N, ch = colors.shape
+        tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
+        n_tiles = tile_w * tile_h
+        dev = means2d.device
+        render = torch.empty(C, height, width, ch, dtype=torch.float32, device=dev)
+        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        for c in range(C):
+            # ids in flatten_ids are cam*N + gaussian: hand the kernels the flat [C*N,...] views
+            rasterize_fwd_raw(means2d.view(C * N, 2), conics.view(C * N, 3),
+                              colors.view(C * N, ch), opacities.view(C * N),
+                              backgrounds[c] if backgrounds is not None else None, width, height,
+                              tile_w, tile_h, offsets_ext[c * n_tiles:], flatten_ids,
+                              out=(render[c], alphas[c], last_ids[c]))
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets_ext,
+                              flatten_ids, alphas, last_ids)
+        ctx.dims = (width, height, tile_w, tile_h, absgrad)
+        return render, alphas.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas):
+        (means2d, conics, colors, opacities, backgrounds, offsets_ext, flatten_ids, alphas,
+         last_ids) = ctx.saved_tensors
+        width, height, tile_w, tile_h, absgrad = ctx.dims
+        C, N, ch = colors.shape
+        n_tiles = tile_w * tile_h
+        dev = means2d.device
+        v_render = _f32c(v_render)
+        v_alphas = _f32c(v_alphas).reshape(C, height, width)
+        acc = (torch.zeros(C * N, 2, device=dev), torch.zeros(C * N, 3, device=dev),
+               torch.zeros(C * N, ch, device=dev), torch.zeros(C * N, device=dev),
+               torch.zeros(C * N, 2, device=dev) if absgrad else None)
+        for c in range(C):
+            rasterize_bwd_raw(means2d.view(C * N, 2), conics.view(C * N, 3),
+                              colors.view(C * N, ch), opacities.view(C * N),
+                              backgrounds[c] if backgrounds is not None else None, width, height,
+                              tile_w, tile_h, offsets_ext[c * n_tiles:], flatten_ids, alphas[c],
+                              last_ids[c], v_render[c], v_alphas[c], absgrad, accum=acc)
+        v_bg = None
+        if backgrounds is not None and ctx.needs_input_grad[4]:
+            v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
+        if absgrad:
+            means2d.absgrad = acc[4].view(C, N, 2)
+        return (acc[0].view(C, N, 2), acc[1].view(C, N, 3), acc[2].view(C, N, ch),
+                acc[3].view(C, N), v_bg, None, None, None, None, None)
+
+
+def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
+                        image_width: int, image_height: int, tile_size: int,
+                        isect_offsets: Tensor, flatten_ids: Tensor,
+                        backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None,
+                        packed: bool = False, absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+    """Depth-ordered alpha compositing.  means2d [C,N,2], conics [C,N,3], colors [C,N,ch],
+    opacities [C,N], isect_offsets [C,th,tw], flatten_ids [n_isects] ->
+    render_colors [C,H,W,ch], render_alphas [C,H,W,1]."""
+    if packed:
+        raise NotImplementedError("packed=True is not supported")
+    if masks is not None:
+        raise NotImplementedError("tile masks are not supported")
+    if tile_size != TILE_SIZE:
+        raise NotImplementedError(f"tile_size must be {TILE_SIZE}")
+    require_device(means2d, conics, colors, opacities, isect_offsets, flatten_ids, backgrounds)
+    C, N = means2d.shape[0], means2d.shape[1]
+    ch = colors.shape[-1]
+    if not 1 <= ch <= 32:
+        raise ValueError(f"{ch} colour channels: supported range is 1..32")
+    tile_w, tile_h = -(-image_width // TILE_SIZE), -(-image_height // TILE_SIZE)
+    if tuple(isect_offsets.shape) != (C, tile_h, tile_w):
+        raise ValueError(f"isect_offsets shape {tuple(isect_offsets.shape)} != {(C, tile_h, tile_w)}")
+    flatten_ids = flatten_ids.to(torch.int32).contiguous()
+    end = torch.full((1,), flatten_ids.numel(), dtype=torch.int32, device=means2d.device)
+    offsets_ext = torch.cat([isect_offsets.reshape(-1).to(torch.int32), end])
+    return _RasterizeToPixels.apply(_f32c(means2d), _f32c(conics), _f32c(colors),
+                                    _f32c(opacities), _f32c(backgrounds), int(image_width),
+                                    int(image_height), offsets_ext, flatten_ids, bool(absgrad))

@@ -1,0 +1,236 @@
+"""`rasterization(...)`: the whole background-render path behind the signature nerfstudio's
+splatfacto calls (gsplat 1.x `rasterization`), plus `render(...)`,
+the Camera/Gaussians convenience the data-generation loop would use.
+
+Per camera the frame is four C-ABI calls on torch's current stream:
+    mgs_project_color_fwd -> mgs_isect_tiles -> mgs_rasterize_fwd        (forward)
+    mgs_rasterize_bwd -> mgs_project_color_bwd                            (backward)
+With `isect_capacity` given nothing is read back from the device, so a frame (or a training
+step) can be captured in a HIP graph.  Without it the intersection bound is read back once
+per camera to size the lists, as the reference operator does.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib, ops
+from ._lib import check, ptr, require_device, stream_handle
+from .ops import TILE_SIZE, _f32c
+
+_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+
+
+class _RenderSH(torch.autograd.Function):
+    """SH-coloured frames for C cameras: fused projection+colour, binning, raster."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds,
+                width, height, sh_degree, eps2d, near_plane, far_plane, radius_clip,
+                antialiased, with_depth, isect_capacity, absgrad, meta_out):
+        C = viewmats.shape[0]
+        dev = means.device
+        tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
+        ch = 4 if with_depth else 3
+        render = torch.empty(C, height, width, ch, dtype=torch.float32, device=dev)
+        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        per_cam = []
+        for c in range(C):
+            radii, means2d, depths, conics, opac_aa, feats = ops.project_color_fwd_raw(
+                means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats[c], Ks[c], width,
+                height, eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth)
+            opac = opac_aa if antialiased else opacities
+            cap = isect_capacity
+            if cap is None:
+                cap = max(1, ops._upper_bound_isects(radii, tile_w, tile_h))
+            tl = ops.isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, cap, c, C,
+                                     want_isect_ids=False, want_tiles_per_gauss=True)
+            ops.rasterize_fwd_raw(means2d, conics, feats, opac,
+                                  backgrounds[c] if backgrounds is not None else None, width,
+                                  height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
+                                  out=(render[c], alphas[c], last_ids[c]))
+            per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl))
+        ctx.per_cam = per_cam
+        ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks,
+                              backgrounds, alphas, last_ids)
+        ctx.cfg = (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
+                   absgrad)
+        meta_out["per_cam"] = per_cam
+        return render, alphas.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas):
+        (means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds, alphas,
+         last_ids) = ctx.saved_tensors
+        (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
+         absgrad) = ctx.cfg
+        C, n = viewmats.shape[0], means.shape[0]
+        v_render = _f32c(v_render)
+        v_alphas = _f32c(v_alphas).reshape(C, height, width)
+        v_means = torch.zeros_like(means)
+        v_quats = torch.zeros_like(quats)
+        v_scales = torch.zeros_like(scales)
+        v_sh = torch.zeros_like(sh_coeffs)
+        v_opacities = torch.zeros_like(opacities)
+        L = _lib.lib()
+        for c in range(C):
+            radii, means2d, depths, conics, opac_aa, feats, tl = ctx.per_cam[c]
+            opac = opac_aa if antialiased else opacities
+            bg = backgrounds[c] if backgrounds is not None else None
+            v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_raw(
+                means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl.tile_offsets,
+                tl.flatten_ids, alphas[c], last_ids[c], v_render[c], v_alphas[c], absgrad)
+            if absgrad:
+                ctx.per_cam[c] = ctx.per_cam[c] + (v_abs,)
+            check(L.mgs_project_color_bwd(
+                n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), sh_degree,
+                sh_coeffs.shape[1], ptr(sh_coeffs), ptr(viewmats[c]), ptr(Ks[c]), width, height,
+                eps2d, ptr(radii), ptr(conics), int(antialiased), feats.shape[1], ptr(feats),
+                ptr(v_feats), ptr(v_means2d), ptr(v_conics), None,
+                ptr(v_opac) if antialiased else None, ptr(v_means), ptr(v_quats), ptr(v_scales),
+                ptr(v_sh), ptr(v_opacities), stream_handle()), "mgs_project_color_bwd")
+            if not antialiased:
+                v_opacities += v_opac
+        v_bg = None
+        if backgrounds is not None and ctx.needs_input_grad[7]:
+            v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
+        return (v_means, v_quats, v_scales, v_opacities, v_sh, None, None, v_bg) + (None,) * 12
+
+
+def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
+                  colors: Tensor, viewmats: Tensor, Ks: Tensor, width: int, height: int,
+                  near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
+                  eps2d: float = 0.3, sh_degree: Optional[int] = None, packed: bool = False,
+                  tile_size: int = TILE_SIZE, backgrounds: Optional[Tensor] = None,
+                  render_mode: str = "RGB", sparse_grad: bool = False, absgrad: bool = False,
+                  rasterize_mode: str = "classic", channel_chunk: int = 32,
+                  isect_capacity: Optional[int] = None) -> Tuple[Tensor, Tensor, Dict]:
+    """Render N Gaussians from C cameras.
+
+    means [N,3], quats [N,4] (wxyz), scales [N,3], opacities [N] (post-activation);
+    colors [N,K,3] SH coefficients when sh_degree is given, else [N,D] / [C,N,D] features;
+    viewmats [C,4,4] OpenCV world-to-camera; Ks [C,3,3].
+    Returns render_colors [C,H,W,D'], render_alphas [C,H,W,1], meta.
+    """
+    if render_mode not in _MODES:
+        raise ValueError(f"render_mode {render_mode!r} not in {_MODES}")
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"rasterize_mode {rasterize_mode!r}")
+    if packed or sparse_grad:
+        raise NotImplementedError("packed / sparse_grad are not supported")
+    if tile_size != TILE_SIZE:
+        raise NotImplementedError(f"tile_size must be {TILE_SIZE}")
+    require_device(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
+    N, C = means.shape[0], viewmats.shape[0]
+    if means.shape != (N, 3) or quats.shape != (N, 4) or scales.shape != (N, 3) \
+            or opacities.shape != (N,):
+        raise ValueError("expected means [N,3], quats [N,4], scales [N,3], opacities [N]")
+    if viewmats.shape != (C, 4, 4) or Ks.shape != (C, 3, 3):
+        raise ValueError("expected viewmats [C,4,4], Ks [C,3,3]")
+    means, quats, scales, opacities = _f32c(means), _f32c(quats), _f32c(scales), _f32c(opacities)
+    colors, viewmats, Ks, backgrounds = _f32c(colors), _f32c(viewmats), _f32c(Ks), _f32c(backgrounds)
+    width, height = int(width), int(height)
+    antialiased = rasterize_mode == "antialiased"
+    want_rgb = render_mode.startswith("RGB")
+    want_depth = render_mode != "RGB"
+    tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
+    meta: Dict = {"width": width, "height": height, "tile_size": TILE_SIZE,
+                  "tile_width": tile_w, "tile_height": tile_h, "n_cameras": C}
+
+    if sh_degree is not None and want_rgb:
+        if colors.dim() != 3 or colors.shape[0] != N or colors.shape[2] != 3:
+            raise ValueError("with sh_degree set, colors must be [N,K,3]")
+        if not 0 <= sh_degree <= 3 or colors.shape[1] < (sh_degree + 1) ** 2:
+            raise ValueError("sh_degree outside 0..3 or too few coefficients")
+        if backgrounds is not None and backgrounds.shape != (C, 4 if want_depth else 3):
+            raise ValueError("backgrounds must be [C, channels]")
+        store: Dict = {}
+        render, alphas = _RenderSH.apply(
+            means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height,
+            int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
+            float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store)
+        per_cam = store["per_cam"]
+        meta.update(
+            radii=torch.stack([p[0] for p in per_cam]),
+            means2d=torch.stack([p[1] for p in per_cam]),
+            depths=torch.stack([p[2] for p in per_cam]),
+            conics=torch.stack([p[3] for p in per_cam]),
+            opacities=(torch.stack([p[4] for p in per_cam]) if antialiased
+                       else opacities.unsqueeze(0).expand(C, N)),
+            tiles_per_gauss=torch.stack([p[6].tiles_per_gauss for p in per_cam]),
+            n_isects=torch.cat([p[6].n_isect for p in per_cam]),
+            isect_status=torch.cat([p[6].status for p in per_cam]),
+            isect_offsets=torch.stack([p[6].tile_offsets[:-1].view(tile_h, tile_w) for p in per_cam]),
+            tile_lists=[p[6] for p in per_cam])
+    else:
+        # feature path: colours are given per Gaussian (or evaluated from SH for "D"/"ED")
+        radii, means2d, depths, conics, comps = ops.fully_fused_projection(
+            means, None, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+            radius_clip, calc_compensations=antialiased)
+        opac = opacities.unsqueeze(0).expand(C, N)
+        if antialiased:
+            opac = opac * comps
+        feats = None
+        if want_rgb:
+            feats = colors.unsqueeze(0).expand(C, N, -1) if colors.dim() == 2 else colors
+            if feats.shape[:2] != (C, N):
+                raise ValueError("colors must be [N,D] or [C,N,D] when sh_degree is None")
+        if want_depth:
+            d = depths.unsqueeze(-1)
+            feats = d if feats is None else torch.cat([feats, d], dim=-1)
+        tpg, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, TILE_SIZE, tile_w,
+                                                      tile_h)
+        offsets = ops.isect_offset_encode(isect_ids, C, tile_w, tile_h)
+        render, alphas = ops.rasterize_to_pixels(means2d, conics, feats.contiguous(),
+                                                 opac.contiguous(), width, height, TILE_SIZE,
+                                                 offsets, flatten_ids, backgrounds=backgrounds,
+                                                 absgrad=absgrad)
+        meta.update(radii=radii, means2d=means2d, depths=depths, conics=conics, opacities=opac,
+                    tiles_per_gauss=tpg, isect_ids=isect_ids, flatten_ids=flatten_ids,
+                    isect_offsets=offsets)
+    if render_mode in ("ED", "RGB+ED"):
+        render = torch.cat([render[..., :-1],
+                            render[..., -1:] / alphas.clamp(min=1e-10)], dim=-1)
+    return render, alphas, meta
+
+
+def check_isect_status(meta: Dict) -> None:
+    """Raise if any camera's intersection list overflowed its capacity (reads one word back)."""
+    if "isect_status" in meta and bool((meta["isect_status"] != 0).any().item()):
+        need = int(meta["n_isects"].max().item())
+        raise _lib.MgsError(f"tile-intersection capacity exceeded: a camera needs {need} slots; "
+                            "re-render with a larger isect_capacity")
+
+
+def render(gaussians, cameras: Sequence, sh_degree: Optional[int] = None,
+           render_mode: str = "RGB+ED", background: Optional[Sequence[float]] = None,
+           device: str = "cuda", tensors: Optional[Dict] = None, **kw):
+    """Render a `Gaussians` scene from `Camera`s (the Python-side API that stays, per the
+    north star).  Applies splatfacto's post-processing: rgb = clamp(rgb + (1-alpha)*bg, 0, 1),
+    depth = where(alpha > 0, depth, max depth).  Returns dict(rgb, depth, alpha, meta)."""
+    cams = list(cameras)
+    w, h = cams[0].width, cams[0].height
+    if any(c.width != w or c.height != h for c in cams):
+        raise ValueError("all cameras of one call must share a resolution")
+    t = tensors if tensors is not None else gaussians.to_torch(device, sh_degree)
+    viewmats = torch.from_numpy(np.stack([c.viewmat() for c in cams]).astype(np.float32)).to(device)
+    Ks = torch.from_numpy(np.stack([c.K for c in cams]).astype(np.float32)).to(device)
+    colors, alphas, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"],
+                                         t["colors"], viewmats, Ks, w, h,
+                                         near_plane=cams[0].near, far_plane=cams[0].far,
+                                         sh_degree=t["sh_degree"], render_mode=render_mode, **kw)
+    out = {"alpha": alphas, "meta": meta}
+    if render_mode.startswith("RGB"):
+        rgb = colors[..., :3]
+        if background is not None:
+            bg = torch.tensor(background, dtype=torch.float32, device=rgb.device)
+            rgb = rgb + (1.0 - alphas) * bg
+        out["rgb"] = rgb.clamp(0.0, 1.0)
+    if render_mode != "RGB":
+        depth = colors[..., -1:]
+        out["depth"] = torch.where(alphas > 0, depth, depth.detach().max())
+    return out

@@ -1,0 +1,221 @@
+"""GPU parity of the forward path against the oracle (oracle/gs_oracle_np.py), stage by stage
+through the C ABI, then end to end.  Scene: BASELINE.json configs[0] (10k Gaussians, 256x256)
+and small variants; tolerances are written next to each assertion.
+
+Integer outputs derived from float thresholds (radii, tile rectangles) can legitimately
+differ on a measure-zero set of Gaussians whose 3*sqrt(lambda) sits within rounding of an
+integer; such cases are counted and bounded, and every downstream stage is checked against
+the oracle run on the HIP stage's own outputs so that a flip cannot mask a real error.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle_np as O
+from robosimgs_amd import camera_ring, synthetic_scene
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _scene(n=10_000, mu=0.05, deg=0, w=256, h=256, theta=0.3, seed=0):
+    g = synthetic_scene(n, math.log(mu), deg, seed)
+    cam = camera_ring(1, w, h, thetas=[theta])[0]
+    return g, cam
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from robosimgs_amd import ops as _ops
+    return _ops
+
+
+def test_single_hip_runtime_loaded(ops):
+    """libmgs.so must bind to the HIP runtime torch loaded (one libamdhip64 in the process)."""
+    from robosimgs_amd import _lib
+    assert _lib.lib().mgs_version() == 100
+    torch.zeros(1, device=DEV)
+    with open("/proc/self/maps") as f:
+        libs = {line.split()[-1] for line in f if "libamdhip64" in line}
+    assert len(libs) == 1, f"two HIP runtimes mapped: {libs}"
+    assert any("libmgs.so" in line for line in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("n,mu,w,h,theta", [(10_000, 0.05, 256, 256, 0.3),
+                                             (3_000, 0.2, 200, 120, 2.1),
+                                             (500, 0.6, 64, 48, 4.0)])
+def test_projection_matches_oracle(ops, n, mu, w, h, theta):
+    g, cam = _scene(n, mu, 0, w, h, theta)
+    ref = O.project(g.means, g.quats, g.scales, cam.viewmat(), cam.K, w, h)
+    radii, means2d, depths, conics, comps = ops.fully_fused_projection(
+        _t(g.means), None, _t(g.quats), _t(g.scales), _t(cam.viewmat())[None], _t(cam.K)[None],
+        w, h, calc_compensations=True)
+    radii = radii[0].cpu().numpy()
+    vis_ref, vis = ref["radii"] > 0, radii > 0
+    flips = int((vis_ref != vis).sum())
+    assert flips <= max(1, n // 5000), f"{flips} visibility flips of {n}"
+    both = vis_ref & vis
+    dr = np.abs(radii[both] - ref["radii"][both])
+    assert dr.max() <= 1 and (dr > 0).sum() <= max(1, n // 2000), \
+        f"radius mismatches: {(dr > 0).sum()} (max {dr.max()})"
+    # fp32 vs fp64: relative 2e-5 on screen-space quantities (|means2d| up to ~1e3 px)
+    np.testing.assert_allclose(means2d[0].cpu().numpy()[both], ref["means2d"][both], rtol=2e-5, atol=2e-3)
+    np.testing.assert_allclose(depths[0].cpu().numpy()[both], ref["depths"][both], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(conics[0].cpu().numpy()[both], ref["conics"][both], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(comps[0].cpu().numpy()[both], ref["compensations"][both], rtol=2e-4, atol=1e-6)
+    # culled rows are zeroed
+    assert np.all(means2d[0].cpu().numpy()[~vis] == 0) and np.all(conics[0].cpu().numpy()[~vis] == 0)
+
+
+@pytest.mark.parametrize("deg,K", [(0, 1), (1, 4), (2, 9), (3, 16), (1, 16), (2, 16), (0, 16)])
+def test_spherical_harmonics_matches_oracle(ops, deg, K):
+    rng = np.random.default_rng(5)
+    n = 4097                                   # ragged: not a multiple of the 64-row wave slab
+    dirs = rng.normal(size=(n, 3))
+    coeffs = rng.normal(size=(n, K, 3))
+    masks = rng.random(n) > 0.3
+    Y = O.sh_basis(deg, dirs / np.linalg.norm(dirs, axis=1, keepdims=True))
+    ref = np.einsum("nk,nkc->nc", Y, coeffs[:, :(deg + 1) ** 2])
+    out = ops.spherical_harmonics(deg, _t(dirs), _t(coeffs)).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=2e-5)
+    out_m = ops.spherical_harmonics(deg, _t(dirs), _t(coeffs), torch.from_numpy(masks).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(out_m[masks], ref[masks], rtol=1e-4, atol=2e-5)
+    assert np.all(out_m[~masks] == 0)
+
+
+@pytest.mark.parametrize("n,mu,w,h", [(10_000, 0.05, 256, 256), (2_000, 0.3, 200, 120),
+                                       (64, 0.05, 16, 16), (5, 0.05, 256, 256)])
+def test_isect_tiles_bit_exact(ops, n, mu, w, h):
+    """Integer path: given the same projected inputs the sorted lists must be identical."""
+    g, cam = _scene(n, mu, 0, w, h)
+    radii, means2d, depths, conics, _ = ops.fully_fused_projection(
+        _t(g.means), None, _t(g.quats), _t(g.scales), _t(cam.viewmat())[None], _t(cam.K)[None], w, h)
+    tw, th = -(-w // 16), -(-h // 16)
+    tpg, isect_ids, flatten_ids = ops.isect_tiles(means2d, radii, depths, 16, tw, th)
+    offs = ops.isect_offset_encode(isect_ids, 1, tw, th)
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d[0].cpu().numpy(), radii[0].cpu().numpy(),
+                                         depths[0].cpu().numpy(), 16, tw, th, dtype=np.float32)
+    np.testing.assert_array_equal(tpg[0].cpu().numpy(), r_tpg)
+    np.testing.assert_array_equal(isect_ids.cpu().numpy(), r_ids)
+    np.testing.assert_array_equal(flatten_ids.cpu().numpy(), r_flat)
+    np.testing.assert_array_equal(offs.cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th))
+
+
+def test_isect_tiles_empty_and_overflow(ops):
+    from robosimgs_amd import _lib
+    w = h = 64
+    means2d = torch.zeros(8, 2, device=DEV)
+    radii = torch.zeros(8, dtype=torch.int32, device=DEV)
+    depths = torch.ones(8, device=DEV)
+    tl = ops.isect_tiles_raw(means2d, radii, depths, 4, 4, 16)
+    assert int(tl.n_isect.item()) == 0 and int(tl.status.item()) == 0
+    assert torch.all(tl.tile_offsets == 0)
+    # one Gaussian covering all 16 tiles, capacity 10 -> overflow flagged, n_isect reports 16
+    means2d[0] = torch.tensor([32.0, 32.0])
+    radii[0] = 100
+    tl = ops.isect_tiles_raw(means2d, radii, depths, 4, 4, 10)
+    assert int(tl.n_isect.item()) == 16
+    assert int(tl.status.item()) & _lib.MGS_STATUS_ISECT_OVERFLOW
+    tl = ops.isect_tiles_raw(means2d, radii, depths, 4, 4, 16)
+    assert int(tl.status.item()) == 0
+    np.testing.assert_array_equal(tl.tile_offsets.cpu().numpy(), np.arange(17))
+    np.testing.assert_array_equal(tl.tile_ids.cpu().numpy(), np.arange(16))
+
+
+def _raster_inputs(ops, g, cam, w, h, deg):
+    t = g.to_torch(DEV, deg)
+    vm, K = _t(cam.viewmat()), _t(cam.K)
+    radii, means2d, depths, conics, opac, feats = ops.project_color_fwd_raw(
+        t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, w, h, 0.3,
+        0.01, 1e10, 0.0, False, True)
+    tw, th = -(-w // 16), -(-h // 16)
+    cap = ops._upper_bound_isects(radii, tw, th) + 1
+    tl = ops.isect_tiles_raw(means2d, radii, depths, tw, th, cap)
+    return t, radii, means2d, depths, conics, feats, tl, tw, th
+
+
+@pytest.mark.parametrize("n,mu,w,h,deg", [(10_000, 0.05, 256, 256, 0), (4_000, 0.15, 200, 120, 3),
+                                           (20_000, 0.08, 96, 80, 1)])
+def test_rasterize_matches_oracle(ops, n, mu, w, h, deg):
+    """Blend stage on identical inputs: |diff| <= 1e-4 abs (north-star tolerance) on RGB,
+    depth-sum and alpha, except at pixels where an alpha sits on the 1/255 or T<=1e-4 threshold
+    (counted; must stay below 0.05% of pixels)."""
+    g, cam = _scene(n, mu, deg, w, h)
+    t, radii, means2d, depths, conics, feats, tl, tw, th = _raster_inputs(ops, g, cam, w, h, deg)
+    bg = torch.tensor([0.1, 0.2, 0.3, 0.0], device=DEV)
+    render, alphas, last = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], bg, w, h,
+                                                 tw, th, tl.tile_offsets, tl.flatten_ids)
+    n_isect = int(tl.n_isect.item())
+    ref_img, ref_alpha, ref_last, stats = O.rasterize(
+        means2d.cpu().numpy(), conics.cpu().numpy(), feats.cpu().numpy(),
+        t["opacities"].cpu().numpy(), tl.flatten_ids[:n_isect].cpu().numpy(),
+        tl.tile_offsets[:-1].cpu().numpy().reshape(th, tw), w, h, 16,
+        background=bg.cpu().numpy())
+    d_img = np.abs(render.cpu().numpy() - ref_img).max(axis=-1)
+    d_alpha = np.abs(alphas.cpu().numpy() - ref_alpha)
+    bad = (d_img > 1e-4) | (d_alpha > 1e-4)
+    frac = bad.mean()
+    assert frac <= 5e-4, f"{bad.sum()} px over 1e-4 (max img {d_img.max():.3e}, alpha {d_alpha.max():.3e})"
+    same_last = (last.cpu().numpy() == ref_last).mean()
+    assert same_last >= 0.999, f"last_ids agree on {same_last:.5f} of pixels"
+    assert stats["contribs"] > 0
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGB+ED", "D", "RGB+D", "ED"])
+def test_rasterization_end_to_end(mode):
+    """configs[0]: 10k Gaussians, SH degree 0, 256x256 -- whole path vs whole oracle."""
+    from robosimgs_amd import rasterization
+    g, cam = _scene(10_000, 0.05, 0, 256, 256)
+    t = g.to_torch(DEV, 0)
+    colors, alphas, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"],
+                                         t["colors"], _t(cam.viewmat())[None], _t(cam.K)[None],
+                                         256, 256, sh_degree=0, render_mode=mode)
+    ref, ref_alpha, rmeta = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                     cam.viewmat(), cam.K, 256, 256, sh_degree=0, render_mode=mode)
+    assert colors.shape == (1,) + ref.shape
+    assert int(meta["radii"].gt(0).sum()) == rmeta["n_vis"] == 9849
+    if "n_isects" in meta:
+        assert int(meta["n_isects"][0]) == rmeta["n_isect"] == 37024
+    d = np.abs(colors[0].cpu().numpy() - ref).max(axis=-1)
+    da = np.abs(alphas[0, ..., 0].cpu().numpy() - ref_alpha[..., 0])
+    # expected-depth divides by alpha: compare that channel relatively
+    tol = 1e-4 if "E" not in mode else 2e-3
+    bad = (d > tol) | (da > 1e-4)
+    assert bad.mean() <= 5e-4, f"{bad.sum()} px off (max {d.max():.3e} / alpha {da.max():.3e})"
+
+
+def test_rasterization_multi_camera_and_capacity():
+    from robosimgs_amd import rasterization, check_isect_status, _lib
+    g = synthetic_scene(5000, math.log(0.08), 2, 3)
+    cams = camera_ring(3, 160, 96)
+    t = g.to_torch(DEV, 2)
+    vm = _t(np.stack([c.viewmat() for c in cams]))
+    Ks = _t(np.stack([c.K for c in cams]))
+    colors, alphas, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"],
+                                         t["colors"], vm, Ks, 160, 96, sh_degree=2,
+                                         isect_capacity=200_000)
+    check_isect_status(meta)
+    for c, cam in enumerate(cams):
+        ref, ref_alpha, _ = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                     cam.viewmat(), cam.K, 160, 96, sh_degree=2)
+        bad = np.abs(colors[c].cpu().numpy() - ref).max(-1) > 1e-4
+        assert bad.mean() <= 5e-4, f"camera {c}: {bad.sum()} px off"
+    _, _, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                               vm, Ks, 160, 96, sh_degree=2, isect_capacity=100)
+    with pytest.raises(_lib.MgsError):
+        check_isect_status(meta)
+
+
+def test_cpu_tensors_are_rejected():
+    from robosimgs_amd import rasterization, _lib
+    z = torch.zeros(4, 3)
+    with pytest.raises(_lib.MgsError):
+        rasterization(z, torch.zeros(4, 4), z, torch.zeros(4), z, torch.eye(4)[None],
+                      torch.eye(3)[None], 16, 16)
