@@ -169,9 +169,12 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
 
 /* Fused-colour backward: chain rule of mgs_project_color_fwd.
  *   v_feats[N,feat_stride] (channel 3, if present, is d/d depth), v_means2d, v_conics,
- *   v_opac_out (nullable; cotangent of opacities*compensation) ->
- *   v_means, v_quats, v_scales (+=), v_sh_coeffs[N,K,3] (+= on the active degree),
- *   v_opacities (+=, nullable). */
+ *   v_depths (nullable, extra d/d depth), v_opac_out (cotangent of opacities*compensation;
+ *   needed iff antialiased) ->
+ *   v_means[N,3], v_quats[N,4], v_scales[N,3], v_sh_coeffs[N,K,3], and, iff antialiased,
+ *   v_opacities[N].  accumulate == 0: every output row is overwritten (zeros for culled
+ *   Gaussians and for coefficients above the active degree); accumulate != 0: added to,
+ *   so the cameras of a batch can be summed without a separate zero-fill pass. */
 int mgs_project_color_bwd(int n, const float *means, const float *quats, const float *scales,
                           const float *opacities, int sh_degree, int coeff_stride,
                           const float *sh_coeffs, const float *viewmat, const float *K,
@@ -181,7 +184,7 @@ int mgs_project_color_bwd(int n, const float *means, const float *quats, const f
                           const float *v_conics, const float *v_depths,
                           const float *v_opac_out, float *v_means, float *v_quats,
                           float *v_scales, float *v_sh_coeffs, float *v_opacities,
-                          mgs_stream_t stream);
+                          int accumulate, mgs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -214,5 +214,172 @@ MGS_HD void sh_basis_grad(int deg, float x, float y, float z, float* Yx, float* 
   Yx[15] = c3a * fC2_x;  Yy[15] = c3a * fC2_y;  Yz[15] = 0.f;
 }
 
+
+// =========================================================================================
+// Backward (vector-Jacobian products) of the functions above
+// =========================================================================================
+
+// v_q (un-normalised wxyz) from the cotangent G (row-major 3x3) of R(q/|q|)
+MGS_HD void quat_to_rotmat_vjp(const float q[4], const float G[9], float v_q[4]) {
+  float inv = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+  float vn[4];
+  vn[0] = 2.f * (x * (G[7] - G[5]) + y * (G[2] - G[6]) + z * (G[3] - G[1]));
+  vn[1] = 2.f * (y * (G[1] + G[3]) + z * (G[2] + G[6]) + w * (G[7] - G[5]) - 2.f * x * (G[4] + G[8]));
+  vn[2] = 2.f * (x * (G[1] + G[3]) + z * (G[5] + G[7]) + w * (G[2] - G[6]) - 2.f * y * (G[0] + G[8]));
+  vn[3] = 2.f * (x * (G[2] + G[6]) + y * (G[5] + G[7]) + w * (G[3] - G[1]) - 2.f * z * (G[0] + G[4]));
+  float d = vn[0] * w + vn[1] * x + vn[2] * y + vn[3] * z;
+  v_q[0] = (vn[0] - d * w) * inv;
+  v_q[1] = (vn[1] - d * x) * inv;
+  v_q[2] = (vn[2] - d * y) * inv;
+  v_q[3] = (vn[3] - d * z) * inv;
+}
+
+struct ProjectedGrad {
+  float v_mean[3];
+  float v_quat[4];
+  float v_scale[3];
+  float v_R[9];   // d/d viewmat rotation (row-major)
+  float v_t[3];   // d/d viewmat translation
+};
+
+// VJP of project_gaussian for a VISIBLE Gaussian (radius > 0).  `conic` is the forward
+// output; v_comp is the cotangent of the compensation factor (0 unless antialiased).
+MGS_HD ProjectedGrad project_gaussian_vjp(const float mean[3], const float quat[4],
+                                          const float scale[3], const CameraParams& cam, float W,
+                                          float H, float eps2d, const float conic[3],
+                                          float compensation, const float v_mean2d[2],
+                                          float v_depth, const float v_conic[3], float v_comp) {
+  ProjectedGrad g;
+  const float* R = cam.R;
+  float x = R[0] * mean[0] + R[1] * mean[1] + R[2] * mean[2] + cam.t[0];
+  float y = R[3] * mean[0] + R[4] * mean[1] + R[5] * mean[2] + cam.t[1];
+  float z = R[6] * mean[0] + R[7] * mean[1] + R[8] * mean[2] + cam.t[2];
+
+  // recompute Sigma_c and J
+  float Rq[9], M[9], cov[9], tmp[9], covc[9];
+  quat_to_rotmat(quat, Rq);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[i * 3 + j] = Rq[i * 3 + j] * scale[j];
+  mat3_mul_bt(M, M, cov);
+  mat3_mul(R, cov, tmp);
+  mat3_mul_bt(tmp, R, covc);
+  float tanx = 0.5f * W / cam.fx, tany = 0.5f * H / cam.fy;
+  float lim_xp = (W - cam.cx) / cam.fx + 0.3f * tanx, lim_xn = cam.cx / cam.fx + 0.3f * tanx;
+  float lim_yp = (H - cam.cy) / cam.fy + 0.3f * tany, lim_yn = cam.cy / cam.fy + 0.3f * tany;
+  float rz = 1.0f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+  float xr = x * rz, yr = y * rz;
+  bool x_in = xr <= lim_xp && xr >= -lim_xn, y_in = yr <= lim_yp && yr >= -lim_yn;
+  float tx = z * fminf(lim_xp, fmaxf(-lim_xn, xr));
+  float ty = z * fminf(lim_yp, fmaxf(-lim_yn, yr));
+  float j00 = cam.fx * rz, j02 = -cam.fx * tx * rz2, j11 = cam.fy * rz, j12 = -cam.fy * ty * rz2;
+
+  // conic = inv(cov2d + eps I):  G2 = -conic * Vc * conic, Vc = [[va, vb/2],[vb/2, vc]]
+  float ca = conic[0], cb = conic[1], cc = conic[2];
+  float va = v_conic[0], vb = 0.5f * v_conic[1], vc = v_conic[2];
+  // P = conic * Vc
+  float p00 = ca * va + cb * vb, p01 = ca * vb + cb * vc;
+  float p10 = cb * va + cc * vb, p11 = cb * vb + cc * vc;
+  float g00 = -(p00 * ca + p01 * cb), g01 = -(p00 * cb + p01 * cc);
+  float g10 = -(p10 * ca + p11 * cb), g11 = -(p10 * cb + p11 * cc);
+  if (v_comp != 0.f) {   // compensation = sqrt(max(0, det(C)/det(C+eps I)))
+    float det_conic = ca * cc - cb * cb;
+    float v_sqr = v_comp * 0.5f / (compensation + 1e-6f);
+    float om = 1.f - compensation * compensation;
+    g00 += v_sqr * (om * ca - eps2d * det_conic);
+    g01 += v_sqr * (om * cb);
+    g10 += v_sqr * (om * cb);
+    g11 += v_sqr * (om * cc - eps2d * det_conic);
+  }
+  // cov2d = J covc J^T ;  v_covc = J^T G2 J ;  v_J = (G2 + G2^T) J covc
+  float J[6] = {j00, 0.f, j02, 0.f, j11, j12};
+  float G2[4] = {g00, g01, g10, g11};
+  float GJ[6];    // G2 * J (2x3)
+  for (int c = 0; c < 3; ++c) {
+    GJ[c] = G2[0] * J[c] + G2[1] * J[3 + c];
+    GJ[3 + c] = G2[2] * J[c] + G2[3] * J[3 + c];
+  }
+  float v_covc[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) v_covc[r * 3 + c] = J[r] * GJ[c] + J[3 + r] * GJ[3 + c];
+  float Gs[4] = {2.f * g00, g01 + g10, g01 + g10, 2.f * g11};
+  float GsJ[6];
+  for (int c = 0; c < 3; ++c) {
+    GsJ[c] = Gs[0] * J[c] + Gs[1] * J[3 + c];
+    GsJ[3 + c] = Gs[2] * J[c] + Gs[3] * J[3 + c];
+  }
+  float vJ00 = 0.f, vJ02 = 0.f, vJ11 = 0.f, vJ12 = 0.f;   // only the non-constant entries of J
+  for (int k = 0; k < 3; ++k) {
+    vJ00 += GsJ[k] * covc[k * 3 + 0];
+    vJ02 += GsJ[k] * covc[k * 3 + 2];
+    vJ11 += GsJ[3 + k] * covc[k * 3 + 1];
+    vJ12 += GsJ[3 + k] * covc[k * 3 + 2];
+  }
+  // camera-space mean
+  float vx = cam.fx * rz * v_mean2d[0];
+  float vy = cam.fy * rz * v_mean2d[1];
+  float vz = -(cam.fx * x * v_mean2d[0] + cam.fy * y * v_mean2d[1]) * rz2 + v_depth;
+  if (x_in) vx += -cam.fx * rz2 * vJ02; else vz += -cam.fx * rz3 * vJ02 * tx;
+  if (y_in) vy += -cam.fy * rz2 * vJ12; else vz += -cam.fy * rz3 * vJ12 * ty;
+  vz += -cam.fx * rz2 * vJ00 - cam.fy * rz2 * vJ11 + 2.f * cam.fx * tx * rz3 * vJ02 +
+        2.f * cam.fy * ty * rz3 * vJ12;
+  // world mean, view matrix
+  g.v_mean[0] = R[0] * vx + R[3] * vy + R[6] * vz;
+  g.v_mean[1] = R[1] * vx + R[4] * vy + R[7] * vz;
+  g.v_mean[2] = R[2] * vx + R[5] * vy + R[8] * vz;
+  g.v_t[0] = vx; g.v_t[1] = vy; g.v_t[2] = vz;
+  float vcs[9];   // symmetrised v_covc
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) vcs[r * 3 + c] = v_covc[r * 3 + c] + v_covc[c * 3 + r];
+  // covc = R cov R^T : v_R = (v_covc + v_covc^T) R cov ; v_cov = R^T v_covc R
+  float Rcov[9];
+  mat3_mul(R, cov, Rcov);
+  mat3_mul(vcs, Rcov, g.v_R);
+  g.v_R[0] += vx * mean[0]; g.v_R[1] += vx * mean[1]; g.v_R[2] += vx * mean[2];
+  g.v_R[3] += vy * mean[0]; g.v_R[4] += vy * mean[1]; g.v_R[5] += vy * mean[2];
+  g.v_R[6] += vz * mean[0]; g.v_R[7] += vz * mean[1]; g.v_R[8] += vz * mean[2];
+  float t2[9], v_cov[9];
+  mat3_mul_at(R, v_covc, t2);
+  mat3_mul(t2, R, v_cov);
+  // cov = M M^T : v_M = (v_cov + v_cov^T) M ; M = Rq diag(s)
+  float vs[9], v_M[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) vs[r * 3 + c] = v_cov[r * 3 + c] + v_cov[c * 3 + r];
+  mat3_mul(vs, M, v_M);
+  float v_Rq[9];
+  for (int j = 0; j < 3; ++j) {
+    g.v_scale[j] = Rq[0 * 3 + j] * v_M[0 * 3 + j] + Rq[1 * 3 + j] * v_M[1 * 3 + j] +
+                   Rq[2 * 3 + j] * v_M[2 * 3 + j];
+    for (int i = 0; i < 3; ++i) v_Rq[i * 3 + j] = v_M[i * 3 + j] * scale[j];
+  }
+  quat_to_rotmat_vjp(quat, v_Rq, g.v_quat);
+  return g;
+}
+
+// VJP of colour = sum_k Y_k(normalize(dir)) coeff_k.  Writes v_coeff[KC*3] and v_dir[3].
+template <int DEG>
+MGS_HD void sh_vjp(const float dir[3], const float* coeff, const float v_rgb[3], float* v_coeff,
+                   float v_dir[3]) {
+  constexpr int KC = (DEG + 1) * (DEG + 1);
+  float n2 = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+  float inv = n2 > 0.f ? 1.0f / sqrtf(n2) : 0.f;
+  float x = dir[0] * inv, y = dir[1] * inv, z = dir[2] * inv;
+  float Y[KC], Yx[KC], Yy[KC], Yz[KC];
+  sh_basis(DEG, x, y, z, Y);
+  sh_basis_grad(DEG, x, y, z, Yx, Yy, Yz);
+  float vx = 0.f, vy = 0.f, vz = 0.f;
+  for (int k = 0; k < KC; ++k) {
+    v_coeff[3 * k + 0] = Y[k] * v_rgb[0];
+    v_coeff[3 * k + 1] = Y[k] * v_rgb[1];
+    v_coeff[3 * k + 2] = Y[k] * v_rgb[2];
+    float s = coeff[3 * k + 0] * v_rgb[0] + coeff[3 * k + 1] * v_rgb[1] + coeff[3 * k + 2] * v_rgb[2];
+    vx += Yx[k] * s; vy += Yy[k] * s; vz += Yz[k] * s;
+  }
+  float d = vx * x + vy * y + vz * z;
+  v_dir[0] = (vx - d * x) * inv;
+  v_dir[1] = (vy - d * y) * inv;
+  v_dir[2] = (vz - d * z) * inv;
+}
+
 }  // namespace mgs
 #endif  // MGS_MATH_H_

@@ -1,4 +1,260 @@
-// placeholder until the raster backward lands (returns MGS_ERR_UNSUPPORTED)
-#include "mgs_common.h"
+// raster_bwd.hip -- per-tile alpha compositing, backward (A.2 step 10), gfx950.
+//
+// Same geometry as the forward (raster_common.h): one wave64 per 16x16 tile, four pixels per
+// lane, the tile's list walked BACK TO FRONT in batches of 64 with the same exact quadrant
+// cull and ballot-compacted wave-private LDS queue.  Per Gaussian each lane sums the
+// contributions of its (up to) four pixels, the wave reduces the 6 + channels partial sums
+// with DPP row operations, and lane 63 issues one hardware float atomic per component --
+// one atomic set per (tile, Gaussian) pair instead of one per pixel.
+#include "raster_common.h"
+
+namespace mgs {
+namespace {
+
+template <int CHT>
+struct BwdEntry {
+  float4 geo0;                       // mean.x, mean.y, conic.a, conic.b
+  float4 geo1;                       // conic.c, opacity, quadrant mask (bits), list index (bits)
+  float4 feat[(CHT + 3) / 4];
+  int gid;
+  int pad[3];
+};
+
+template <int CHT>
+struct BwdPixel {
+  float T;            // transmittance in front of the Gaussian being processed
+  float T_final;
+  float v_alpha;      // d loss / d alpha_out (minus the background term)
+  float buf[CHT];     // colour accumulated BEHIND the current Gaussian
+  float v_c[CHT];     // d loss / d render
+  int last;
+};
+
+template <int CHT>
+struct GaussGrad {
+  float v_x, v_y, v_ca, v_cb, v_cc, v_op, a_x, a_y;
+  float v_f[CHT];
+};
+
+template <int CHT, bool ABSGRAD>
+__device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, float pxf,
+                                           float pyf, float mx, float my, float ca, float cb,
+                                           float cc, float opac, const float* feat, int idx) {
+  float dx = mx - pxf, dy = my - pyf;
+  float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+  float vis = __expf(-sigma);
+  float alpha = fminf(kAlphaMax, opac * vis);
+  bool valid = idx <= px.last && sigma >= 0.f && alpha >= kAlphaMin;
+  if (valid) {
+    float ra = 1.0f / (1.0f - alpha);
+    px.T *= ra;
+    float fac = alpha * px.T;
+    float v_alpha = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHT; ++c) {
+      gg.v_f[c] += fac * px.v_c[c];
+      v_alpha += (feat[c] * px.T - px.buf[c] * ra) * px.v_c[c];
+      px.buf[c] += feat[c] * fac;
+    }
+    v_alpha += px.T_final * ra * px.v_alpha;
+    if (opac * vis <= kAlphaMax) {
+      float v_sigma = -opac * vis * v_alpha;
+      gg.v_ca += 0.5f * v_sigma * dx * dx;
+      gg.v_cb += v_sigma * dx * dy;
+      gg.v_cc += 0.5f * v_sigma * dy * dy;
+      float gx = v_sigma * (ca * dx + cb * dy), gy = v_sigma * (cb * dx + cc * dy);
+      gg.v_x += gx;
+      gg.v_y += gy;
+      if (ABSGRAD) { gg.a_x += fabsf(gx); gg.a_y += fabsf(gy); }
+      gg.v_op += vis * v_alpha;
+    }
+  }
+  return valid;
+}
+
+template <int CHT, bool ABSGRAD>
+__global__ __launch_bounds__(64) void raster_bwd_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ feats, const float* __restrict__ opacities,
+    const float* __restrict__ background, int channels, int width, int height, int tile_w,
+    int n_tiles, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
+    const float* __restrict__ v_alphas, float* __restrict__ v_means2d,
+    float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
+    float* __restrict__ v_feats, float* __restrict__ v_opacities) {
+  __shared__ BwdEntry<CHT> queue[kQueue];
+  const int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  const unsigned lane = threadIdx.x;
+  const int tx = tile % tile_w, ty = tile / tile_w;
+  const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
+  const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  if (end <= start) return;
+  const int ix = tx * 16 + (int)(lane & 7), iy = ty * 16 + (int)(lane >> 3);
+  const float px0 = (float)ix + 0.5f, py0 = (float)iy + 0.5f;
+
+  BwdPixel<CHT> st[4];
+  int hi = -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = ix + 8 * (k & 1), y = iy + 8 * (k >> 1);
+    const bool inside = x < width && y < height;
+    const size_t p = inside ? (size_t)y * width + x : 0;
+    st[k].T_final = inside ? 1.0f - alphas[p] : 1.f;
+    st[k].T = st[k].T_final;
+    st[k].last = inside ? last_ids[p] : -1;
+    float va = inside ? v_alphas[p] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CHT; ++c) {
+      st[k].buf[c] = 0.f;
+      st[k].v_c[c] = (inside && c < channels) ? v_render[p * channels + c] : 0.f;
+      if (background && c < channels) va -= background[c] * st[k].v_c[c];
+    }
+    st[k].v_alpha = va;
+    hi = max(hi, st[k].last);
+  }
+  // wave-wide maximum of the last contributing index
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) hi = max(hi, __shfl_xor(hi, d));
+  hi = min(hi, end - 1);
+  if (hi < start) return;
+
+  for (int q = (hi - start) / kQueue; q >= 0; --q) {
+    const int b = start + q * kQueue;
+    // quadrants that still have a pixel with something left at or above this batch
+    unsigned live = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (__ballot(st[k].last >= b) != 0ull) live |= 1u << k;
+    if (live == 0) continue;
+
+    const int idx = b + (int)lane;
+    unsigned qmask = 0;
+    int g = 0;
+    float2 xy = make_float2(0.f, 0.f);
+    float ca = 1.f, cb = 0.f, cc = 1.f, op = 0.f;
+    if (idx <= hi) {
+      g = flatten_ids[idx];
+      xy = reinterpret_cast<const float2*>(means2d)[g];
+      ca = conics[3 * (size_t)g + 0];
+      cb = conics[3 * (size_t)g + 1];
+      cc = conics[3 * (size_t)g + 2];
+      op = opacities[g];
+      qmask = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, tile_x, tile_y) & live;
+    }
+    const unsigned long long keep = __ballot(qmask != 0u);
+    const int count = __popcll(keep);
+    if (qmask != 0u) {
+      BwdEntry<CHT>& e = queue[mask_rank(keep)];
+      e.geo0 = make_float4(xy.x, xy.y, ca, cb);
+      e.geo1 = make_float4(cc, op, __uint_as_float(qmask), __int_as_float(idx));
+      e.gid = g;
+      float f[((CHT + 3) / 4) * 4];
+#pragma unroll
+      for (int c = 0; c < ((CHT + 3) / 4) * 4; ++c)
+        f[c] = (c < CHT && c < channels) ? feats[(size_t)g * channels + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < (CHT + 3) / 4; ++j)
+        e.feat[j] = make_float4(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    for (int j = count - 1; j >= 0; --j) {
+      const BwdEntry<CHT>& e = queue[j];
+      const float4 g0 = e.geo0, g1 = e.geo1;
+      float feat[CHT];
+#pragma unroll
+      for (int f = 0; f < (CHT + 3) / 4; ++f) {
+        float4 v = e.feat[f];
+        feat[4 * f] = v.x;
+        if (4 * f + 1 < CHT) feat[4 * f + 1] = v.y;
+        if (4 * f + 2 < CHT) feat[4 * f + 2] = v.z;
+        if (4 * f + 3 < CHT) feat[4 * f + 3] = v.w;
+      }
+      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z));
+      const int gi = __float_as_int(g1.w);
+      const int gid = __builtin_amdgcn_readfirstlane(e.gid);
+      GaussGrad<CHT> gg;
+      gg.v_x = gg.v_y = gg.v_ca = gg.v_cb = gg.v_cc = gg.v_op = gg.a_x = gg.a_y = 0.f;
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) gg.v_f[c] = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (m & (1u << k))
+          any |= grad_pixel<CHT, ABSGRAD>(st[k], gg, px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1),
+                                          g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, gi);
+      }
+      if (__ballot(any) == 0ull) continue;
+      // wave reduction, then one atomic per component from lane 63
+      float rx = wave_reduce_to_lane63(gg.v_x), ry = wave_reduce_to_lane63(gg.v_y);
+      float ra = wave_reduce_to_lane63(gg.v_ca), rb = wave_reduce_to_lane63(gg.v_cb);
+      float rc = wave_reduce_to_lane63(gg.v_cc), ro = wave_reduce_to_lane63(gg.v_op);
+      float rf[CHT];
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) rf[c] = wave_reduce_to_lane63(gg.v_f[c]);
+      float ax = 0.f, ay = 0.f;
+      if (ABSGRAD) { ax = wave_reduce_to_lane63(gg.a_x); ay = wave_reduce_to_lane63(gg.a_y); }
+      if (lane == 63) {
+        unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 0], rx);
+        unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 1], ry);
+        unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 0], ra);
+        unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 1], rb);
+        unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 2], rc);
+        unsafeAtomicAdd(&v_opacities[gid], ro);
+#pragma unroll
+        for (int c = 0; c < CHT; ++c)
+          if (c < channels) unsafeAtomicAdd(&v_feats[(size_t)gid * channels + c], rf[c]);
+        if (ABSGRAD) {
+          unsafeAtomicAdd(&v_means2d_abs[2 * (size_t)gid + 0], ax);
+          unsafeAtomicAdd(&v_means2d_abs[2 * (size_t)gid + 1], ay);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+}  // namespace mgs
+
 using namespace mgs;
-extern "C" int mgs_rasterize_bwd(int, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, const int32_t*, const int32_t*, const float*, const int32_t*, const float*, const float*, float*, float*, float*, float*, float*, mgs_stream_t) { return set_error(MGS_ERR_UNSUPPORTED, "rasterize_bwd: not built yet"); }
+
+extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conics,
+                                 const float* feats, const float* opacities,
+                                 const float* background, int channels, int width, int height,
+                                 int tile_w, int tile_h, const int32_t* tile_offsets,
+                                 const int32_t* flatten_ids, const float* alphas,
+                                 const int32_t* last_ids, const float* v_render,
+                                 const float* v_alphas, float* v_means2d, float* v_means2d_abs,
+                                 float* v_conics, float* v_feats, float* v_opacities,
+                                 mgs_stream_t stream) {
+  MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "rasterize_bwd: bad sizes");
+  MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_bwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
+  MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
+              "rasterize_bwd: tile grid does not match the image at tile size 16");
+  MGS_REQUIRE(means2d && conics && feats && opacities && tile_offsets && flatten_ids && alphas &&
+                  last_ids && v_render && v_alphas && v_means2d && v_conics && v_feats &&
+                  v_opacities, "rasterize_bwd: null pointer");
+  const int n_tiles = tile_w * tile_h;
+  hipStream_t s = (hipStream_t)stream;
+#define MGS_RB_LAUNCH(C, A)                                                                    \
+  hipLaunchKernelGGL((raster_bwd_kernel<C, A>), dim3(n_tiles), dim3(64), 0, s, means2d, conics, \
+                     feats, opacities, background, channels, width, height, tile_w, n_tiles,   \
+                     tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas,          \
+                     v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities)
+#define MGS_RB(C) if (v_means2d_abs) MGS_RB_LAUNCH(C, true); else MGS_RB_LAUNCH(C, false)
+  if (channels == 1) { MGS_RB(1); }
+  else if (channels == 2) { MGS_RB(2); }
+  else if (channels == 3) { MGS_RB(3); }
+  else if (channels == 4) { MGS_RB(4); }
+  else if (channels <= 8) { MGS_RB(8); }
+  else if (channels <= 16) { MGS_RB(16); }
+  else { MGS_RB(32); }
+#undef MGS_RB
+#undef MGS_RB_LAUNCH
+  return check_launch("rasterize_bwd");
+}

@@ -71,11 +71,12 @@ class _RenderSH(torch.autograd.Function):
         C, n = viewmats.shape[0], means.shape[0]
         v_render = _f32c(v_render)
         v_alphas = _f32c(v_alphas).reshape(C, height, width)
-        v_means = torch.zeros_like(means)
-        v_quats = torch.zeros_like(quats)
-        v_scales = torch.zeros_like(scales)
-        v_sh = torch.zeros_like(sh_coeffs)
-        v_opacities = torch.zeros_like(opacities)
+        # the first camera overwrites the outputs, later ones accumulate: no zero-fill pass
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_sh = torch.empty_like(sh_coeffs)
+        v_opacities = torch.empty_like(opacities) if antialiased else None
         L = _lib.lib()
         for c in range(C):
             radii, means2d, depths, conics, opac_aa, feats, tl = ctx.per_cam[c]
@@ -92,9 +93,10 @@ class _RenderSH(torch.autograd.Function):
                 eps2d, ptr(radii), ptr(conics), int(antialiased), feats.shape[1], ptr(feats),
                 ptr(v_feats), ptr(v_means2d), ptr(v_conics), None,
                 ptr(v_opac) if antialiased else None, ptr(v_means), ptr(v_quats), ptr(v_scales),
-                ptr(v_sh), ptr(v_opacities), stream_handle()), "mgs_project_color_bwd")
+                ptr(v_sh), ptr(v_opacities), int(c > 0), stream_handle()),
+                "mgs_project_color_bwd")
             if not antialiased:
-                v_opacities += v_opac
+                v_opacities = v_opac if v_opacities is None else v_opacities + v_opac
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[7]:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
