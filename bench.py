@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one forward render of the 1 M-Gaussian, SH-degree-3 synthetic scene at 1920x1080
+(BASELINE.json configs[1]) per rank: projection+SH, tile binning, tile raster, all through
+the C ABI of libmgs.so, replayed as one HIP graph with the scene resident in HBM.  For N > 1
+(launched by torch.distributed.run, one process per GPU over RCCL) every rank renders its own
+camera of the ring and rank 0 gathers the finished fp32 RGB frames (config 4's collective);
+value = frames all ranks rendered / max-over-ranks time, so scaling is weak.
+
+Rank 0 prints ONE JSON line.  Beside the contract fields it carries
+  roofline      tile-raster forward kernel: algorithmic bytes / HIP-event time vs 8 TB/s
+  cpu_baseline  the C++/OpenMP port in oracle/gs_cpu.cpp timed on this box's host cores
+  fwd_bwd       the training-step variant (configs[2]): forward + L1 loss + backward
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from robosimgs_amd import camera_ring, synthetic_scene  # noqa: E402
+from robosimgs_amd import ops  # noqa: E402
+from robosimgs_amd.rendering import rasterization  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--log-scale-mean", type=float, default=math.log(0.012))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--bwd-steps", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H, deg = a.width, a.height, a.sh_degree
+    scene = synthetic_scene(a.n, a.log_scale_mean, deg, seed=0)
+    theta = 0.3 + 2.0 * math.pi * rank / world
+    cam = camera_ring(1, W, H, thetas=[theta])[0]
+    t = scene.to_torch(dev, deg)
+    vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)[None]
+    K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)[None]
+    tile_w, tile_h = -(-W // 16), -(-H // 16)
+
+    def forward(cap=None):
+        return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                             vm, K, W, H, sh_degree=deg, render_mode="RGB", isect_capacity=cap)
+
+    # sizing pass (reads n_isect back once, outside every timed region)
+    colors, alphas, meta = forward()
+    torch.cuda.synchronize()
+    n_isect = int(meta["n_isects"][0])
+    n_vis = int((meta["radii"] > 0).sum())
+    cap = int(n_isect * 1.25) + 4096
+
+    # ---- forward frame as one HIP graph -------------------------------------------------
+    side = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            forward(cap)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            g_colors, g_alphas, g_meta = forward(cap)
+    torch.cuda.synchronize()
+
+    do_gather = world > 1 and not a.no_gather
+    gather_bufs = None
+    if do_gather and rank == 0:
+        gather_bufs = [[torch.empty_like(g_colors) for _ in range(world)] for _ in range(2)]
+    send_bufs = [torch.empty_like(g_colors) for _ in range(2)] if do_gather else None
+    pending = []
+
+    def step(i):
+        graph.replay()
+        if do_gather:
+            # double-buffered: the collective of frame i overlaps the render of frame i+1
+            slot = i & 1
+            if len(pending) >= 2:
+                pending.pop(0).wait()
+            send_bufs[slot].copy_(g_colors, non_blocking=True)
+            pending.append(dist.gather(send_bufs[slot], gather_bufs[slot] if rank == 0 else None,
+                                       dst=0, async_op=True))
+
+    for i in range(a.warmup):
+        step(i)
+    while pending:
+        pending.pop(0).wait()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    while pending:
+        pending.pop(0).wait()
+    barrier_sync(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    status = int(g_meta["isect_status"].max().item())
+    assert status == 0, "tile-intersection capacity overflow inside the timed region"
+    frames_per_s = world * a.steps / elapsed
+    ms_per_step = elapsed / a.steps * 1e3
+
+    result = {
+        "metric": "frames/sec + ms/frame (fwd, fwd+bwd) at 1M Gaussians 1920x1080",
+        "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {a.n} Gaussians, SH degree {deg}, {W}x{H} forward "
+                               "render, one camera per GPU",
+                   "n_gaussians": a.n, "n_visible": n_vis, "n_isect": n_isect,
+                   "tiles": tile_w * tile_h, "cameras_per_step": world,
+                   "gather": "fp32 RGB frames to rank 0 (RCCL)" if do_gather else "none",
+                   "launch": "one HIP graph per frame, no host read-back"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (tile raster forward), HIP events on the stream
+        radii, m2d, depths, con, _, feats = ops.project_color_fwd_raw(
+            t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W,
+            H, 0.3, 0.01, 1e10, 0.0, False, False)
+        tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False)
+        out = None
+        reps = 50
+        for _ in range(5):
+            out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
+                                        tl.tile_offsets, tl.flatten_ids, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
+                                  tl.tile_offsets, tl.flatten_ids, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        raster_ms = e0.elapsed_time(e1) / reps
+        n_px = W * H
+        algo_bytes = n_isect * 44 + n_px * 24 + tile_w * tile_h * 8
+        achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
+        result["roofline"] = {"kernel": "raster_fwd_kernel<3>", "bound": "hbm",
+                              "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                              "algorithmic_bytes": algo_bytes,
+                              "kernel_ms": round(raster_ms, 4),
+                              "note": "VALU/exp-bound kernel (SURVEY.md 7): the HBM fraction is "
+                                      "reported as the contract asks; see DESIGN.md"}
+
+        # ---- training-step variant (configs[2]): forward + L1 + backward ------------------
+        try:
+            result["fwd_bwd"] = bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev)
+        except Exception as e:  # keep the headline line even if this leg fails
+            result["fwd_bwd"] = {"error": repr(e)[:200]}
+
+        # ---- CPU baseline: the oracle's C++/OpenMP port on this box's host cores -----------
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(scene, cam, W, H, deg, a.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
+    names = ("means", "quats", "scales", "opacities", "colors")
+    params = {k: t[k].detach().clone().requires_grad_(True) for k in names}
+    target = torch.rand(1, H, W, 3, device=dev, generator=torch.Generator(dev).manual_seed(1))
+
+    def train_step():
+        for p in params.values():
+            p.grad = None
+        colors, alphas, meta = rasterization(params["means"], params["quats"], params["scales"],
+                                             params["opacities"], params["colors"], vm, K, W, H,
+                                             sh_degree=deg, render_mode="RGB", isect_capacity=cap)
+        loss = (colors - target).abs().mean()
+        loss.backward()
+        return loss
+
+    for _ in range(3):
+        train_step()
+    torch.cuda.synchronize()
+    mode = "eager"
+    runner = train_step
+    try:
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):
+            train_step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                train_step()
+        torch.cuda.synchronize()
+        runner, mode = g.replay, "hip-graph"
+    except Exception:
+        torch.cuda.synchronize()
+    for _ in range(3):
+        runner()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.bwd_steps):
+        runner()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.bwd_steps
+    return {"workload": "configs[2]: forward + L1 loss to U(0,1) target (seed 1) + backward",
+            "ms_per_step": round(dt * 1e3, 4), "steps_per_s": round(1.0 / dt, 2),
+            "steps": a.bwd_steps, "launch": mode}
+
+
+def cpu_baseline(scene, cam, W, H, deg, budget_s):
+    from oracle import cpu_ref
+    threads = cpu_ref.max_threads()
+    args = (scene.means, scene.quats, scene.scales, scene.opacities, scene.sh_coeffs,
+            cam.viewmat(), cam.K, W, H, deg)
+    cpu_ref.render(*args)                                   # warm-up (page-in, thread pool)
+    times = []
+    t_start = time.perf_counter()
+    while (time.perf_counter() - t_start) < budget_s and len(times) < 50:
+        t0 = time.perf_counter()
+        _, _, info = cpu_ref.render(*args)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} full frames of the same 1M-Gaussian 1080p workload after 1 "
+                      f"warm-up, median {med * 1e3:.1f} ms/frame; oracle/gs_cpu.cpp, OpenMP, "
+                      f"{threads} threads on {model}",
+            "pair_evals": info["pair_evals"]}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""Build + ctypes binding of oracle/gs_cpu.cpp (TEST INFRASTRUCTURE ONLY; see its header).
+Used by tests/ as the large-scene checker and by bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "gs_cpu.cpp")
+LIB = os.path.join(HERE, "_build", "libgs_cpu.so")
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        # no -march=native: the .so is built in the dev container and runs on the GPU box's host
+        subprocess.run(["g++", "-O3", "-std=c++17", "-fopenmp", "-shared", "-fPIC", SRC, "-o", LIB],
+                       check=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.gs_cpu_render.restype = ctypes.c_longlong
+        _lib.gs_cpu_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def max_threads() -> int:
+    return lib().gs_cpu_max_threads()
+
+
+def render(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height, sh_degree,
+           with_depth=False, background=None, eps2d=0.3, near_plane=0.01, far_plane=1e10,
+           radius_clip=0.0, n_threads=0):
+    """Forward frame on the host.  Returns (render[H,W,ch], alpha[H,W], info dict)."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    means, quats, scales, opacities, sh = f(means), f(quats), f(scales), f(opacities), f(sh_coeffs)
+    vm, Km = f(viewmat), f(K)
+    n, ch = means.shape[0], 4 if with_depth else 3
+    out = np.empty((height, width, ch), np.float32)
+    alpha = np.empty((height, width), np.float32)
+    counters = np.zeros(2, np.int64)
+    bg = f(background) if background is not None else None
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    cf = ctypes.c_float
+    n_isect = lib().gs_cpu_render(n, p(means), p(quats), p(scales), p(opacities), int(sh_degree),
+                                  sh.shape[1], p(sh), p(vm), p(Km), int(width), int(height),
+                                  cf(eps2d), cf(near_plane), cf(far_plane), cf(radius_clip), ch,
+                                  p(bg), int(n_threads), p(out), p(alpha), p(counters))
+    return out, alpha, {"n_isect": int(n_isect), "n_vis": int(counters[0]),
+                        "pair_evals": int(counters[1])}
