@@ -156,17 +156,23 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store)
         per_cam = store["per_cam"]
+
+        def _stk(xs):                 # no copy for the common single-camera call
+            return xs[0].unsqueeze(0) if len(xs) == 1 else torch.stack(xs)
+
+        def _cat(xs):
+            return xs[0] if len(xs) == 1 else torch.cat(xs)
         meta.update(
-            radii=torch.stack([p[0] for p in per_cam]),
-            means2d=torch.stack([p[1] for p in per_cam]),
-            depths=torch.stack([p[2] for p in per_cam]),
-            conics=torch.stack([p[3] for p in per_cam]),
-            opacities=(torch.stack([p[4] for p in per_cam]) if antialiased
+            radii=_stk([p[0] for p in per_cam]),
+            means2d=_stk([p[1] for p in per_cam]),
+            depths=_stk([p[2] for p in per_cam]),
+            conics=_stk([p[3] for p in per_cam]),
+            opacities=(_stk([p[4] for p in per_cam]) if antialiased
                        else opacities.unsqueeze(0).expand(C, N)),
-            tiles_per_gauss=torch.stack([p[6].tiles_per_gauss for p in per_cam]),
-            n_isects=torch.cat([p[6].n_isect for p in per_cam]),
-            isect_status=torch.cat([p[6].status for p in per_cam]),
-            isect_offsets=torch.stack([p[6].tile_offsets[:-1].view(tile_h, tile_w) for p in per_cam]),
+            tiles_per_gauss=_stk([p[6].tiles_per_gauss for p in per_cam]),
+            n_isects=_cat([p[6].n_isect for p in per_cam]),
+            isect_status=_cat([p[6].status for p in per_cam]),
+            isect_offsets=_stk([p[6].tile_offsets[:-1].view(tile_h, tile_w) for p in per_cam]),
             tile_lists=[p[6] for p in per_cam])
     else:
         # feature path: colours are given per Gaussian (or evaluated from SH for "D"/"ED")

@@ -1,0 +1,34 @@
+"""Run one stage of the config-2 frame repeatedly (for rocprofv3 --pmc passes).
+usage: run_stage.py {raster|raster_bwd|binning|project|frame} [reps]"""
+import math, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from robosimgs_amd import synthetic_scene, camera_ring, ops
+stage = sys.argv[1] if len(sys.argv) > 1 else "raster"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+n, mu, W, H, deg = int(os.environ.get("N", 1_000_000)), float(os.environ.get("MU", 0.012)), int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080)), 3
+dev = "cuda"
+g = synthetic_scene(n, math.log(mu), deg, 0)
+cam = camera_ring(1, W, H, thetas=[0.3])[0]
+t = g.to_torch(dev, deg)
+vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)
+K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)
+tw, th = -(-W // 16), -(-H // 16)
+def project():
+    return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, False)
+radii, m2d, dep, con, _, feats = project()
+tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 else 8_000_000, want_tiles_per_gauss=False)
+out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids)
+torch.cuda.synchronize()
+print("n_isect", int(tl.n_isect))
+vr = torch.rand(H, W, 3, device=dev); va = torch.rand(H, W, device=dev)
+for _ in range(reps):
+    if stage == "raster":
+        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out)
+    elif stage == "raster_bwd":
+        ops.rasterize_bwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out[1], out[2], vr, va)
+    elif stage == "binning":
+        ops.isect_tiles_raw(m2d, radii, dep, tw, th, 8_000_000, want_tiles_per_gauss=False)
+    elif stage == "project":
+        project()
+torch.cuda.synchronize()

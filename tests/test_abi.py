@@ -1,0 +1,71 @@
+"""The drop-in boundary: include/mgs.h <-> libmgs.so <-> the ctypes table, and the rule that the
+product never reaches into oracle/ (no compute calls here: CPU-only)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mgs.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = re.findall(r"\b(?:int|const char \*)\s*\*?\s*(mgs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    return {name: 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
+            for name, args in decls}
+
+
+def test_header_symbols_are_exported_and_bound():
+    from robosimgs_amd import _lib
+    decl = _declared()
+    assert len(decl) == 12, sorted(decl)
+    assert sorted(decl) == sorted(_lib.EXPORTS)
+    L = _lib.lib()
+    for name, nargs in decl.items():
+        fn = getattr(L, name)
+        assert len(fn.argtypes) == nargs, f"{name}: header has {nargs} parameters, ctypes table {len(fn.argtypes)}"
+    assert L.mgs_version() == 100
+    assert isinstance(L.mgs_last_error_string(), bytes)
+
+
+def test_library_is_gfx950_only_and_links_no_torch():
+    from robosimgs_amd import _lib
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any("torch" in n or "c10" in n for n in needed), needed
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if os.path.exists(objdump):
+        o = subprocess.run([objdump, "--offloading", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        archs = set(re.findall(r"gfx\w+", o))
+        assert archs == {"gfx950"}, archs
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from robosimgs_amd import _lib
+    L = _lib.lib()
+    rc = L.mgs_rasterize_fwd(1, None, None, None, None, None, 99, 16, 16, 1, 1, None, None, None, None, None, None)
+    assert rc == -1 and b"channels" in L.mgs_last_error_string()
+    rc = L.mgs_sh_fwd(4, 7, 16, None, None, None, None, None)
+    assert rc == -1 and b"degree" in L.mgs_last_error_string()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "robosimgs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "gs_cpu" not in text and "oracle/" not in text.replace("see oracle/", ""), f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from robosimgs_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.MgsError, match="no CPU or PyTorch fallback"):
+        _lib.lib()

@@ -1,0 +1,187 @@
+"""The oracle is unpinned by the reference (no renderer there), so it is validated
+independently of itself: closed-form cases, algebraic identities, fp32-vs-fp64 agreement,
+NumPy-loop vs torch-vectorised agreement, and autograd vs central finite differences."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gs_oracle_np as O
+from oracle import gs_oracle_torch as OT
+from robosimgs_amd import camera_ring, synthetic_scene
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_small.npz"))
+EYE_VIEW = np.eye(4)                       # camera at the origin looking down +Z (OpenCV)
+
+
+def _K(f, w, h):
+    return np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1.0]])
+
+
+def test_single_isotropic_gaussian_closed_form():
+    W = H = 64
+    f, z, s, o = 100.0, 4.0, 0.2, 0.7
+    K = _K(f, W, H)
+    means = np.array([[0.013, -0.021, z]])
+    img, alpha, meta = O.render(means, np.array([[1.0, 0, 0, 0]]), np.full((1, 3), s), np.array([o]),
+                                np.array([[0.3, 0.6, 0.9]]), EYE_VIEW, K, W, H, sh_degree=None)
+    mu = np.array([f * means[0, 0] / z + W / 2, f * means[0, 1] / z + H / 2])
+    np.testing.assert_allclose(meta["means2d"][0], mu, rtol=1e-12)
+    # EWA with J = [[f/z,0,-f x/z^2],[0,f/z,-f y/z^2]] on an isotropic Sigma = s^2 I
+    x, y = means[0, 0], means[0, 1]
+    J = np.array([[f / z, 0, -f * x / z ** 2], [0, f / z, -f * y / z ** 2]])
+    cov2 = J @ (s * s * np.eye(3)) @ J.T + 0.3 * np.eye(2)
+    conic = np.linalg.inv(cov2)
+    np.testing.assert_allclose(meta["conics"][0], [conic[0, 0], conic[0, 1], conic[1, 1]], rtol=1e-10)
+    lam = np.linalg.eigvalsh(cov2).max()
+    assert meta["radii"][0] == math.ceil(3 * math.sqrt(lam))
+    py, px = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing="ij")
+    d = np.stack([mu[0] - px, mu[1] - py], -1)
+    sigma = 0.5 * np.einsum("hwi,ij,hwj->hw", d, conic, d)
+    a = np.minimum(0.999, o * np.exp(-sigma))
+    a = np.where(a >= 1 / 255, a, 0.0)
+    # pixels outside the Gaussian's tile rectangle receive nothing
+    r = meta["radii"][0]
+    x0, x1 = math.floor((mu[0] - r) / 16) * 16, math.ceil((mu[0] + r) / 16) * 16
+    y0, y1 = math.floor((mu[1] - r) / 16) * 16, math.ceil((mu[1] + r) / 16) * 16
+    box = (px > x0) & (px < x1) & (py > y0) & (py < y1)
+    a = np.where(box, a, 0.0)
+    np.testing.assert_allclose(alpha[..., 0], a, atol=1e-13)
+    np.testing.assert_allclose(img, a[..., None] * np.array([0.3, 0.6, 0.9]), atol=1e-13)
+    c = int(mu[1]), int(mu[0])
+    assert abs(alpha[c[0], c[1], 0] - o) < 0.02          # centre pixel ~ opacity
+
+
+def test_two_gaussians_occlusion_order_and_saturation():
+    W = H = 32
+    K = _K(80.0, W, H)
+    means = np.array([[0.0, 0.0, 6.0], [0.0, 0.0, 3.0]])          # second is in front
+    cols = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    img, alpha, meta = O.render(means, np.tile([1.0, 0, 0, 0], (2, 1)), np.full((2, 3), 0.5),
+                                np.array([0.9, 0.6]), cols, EYE_VIEW, K, W, H)
+    order = meta["flatten_ids"][: 2]
+    assert list(order) == [1, 0]                                   # front-to-back
+    p = img[16, 16]
+    a_front = min(0.999, 0.6 * math.exp(-0.5 * 0.5 ** 2 * 2 * meta["conics"][1][0]))
+    assert abs(p[1] - a_front) < 1e-12 and abs(p[0] - (1 - a_front) * meta["opacities"][0] *
+                                               math.exp(-0.25 * meta["conics"][0][0])) < 1e-12
+    # opaque stack: T falls under 1e-4 and later Gaussians are ignored (stop BEFORE blending)
+    n = 40
+    means = np.stack([np.zeros(n), np.zeros(n), 3.0 + 0.1 * np.arange(n)], -1)
+    img, alpha, meta = O.render(means, np.tile([1.0, 0, 0, 0], (n, 1)), np.full((n, 3), 0.5),
+                                np.full(n, 0.9), np.ones((n, 3)), EYE_VIEW, K, W, H)
+    T = 1 - alpha[16, 16, 0]
+    assert 1e-4 < T < 1e-3
+    start = meta["isect_offsets"][1, 1]                            # pixel (16,16) lies in tile (1,1)
+    k = meta["last_ids"][16, 16] - start                           # list position of the last blended
+    assert 0 < k < n - 1
+    nxt = meta["flatten_ids"][start + k + 1]
+    d = meta["means2d"][nxt] - np.array([16.5, 16.5])
+    c = meta["conics"][nxt]
+    a = min(0.999, 0.9 * math.exp(-(0.5 * (c[0] * d[0] ** 2 + c[2] * d[1] ** 2) + c[1] * d[0] * d[1])))
+    assert T * (1 - a) <= 1e-4                                      # the next one crosses 1e-4
+
+
+def test_projection_identities():
+    g = synthetic_scene(3000, math.log(0.1), 0, 3)
+    cam = camera_ring(1, 160, 120, thetas=[1.1])[0]
+    p = O.project(g.means, g.quats, g.scales, cam.viewmat(), cam.K, 160, 120)
+    vis = p["radii"] > 0
+    assert 1000 < vis.sum() < 3000
+    # conic * (cov2d + 0.3 I) == I, via an independent route (finite-difference Jacobian)
+    Rcw, t = cam.viewmat()[:3, :3], cam.viewmat()[:3, 3]
+    cov = O.covar_world(g.quats, g.scales)
+    for i in np.nonzero(vis)[0][:40]:
+        pc = Rcw @ g.means[i].astype(np.float64) + t
+        lim = 1.3 * 0.5 * 160 / cam.fx
+        if abs(pc[0] / pc[2]) > lim * 0.95 or abs(pc[1] / pc[2]) > 1.3 * 0.5 * 120 / cam.fy * 0.95:
+            continue                                           # clamped-Jacobian region
+
+        def proj(q):
+            return np.array([cam.fx * q[0] / q[2] + cam.cx, cam.fy * q[1] / q[2] + cam.cy])
+        J = np.stack([(proj(pc + 1e-6 * e) - proj(pc - 1e-6 * e)) / 2e-6 for e in np.eye(3)], 1)
+        cov2 = J @ Rcw @ cov[i] @ Rcw.T @ J.T + 0.3 * np.eye(2)
+        C = np.array([[p["conics"][i, 0], p["conics"][i, 1]], [p["conics"][i, 1], p["conics"][i, 2]]])
+        np.testing.assert_allclose(C @ cov2, np.eye(2), atol=1e-6)
+        assert p["radii"][i] == math.ceil(3 * math.sqrt(max(np.linalg.eigvalsh(cov2).max(),
+                                                            0.5 * np.trace(cov2) + 0.1)))
+        det0 = np.linalg.det(cov2 - 0.3 * np.eye(2))
+        assert abs(p["compensations"][i] - math.sqrt(max(0, det0 / np.linalg.det(cov2)))) < 1e-7
+    # fp32 evaluation agrees with fp64 (device-rounding proxy)
+    q = O.project(g.means, g.quats, g.scales, cam.viewmat(), cam.K, 160, 120, dtype=np.float32)
+    both = vis & (q["radii"] > 0)
+    assert (vis != (q["radii"] > 0)).sum() <= 1
+    np.testing.assert_allclose(q["means2d"][both], p["means2d"][both], rtol=3e-5, atol=3e-3)
+    np.testing.assert_allclose(q["conics"][both], p["conics"][both], rtol=5e-4, atol=1e-6)
+
+
+def test_tile_lists_are_sorted_and_complete():
+    g = GOLD
+    ids, flat, offs = g["isect_ids"], g["flatten_ids"], g["isect_offsets"]
+    assert np.all(np.diff(ids) >= 0) and len(ids) == int(g["n_isect"]) == int(g["tiles_per_gauss"].sum())
+    tw = offs.shape[1]
+    tile = ids >> 32
+    # every pair (gaussian, tile in its rectangle) appears exactly once
+    x0, x1, y0, y1 = O.tile_rects(g["means2d"], g["radii"], 16, offs.shape[1], offs.shape[0])
+    expect = set()
+    for i in np.nonzero(g["radii"] > 0)[0]:
+        for y in range(y0[i], y1[i]):
+            for x in range(x0[i], x1[i]):
+                expect.add((int(i), y * tw + x))
+    assert expect == set(zip(flat.tolist(), tile.tolist()))
+    # depth order inside a tile, ties by Gaussian index
+    d = g["depths"].astype(np.float32)[flat]
+    same = tile[1:] == tile[:-1]
+    assert np.all((d[1:] >= d[:-1]) | ~same)
+    np.testing.assert_array_equal(offs.reshape(-1), np.searchsorted(tile, np.arange(offs.size)))
+
+
+def test_numpy_loop_equals_torch_vectorised_and_golden():
+    g = GOLD
+    W, H, deg = int(g["width"]), int(g["height"]), int(g["sh_degree"])
+    img, alpha, meta = O.render(g["means"], g["quats"], g["scales"], g["opacities"], g["sh_coeffs"],
+                                g["viewmat"], g["K"], W, H, sh_degree=deg)
+    np.testing.assert_allclose(img, g["RGB_image"], atol=1e-14)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))
+    timg, talpha, _ = OT.render(t(g["means"]), t(g["quats"]), t(g["scales"]), t(g["opacities"]),
+                                t(g["sh_coeffs"]), t(g["viewmat"]), t(g["K"]), W, H, sh_degree=deg)
+    np.testing.assert_allclose(timg.numpy(), img, atol=1e-13)
+    np.testing.assert_allclose(talpha.numpy(), alpha, atol=1e-13)
+    # the "expected depth" mode divides the depth channel by alpha
+    ed = g["RGB_ED_image"]
+    a = g["RGB_ED_alpha"][..., 0]
+    assert np.all(ed[..., 3][a > 0.5] > 2.0) and np.all(ed[..., 3][a == 0] == 0)
+
+
+def test_autograd_matches_finite_differences():
+    g = GOLD
+    W, H, deg = int(g["width"]), int(g["height"]), int(g["sh_degree"])
+    wi, wa = torch.tensor(g["w_img"]), torch.tensor(g["w_alpha"])
+    base = {k: np.asarray(g[k], dtype=np.float64) for k in ("means", "quats", "scales", "opacities", "sh_coeffs")}
+
+    def loss(vals):
+        t = {k: torch.tensor(v) for k, v in vals.items()}
+        img, al, _ = OT.render(t["means"], t["quats"], t["scales"], t["opacities"], t["sh_coeffs"],
+                               torch.tensor(g["viewmat"]), torch.tensor(g["K"]), W, H, sh_degree=deg)
+        return float((img * wi).sum() + (al[..., 0] * wa).sum())
+    rng = np.random.default_rng(0)
+    vis = np.nonzero(g["radii"] > 0)[0]
+    checked = 0
+    for name in ("means", "quats", "scales", "opacities", "sh_coeffs"):
+        grad = g["grad_" + name]
+        for _ in range(6):
+            i = rng.choice(vis)
+            idx = (i,) + tuple(rng.integers(0, s) for s in base[name].shape[1:])
+            h = 1e-6 * max(1.0, abs(base[name][idx]))
+            up, dn = {k: v.copy() for k, v in base.items()}, {k: v.copy() for k, v in base.items()}
+            up[name][idx] += h
+            dn[name][idx] -= h
+            fd = (loss(up) - loss(dn)) / (2 * h)
+            if abs(fd - grad[idx]) > 1e-4 * max(1.0, abs(fd)):
+                # a perturbation may flip an alpha >= 1/255 test; accept only tiny discontinuities
+                assert abs(fd - grad[idx]) < 5e-2 * max(1.0, abs(fd)), (name, idx, fd, grad[idx])
+            else:
+                checked += 1
+    assert checked >= 24
