@@ -16,7 +16,7 @@ HEADERS = ["mgs_common.h", "mgs_math.h", "raster_common.h", "../../include/mgs.h
 LIB = os.path.join(HERE, "libmgs.so")
 OBJ_DIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("MGS_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -4,16 +4,23 @@
 // effort on evaluating fewer pairs, not on moving bytes.
 #include "raster_common.h"
 
+#ifndef MGS_RASTER_WAVES
+#define MGS_RASTER_WAVES 4   // min waves per SIMD asked of the register allocator; measured: 8/6/5 spill and lose (522/356/313 us), 4 = 292 us
+#endif
+
 namespace mgs {
 namespace {
 
 template <int CHT>
 struct QueueEntry {
-  float4 geo0;                       // mean.x, mean.y, conic.a, conic.b
-  float4 geo1;                       // conic.c, opacity, quadrant mask (bits), list index (bits)
+  float4 geo0;                       // mean.x, mean.y, A, B   (A,B,C: conic pre-scaled, below)
+  float4 geo1;                       // C, opacity, quadrant mask (bits), list index (bits)
   float4 feat[(CHT + 3) / 4];
 };
 
+// Per-pixel state.  T > 0: transmittance, pixel still open.  T < 0: pixel finished, |T| is its
+// final transmittance (the "done" flag of A.2 step 9 lives in the sign bit, so the blend needs
+// no separate flag and a finished pixel can never accumulate again: T*(1-alpha) < 0 < 1e-4).
 template <int CHT>
 struct PixelState {
   float T;
@@ -21,28 +28,31 @@ struct PixelState {
   int last;
 };
 
+constexpr float kLog2e = 1.4426950408889634f;
+
 // One Gaussian against the 64 pixels of one quadrant (one pixel per lane).
+//   power = -sigma * log2(e) = A dx^2 + C dy^2 + B dx dy  with  A = -0.5 log2e a, B = -log2e b,
+//   C = -0.5 log2e c, so exp(-sigma) is a single v_exp_f32 and "sigma >= 0" is "power <= 0".
 template <int CHT>
-__device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, bool& done, float pxf, float pyf,
-                                            float mx, float my, float ca, float cb, float cc,
-                                            float opac, const float* feat, int idx) {
+__device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, float pyf, float mx,
+                                            float my, float A, float B, float C, float opac,
+                                            const float* feat, int idx) {
   float dx = mx - pxf, dy = my - pyf;
-  float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-  float alpha = fminf(kAlphaMax, opac * __expf(-sigma));
-  bool valid = !done && sigma >= 0.f && alpha >= kAlphaMin;
-  float next_T = px.T * (1.0f - alpha);
-  bool stop = valid && next_T <= kTStop;
-  done = done || stop;
-  bool acc = valid && !stop;
+  float power = dx * fmaf(B, dy, A * dx) + (C * dy) * dy;
+  float alpha = fminf(kAlphaMax, opac * __builtin_amdgcn_exp2f(power));
+  bool valid = power <= 0.f && alpha >= kAlphaMin;
+  float next_T = fmaf(-alpha, px.T, px.T);
+  bool acc = valid && next_T > kTStop;            // false for finished pixels (T < 0)
   float w = acc ? alpha * px.T : 0.f;
 #pragma unroll
-  for (int c = 0; c < CHT; ++c) px.C[c] += w * feat[c];
-  px.T = acc ? next_T : px.T;
+  for (int c = 0; c < CHT; ++c) px.C[c] = fmaf(w, feat[c], px.C[c]);
+  float closed = valid ? -fabsf(px.T) : px.T;     // valid but not accumulated: the pixel finishes
+  px.T = acc ? next_T : closed;
   px.last = acc ? idx : px.last;
 }
 
 template <int CHT>
-__global__ __launch_bounds__(64) void raster_fwd_kernel(
+__global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_fwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
     const float* __restrict__ background, int channels, int width, int height, int tile_w,
@@ -62,14 +72,13 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(
   const float px0 = (float)ix + 0.5f, py0 = (float)iy + 0.5f;
 
   PixelState<CHT> st[4];
-  bool done[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    st[k].T = 1.f;
+    const bool inside = ix + 8 * (k & 1) < width && iy + 8 * (k >> 1) < height;
+    st[k].T = inside ? 1.f : -1.f;               // pixels outside the image start finished
     st[k].last = 0;
 #pragma unroll
     for (int c = 0; c < CHT; ++c) st[k].C[c] = 0.f;
-    done[k] = !(ix + 8 * (k & 1) < width && iy + 8 * (k >> 1) < height);
   }
 
   // raw batch registers (software prefetch of the next 64 list entries)
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(
     unsigned live = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (__ballot(!done[k]) != 0ull) live |= 1u << k;
+      if (__ballot(st[k].T > 0.f) != 0ull) live |= 1u << k;
     if (live == 0) break;
 
     // take the prefetched batch, start the next one
@@ -120,8 +129,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(
     const int count = __popcll(keep);
     if (qmask != 0u) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
-      e.geo0 = make_float4(c_xy.x, c_xy.y, c_ca, c_cb);
-      e.geo1 = make_float4(c_cc, c_op, __uint_as_float(qmask), __int_as_float(c_idx));
+      e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
+      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, c_op, __uint_as_float(qmask), __int_as_float(c_idx));
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
         float4 v;
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // (reading entry j+1 while blending entry j was measured slower: 307 vs 292 us)
     for (int j = 0; j < count; ++j) {
       const QueueEntry<CHT>& e = queue[j];
       const float4 g0 = e.geo0, g1 = e.geo1;
@@ -153,8 +163,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (m & (1u << k))
-          blend_pixel<CHT>(st[k], done[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y,
-                           g0.z, g0.w, g1.x, g1.y, feat, idx);
+          blend_pixel<CHT>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y, g0.z, g0.w,
+                           g1.x, g1.y, feat, idx);
       }
     }
     __builtin_amdgcn_wave_barrier();   // queue is rewritten by the next batch
@@ -168,8 +178,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(
 #pragma unroll
       for (int c = 0; c < CHT; ++c)
         if (c < channels)
-          render[p * channels + c] = st[k].C[c] + (background ? st[k].T * background[c] : 0.f);
-      alphas[p] = 1.0f - st[k].T;
+          render[p * channels + c] = st[k].C[c] + (background ? fabsf(st[k].T) * background[c] : 0.f);
+      alphas[p] = 1.0f - fabsf(st[k].T);
       last_ids[p] = st[k].last;
     }
   }

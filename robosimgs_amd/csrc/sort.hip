@@ -1,14 +1,19 @@
 // sort.hip -- stable LSD radix sort of (uint32 key, uint32 value) pairs for gfx950, with the
 // element count resident in device memory (no host read-back anywhere in the frame).
 //
-// 8 bits per pass, three kernels per pass:
+// Up to 8 bits per pass, three kernels per pass:
 //   hist     per-block digit counts                     -> counts[digit][block]
 //   rowscan  one workgroup per digit scans its row      -> exclusive prefix per (digit, block),
 //                                                          digit totals
 //   scatter  wave64 ballot match ranks every element among its equal-digit peers
-//            (8 ballots + mbcnt), adds the wave / block / global bases and writes it out
-// Grids are sized from the caller's capacity; workgroups past ceil(n / kTile) exit at once.
-// Byte / integer work, HBM-bound: per pass each element is read twice and written once.
+//            (ballots + mbcnt), the block's elements are re-ordered by digit in LDS, and each
+//            digit's run then leaves as ONE contiguous, lane-linear store (a 4-byte scatter
+//            straight to HBM defeats write combining: measured 64 us per 5 M-element pass
+//            against ~20 us staged).
+// Grids are sized from the caller's capacity; workgroups past ceil(n / tile) exit at once.
+// Block tile: 1024 elements for small inputs (enough workgroups to fill 256 CUs), 4096 for
+// large ones (longer per-digit runs).  Byte / integer work, HBM-bound: per pass each element is
+// read twice and written once.
 #include "mgs_common.h"
 
 namespace mgs {
@@ -16,18 +21,24 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kItems = 8;                       // per thread
-constexpr int kTile = kThreads * kItems;        // 2048 elements per workgroup
-constexpr int kWaveTile = 64 * kItems;          // 512 per wave
 constexpr int kRadix = 256;
+constexpr uint32_t kSmallLimit = 2u << 20;     // capacities up to 2 M use the small tile
 
-__device__ __forceinline__ unsigned digit_of(uint32_t key, int shift) {
-  return (key >> shift) & (kRadix - 1);
+template <int ITEMS>
+struct Cfg {
+  static constexpr int kTile = kThreads * ITEMS;
+  static constexpr int kWaveTile = 64 * ITEMS;
+};
+
+__device__ __forceinline__ unsigned digit_of(uint32_t key, int shift, uint32_t mask) {
+  return (key >> shift) & mask;
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(kThreads) void radix_hist_kernel(
-    const uint32_t* __restrict__ n_ptr, uint32_t capacity, int shift,
+    const uint32_t* __restrict__ n_ptr, uint32_t capacity, int shift, uint32_t mask,
     const uint32_t* __restrict__ keys, uint32_t* __restrict__ counts, uint32_t nblk_cap) {
+  constexpr int kTile = Cfg<ITEMS>::kTile;
   __shared__ uint32_t hist[kRadix];
   uint32_t n = min(*n_ptr, capacity);
   uint32_t nblk = (n + kTile - 1) / kTile;
@@ -37,9 +48,9 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(
   __syncthreads();
   uint32_t base = blk * kTile;
 #pragma unroll
-  for (int i = 0; i < kItems; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     uint32_t idx = base + i * kThreads + threadIdx.x;
-    if (idx < n) atomicAdd(&hist[digit_of(keys[idx], shift)], 1u);
+    if (idx < n) atomicAdd(&hist[digit_of(keys[idx], shift, mask)], 1u);
   }
   __syncthreads();
   counts[(size_t)threadIdx.x * nblk_cap + blk] = hist[threadIdx.x];
@@ -70,11 +81,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 }
 
 __global__ __launch_bounds__(kThreads) void radix_rowscan_kernel(
-    const uint32_t* __restrict__ n_ptr, uint32_t capacity, uint32_t* __restrict__ counts,
-    uint32_t* __restrict__ digit_totals, uint32_t nblk_cap) {
+    const uint32_t* __restrict__ n_ptr, uint32_t capacity, uint32_t tile,
+    uint32_t* __restrict__ counts, uint32_t* __restrict__ digit_totals, uint32_t nblk_cap) {
   __shared__ uint32_t wave_sums[kWaves];
   uint32_t n = min(*n_ptr, capacity);
-  uint32_t nblk = (n + kTile - 1) / kTile;
+  uint32_t nblk = (n + tile - 1) / tile;
   uint32_t* row = counts + (size_t)blockIdx.x * nblk_cap;
   uint32_t running = 0;
   for (uint32_t b0 = 0; b0 < nblk; b0 += kThreads) {
@@ -88,14 +99,19 @@ __global__ __launch_bounds__(kThreads) void radix_rowscan_kernel(
   if (threadIdx.x == 0) digit_totals[blockIdx.x] = running;
 }
 
+template <int ITEMS, int BITS>
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
-    const uint32_t* __restrict__ n_ptr, uint32_t capacity, int shift,
+    const uint32_t* __restrict__ n_ptr, uint32_t capacity, int shift, uint32_t mask,
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ digit_totals,
     uint32_t nblk_cap) {
-  __shared__ uint32_t wave_hist[kWaves][kRadix];   // per-wave digit counts -> bases
+  constexpr int kTile = Cfg<ITEMS>::kTile, kWaveTile = Cfg<ITEMS>::kWaveTile;
+  __shared__ uint32_t wave_hist[kWaves][kRadix];   // per-wave digit counts -> per-wave local bases
+  __shared__ uint32_t gdst[kRadix];                // global address of the digit's run minus its local start
   __shared__ uint32_t wave_sums[kWaves];
+  __shared__ uint32_t stage_k[kTile];
+  __shared__ uint32_t stage_v[kTile];
   uint32_t n = min(*n_ptr, capacity);
   uint32_t nblk = (n + kTile - 1) / kTile;
   uint32_t blk = blockIdx.x;
@@ -105,19 +121,24 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
   for (int w = 0; w < kWaves; ++w) wave_hist[w][threadIdx.x] = 0;
   __syncthreads();
 
-  // phase A: rank inside the wave's 512-element slice (rounds of 64 consecutive elements)
-  uint32_t key[kItems], val[kItems], rank[kItems];
+  // phase A: rank inside the wave's slice (rounds of 64 consecutive elements)
+  uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
   const uint32_t wbase = blk * kTile + wave * kWaveTile;
 #pragma unroll
-  for (int r = 0; r < kItems; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     uint32_t idx = wbase + r * 64 + lane;
     bool valid = idx < n;
     key[r] = valid ? keys_in[idx] : 0xffffffffu;
     val[r] = valid ? vals_in[idx] : 0u;
-    unsigned d = digit_of(key[r], shift);
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    uint32_t idx = wbase + r * 64 + lane;
+    bool valid = idx < n;
+    unsigned d = digit_of(key[r], shift, mask);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
@@ -131,58 +152,110 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
   }
   __syncthreads();
 
-  // phase B: thread t owns digit t: base = global digit offset + this block's prefix in the
-  // digit's row + counts of the earlier waves of this block
+  // phase B: thread t owns digit t
   {
-    uint32_t tot;
-    uint32_t digit_base = block_exclusive_scan(digit_totals[threadIdx.x], wave_sums, &tot);
-    uint32_t run = digit_base + counts[(size_t)threadIdx.x * nblk_cap + blk];
+    uint32_t c[kWaves], block_cnt = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) {
-      uint32_t c = wave_hist[w][threadIdx.x];
-      wave_hist[w][threadIdx.x] = run;
-      run += c;
+      c[w] = wave_hist[w][threadIdx.x];
+      block_cnt += c[w];
+    }
+    uint32_t tot;
+    uint32_t digit_base = block_exclusive_scan(digit_totals[threadIdx.x], wave_sums, &tot);
+    uint32_t local_start = block_exclusive_scan(block_cnt, wave_sums, &tot);
+    uint32_t run = local_start;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      wave_hist[w][threadIdx.x] = run;      // local position of this wave's first element of the digit
+      run += c[w];
+    }
+    gdst[threadIdx.x] = digit_base + counts[(size_t)threadIdx.x * nblk_cap + blk] - local_start;
+  }
+  __syncthreads();
+
+  // phase C: re-order by digit inside LDS
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    uint32_t idx = wbase + r * 64 + lane;
+    if (idx < n) {
+      uint32_t pos = wave_hist[wave][digit_of(key[r], shift, mask)] + rank[r];
+      stage_k[pos] = key[r];
+      stage_v[pos] = val[r];
     }
   }
   __syncthreads();
 
-  // phase C: scatter
+  // phase D: lane-linear stores; consecutive threads hit consecutive addresses inside a run
+  const uint32_t n_block = min((uint32_t)kTile, n - blk * kTile);
 #pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    uint32_t idx = wbase + r * 64 + lane;
-    if (idx < n) {
-      uint32_t dst = wave_hist[wave][digit_of(key[r], shift)] + rank[r];
-      keys_out[dst] = key[r];
-      vals_out[dst] = val[r];
+  for (int i = 0; i < ITEMS; ++i) {
+    uint32_t p = i * kThreads + threadIdx.x;
+    if (p < n_block) {
+      uint32_t k = stage_k[p];
+      uint32_t dst = gdst[digit_of(k, shift, mask)] + p;
+      keys_out[dst] = k;
+      vals_out[dst] = stage_v[p];
     }
   }
 }
 
+template <int ITEMS>
+void launch_pass(const uint32_t* n_dev, uint32_t capacity, int shift, int bits, uint32_t* keys_a,
+                 uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t* counts,
+                 uint32_t* totals, hipStream_t stream) {
+  constexpr int kTile = Cfg<ITEMS>::kTile;
+  uint32_t nblk_cap = div_up(capacity, kTile);
+  uint32_t mask = (1u << bits) - 1u;
+  hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nblk_cap), dim3(kThreads), 0, stream, n_dev,
+                     capacity, shift, mask, keys_a, counts, nblk_cap);
+  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kThreads), 0, stream, n_dev,
+                     capacity, (uint32_t)kTile, counts, totals, nblk_cap);
+#define MGS_SCATTER(B)                                                                          \
+  hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, B>), dim3(nblk_cap), dim3(kThreads), 0,      \
+                     stream, n_dev, capacity, shift, mask, keys_a, vals_a, keys_b, vals_b,      \
+                     counts, totals, nblk_cap)
+  switch (bits) {
+    case 1: MGS_SCATTER(1); break;
+    case 2: MGS_SCATTER(2); break;
+    case 3: MGS_SCATTER(3); break;
+    case 4: MGS_SCATTER(4); break;
+    case 5: MGS_SCATTER(5); break;
+    case 6: MGS_SCATTER(6); break;
+    case 7: MGS_SCATTER(7); break;
+    default: MGS_SCATTER(8); break;
+  }
+#undef MGS_SCATTER
+}
+
 }  // namespace
 
+// passes: key bits split as evenly as possible into digits of at most 8 bits
+int radix_sort_passes(int key_bits) { return (key_bits + 7) / 8; }
+
 size_t radix_sort_temp_bytes(uint32_t capacity) {
-  size_t nblk_cap = div_up(capacity ? capacity : 1u, kTile);
+  size_t nblk_cap = div_up(capacity ? capacity : 1u, Cfg<4>::kTile);   // the smaller tile bounds both
   return align_up((kRadix * nblk_cap + kRadix) * sizeof(uint32_t), 256);
 }
 
 // Result lands in (keys_b, vals_b) when the pass count ceil(key_bits/8) is odd, else in
-// (keys_a, vals_a); callers pick their buffers with radix_sort_passes().
+// (keys_a, vals_a).
 int radix_sort_pairs(const uint32_t* n_dev, uint32_t capacity, int key_bits, uint32_t* keys_a,
                      uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, void* temp,
                      hipStream_t stream) {
   if (capacity == 0) return MGS_OK;
-  uint32_t nblk_cap = div_up(capacity, kTile);
+  const bool small = capacity <= kSmallLimit;
+  uint32_t nblk_cap = div_up(capacity, small ? Cfg<4>::kTile : Cfg<16>::kTile);
   uint32_t* counts = static_cast<uint32_t*>(temp);
   uint32_t* totals = counts + (size_t)kRadix * nblk_cap;
-  int passes = (key_bits + 7) / 8;
+  const int passes = radix_sort_passes(key_bits);
+  int shift = 0;
   for (int p = 0; p < passes; ++p) {
-    int shift = 8 * p;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk_cap), dim3(kThreads), 0, stream, n_dev,
-                       capacity, shift, keys_a, counts, nblk_cap);
-    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kThreads), 0, stream, n_dev,
-                       capacity, counts, totals, nblk_cap);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk_cap), dim3(kThreads), 0, stream, n_dev,
-                       capacity, shift, keys_a, vals_a, keys_b, vals_b, counts, totals, nblk_cap);
+    int bits = (key_bits - shift + (passes - p) - 1) / (passes - p);   // even split, <= 8
+    if (small)
+      launch_pass<4>(n_dev, capacity, shift, bits, keys_a, vals_a, keys_b, vals_b, counts, totals, stream);
+    else
+      launch_pass<16>(n_dev, capacity, shift, bits, keys_a, vals_a, keys_b, vals_b, counts, totals, stream);
+    shift += bits;
     uint32_t* t;
     t = keys_a; keys_a = keys_b; keys_b = t;
     t = vals_a; vals_a = vals_b; vals_b = t;
