@@ -113,7 +113,8 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
     int n, const uint32_t* __restrict__ sorted_ids, const float* __restrict__ means2d,
     const int32_t* __restrict__ radii, float tile_size, int tile_w, int tile_h,
     const uint32_t* __restrict__ blockbase, uint32_t capacity,
-    uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out) {
+    uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out,
+    int4* __restrict__ pair_info) {
   __shared__ uint32_t prefix[kBlock + 1];
   __shared__ uint32_t gid[kBlock];
   __shared__ int rx0[kBlock], ry0[kBlock], rw[kBlock];
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
   rw[threadIdx.x] = max(rect.w, 1);
   __syncthreads();
   const uint32_t base = blockbase[blockIdx.x];
+  // slot of the pair (g, tile (tx,ty)) in emit order: slot_base + (ty - y0) * w + (tx - x0)
+  if (pair_info && r < n)
+    pair_info[g] = cnt ? make_int4((int)(base + off + incl - cnt), rect.x0, rect.y0, rect.w | (rect.h << 16))
+                       : make_int4(0, 0, 0, 0);
   for (uint32_t k = threadIdx.x; k < total; k += kBlock) {
     // largest j with prefix[j] <= k
     int lo = 0, hi = kBlock;   // invariant: prefix[lo] <= k < prefix[hi]
@@ -255,8 +260,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                                int cam_id, int n_cams, uint32_t isect_capacity,
                                int32_t* tiles_per_gauss, uint32_t* n_isect, uint32_t* tile_ids,
                                int32_t* flatten_ids, int64_t* isect_ids, int32_t* tile_offsets,
-                               uint32_t* status, void* workspace, size_t* workspace_bytes,
-                               mgs_stream_t stream) {
+                               int32_t* pair_info, uint32_t* status, void* workspace,
+                               size_t* workspace_bytes, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "isect_tiles: bad sizes");
   MGS_REQUIRE((long long)tile_w * tile_h < (1ll << 30), "isect_tiles: too many tiles");
   MGS_REQUIRE(workspace_bytes, "isect_tiles: workspace_bytes is null");
@@ -303,7 +308,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     uint32_t *a_t = user_t, *a_i = user_i, *b_t = u32(ws.tile_alt), *b_i = u32(ws.id_alt);
     if (passes & 1) { a_t = u32(ws.tile_alt); a_i = u32(ws.id_alt); b_t = user_t; b_i = user_i; }
     hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a), means2d,
-                       radii, (float)tile_size, tile_w, tile_h, u32(ws.blocksums), cap, a_t, a_i);
+                       radii, (float)tile_size, tile_w, tile_h, u32(ws.blocksums), cap, a_t, a_i,
+                       reinterpret_cast<int4*>(pair_info));
     rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
     if (rc) return rc;
   }

@@ -72,7 +72,11 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   return valid;
 }
 
-template <int CHT, bool ABSGRAD>
+// RECORDS == false: lane 63 adds the wave-reduced sums to the per-Gaussian outputs with float
+// atomics.  RECORDS == true: it stores them as one record at the pair's slot (pair_info) and
+// sets the slot's flag; reduce_records_kernel then sums each Gaussian's slots -- no atomics,
+// bit-reproducible.
+template <int CHT, bool ABSGRAD, bool RECORDS>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
@@ -82,7 +86,9 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
     const float* __restrict__ v_alphas, float* __restrict__ v_means2d,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
-    float* __restrict__ v_feats, float* __restrict__ v_opacities) {
+    float* __restrict__ v_feats, float* __restrict__ v_opacities,
+    const int4* __restrict__ pair_info, float* __restrict__ records,
+    uint8_t* __restrict__ flags) {
   __shared__ BwdEntry<CHT> queue[kQueue];
   const int tile = blockIdx.x;
   if (tile >= n_tiles) return;
@@ -149,7 +155,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
       BwdEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(xy.x, xy.y, ca, cb);
       e.geo1 = make_float4(cc, op, __uint_as_float(qmask), __int_as_float(idx));
-      e.gid = g;
+      if (RECORDS) {
+        const int4 info = pair_info[g];
+        e.gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
+      } else {
+        e.gid = g;
+      }
       float f[((CHT + 3) / 4) * 4];
 #pragma unroll
       for (int c = 0; c < ((CHT + 3) / 4) * 4; ++c)
@@ -199,23 +210,73 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
       float ax = 0.f, ay = 0.f;
       if (ABSGRAD) { ax = wave_reduce_to_lane63(gg.a_x); ay = wave_reduce_to_lane63(gg.a_y); }
       if (lane == 63) {
-        unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 0], rx);
-        unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 1], ry);
-        unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 0], ra);
-        unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 1], rb);
-        unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 2], rc);
-        unsafeAtomicAdd(&v_opacities[gid], ro);
+        if (RECORDS) {
+          const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
+          float* rec = records + (size_t)gid * rs;
+          rec[0] = rx; rec[1] = ry; rec[2] = ra; rec[3] = rb; rec[4] = rc; rec[5] = ro;
 #pragma unroll
-        for (int c = 0; c < CHT; ++c)
-          if (c < channels) unsafeAtomicAdd(&v_feats[(size_t)gid * channels + c], rf[c]);
-        if (ABSGRAD) {
-          unsafeAtomicAdd(&v_means2d_abs[2 * (size_t)gid + 0], ax);
-          unsafeAtomicAdd(&v_means2d_abs[2 * (size_t)gid + 1], ay);
+          for (int c = 0; c < CHT; ++c)
+            if (c < channels) rec[6 + c] = rf[c];
+          if (ABSGRAD) { rec[6 + channels] = ax; rec[7 + channels] = ay; }
+          flags[gid] = 1;
+        } else {
+          unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 0], rx);
+          unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 1], ry);
+          unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 0], ra);
+          unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 1], rb);
+          unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 2], rc);
+          unsafeAtomicAdd(&v_opacities[gid], ro);
+#pragma unroll
+          for (int c = 0; c < CHT; ++c)
+            if (c < channels) unsafeAtomicAdd(&v_feats[(size_t)gid * channels + c], rf[c]);
+          if (ABSGRAD) {
+            unsafeAtomicAdd(&v_means2d_abs[2 * (size_t)gid + 0], ax);
+            unsafeAtomicAdd(&v_means2d_abs[2 * (size_t)gid + 1], ay);
+          }
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// Sum the records of each Gaussian's slots (its tile rectangle, emit order) into the outputs.
+template <int CHT, bool ABSGRAD>
+__global__ __launch_bounds__(256) void reduce_records_kernel(
+    int n, const int4* __restrict__ pair_info, const float* __restrict__ records,
+    const uint8_t* __restrict__ flags, int channels, float* __restrict__ v_means2d,
+    float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
+    float* __restrict__ v_feats, float* __restrict__ v_opacities) {
+  int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= n) return;
+  const int4 info = pair_info[g];
+  const int cnt = (info.w & 0xffff) * ((unsigned)info.w >> 16);
+  const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
+  float acc[6], af[CHT], ab[2] = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < CHT; ++c) af[c] = 0.f;
+  for (int sl = 0; sl < cnt; ++sl) {
+    const size_t slot = (size_t)info.x + sl;
+    if (!flags[slot]) continue;
+    const float* rec = records + slot * rs;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] += rec[i];
+#pragma unroll
+    for (int c = 0; c < CHT; ++c)
+      if (c < channels) af[c] += rec[6 + c];
+    if (ABSGRAD) { ab[0] += rec[6 + channels]; ab[1] += rec[7 + channels]; }
+  }
+  reinterpret_cast<float2*>(v_means2d)[g] = make_float2(acc[0], acc[1]);
+  v_conics[3 * (size_t)g + 0] = acc[2];
+  v_conics[3 * (size_t)g + 1] = acc[3];
+  v_conics[3 * (size_t)g + 2] = acc[4];
+  v_opacities[g] = acc[5];
+#pragma unroll
+  for (int c = 0; c < CHT; ++c)
+    if (c < channels) v_feats[(size_t)g * channels + c] = af[c];
+  if (ABSGRAD) reinterpret_cast<float2*>(v_means2d_abs)[g] = make_float2(ab[0], ab[1]);
 }
 
 }  // namespace
@@ -242,10 +303,11 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
 #define MGS_RB_LAUNCH(C, A)                                                                    \
-  hipLaunchKernelGGL((raster_bwd_kernel<C, A>), dim3(n_tiles), dim3(64), 0, s, means2d, conics, \
-                     feats, opacities, background, channels, width, height, tile_w, n_tiles,   \
-                     tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas,          \
-                     v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities)
+  hipLaunchKernelGGL((raster_bwd_kernel<C, A, false>), dim3(n_tiles), dim3(64), 0, s, means2d,  \
+                     conics, feats, opacities, background, channels, width, height, tile_w,    \
+                     n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
+                     v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities,                 \
+                     (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr)
 #define MGS_RB(C) if (v_means2d_abs) MGS_RB_LAUNCH(C, true); else MGS_RB_LAUNCH(C, false)
   if (channels == 1) { MGS_RB(1); }
   else if (channels == 2) { MGS_RB(2); }
@@ -257,4 +319,64 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
 #undef MGS_RB
 #undef MGS_RB_LAUNCH
   return check_launch("rasterize_bwd");
+}
+
+extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* conics,
+                                     const float* feats, const float* opacities,
+                                     const float* background, int channels, int width,
+                                     int height, int tile_w, int tile_h,
+                                     const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                     const float* alphas, const int32_t* last_ids,
+                                     const float* v_render, const float* v_alphas,
+                                     const int32_t* pair_info, uint32_t isect_capacity,
+                                     float* v_means2d, float* v_means2d_abs, float* v_conics,
+                                     float* v_feats, float* v_opacities, void* workspace,
+                                     size_t* workspace_bytes, mgs_stream_t stream) {
+  MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "rasterize_bwd_det: bad sizes");
+  MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_bwd_det: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
+  MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
+              "rasterize_bwd_det: tile grid does not match the image at tile size 16");
+  MGS_REQUIRE(workspace_bytes, "rasterize_bwd_det: workspace_bytes is null");
+  const int rs = 6 + channels + (v_means2d_abs ? 2 : 0);
+  const size_t cap = isect_capacity ? isect_capacity : 1;
+  const size_t rec_bytes = align_up(cap * rs * sizeof(float), 256);
+  const size_t need = rec_bytes + align_up(cap, 256);
+  if (!workspace) {
+    *workspace_bytes = need;
+    return MGS_OK;
+  }
+  if (*workspace_bytes < need)
+    return set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "rasterize_bwd_det: workspace %zu < %zu bytes",
+                     *workspace_bytes, need);
+  MGS_REQUIRE(means2d && conics && feats && opacities && tile_offsets && flatten_ids && alphas &&
+                  last_ids && v_render && v_alphas && pair_info && v_means2d && v_conics &&
+                  v_feats && v_opacities, "rasterize_bwd_det: null pointer");
+  if (n == 0) return MGS_OK;
+  const int n_tiles = tile_w * tile_h;
+  hipStream_t s = (hipStream_t)stream;
+  float* records = static_cast<float*>(workspace);
+  uint8_t* flags = static_cast<uint8_t*>(workspace) + rec_bytes;
+  hipError_t e = hipMemsetAsync(flags, 0, cap, s);
+  if (e != hipSuccess) return set_error((int)e, "rasterize_bwd_det: memset: %s", hipGetErrorString(e));
+  const int4* info = reinterpret_cast<const int4*>(pair_info);
+#define MGS_RD_LAUNCH(C, A)                                                                     \
+  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true>), dim3(n_tiles), dim3(64), 0, s, means2d,   \
+                     conics, feats, opacities, background, channels, width, height, tile_w,    \
+                     n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
+                     (float*)nullptr, info, records, flags);                                   \
+  hipLaunchKernelGGL((reduce_records_kernel<C, A>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
+                     info, records, flags, channels, v_means2d, v_means2d_abs, v_conics,       \
+                     v_feats, v_opacities)
+#define MGS_RD(C) if (v_means2d_abs) { MGS_RD_LAUNCH(C, true); } else { MGS_RD_LAUNCH(C, false); }
+  if (channels == 1) { MGS_RD(1) }
+  else if (channels == 2) { MGS_RD(2) }
+  else if (channels == 3) { MGS_RD(3) }
+  else if (channels == 4) { MGS_RD(4) }
+  else if (channels <= 8) { MGS_RD(8) }
+  else if (channels <= 16) { MGS_RD(16) }
+  else { MGS_RD(32) }
+#undef MGS_RD
+#undef MGS_RD_LAUNCH
+  return check_launch("rasterize_bwd_det");
 }

@@ -76,7 +76,7 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
 class TileLists:
     """Depth-ordered per-tile lists of one camera (device resident, capacity sized)."""
     __slots__ = ("n_isect", "tile_ids", "flatten_ids", "tile_offsets", "tiles_per_gauss",
-                 "isect_ids", "status", "capacity")
+                 "isect_ids", "status", "capacity", "pair_info")
 
 
 _workspaces: dict = {}
@@ -95,7 +95,8 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 
 def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_id=0, n_cams=1,
-                    want_isect_ids=False, want_tiles_per_gauss=True) -> TileLists:
+                    want_isect_ids=False, want_tiles_per_gauss=True,
+                    want_pair_info=False) -> TileLists:
     n = means2d.shape[0]
     dev = means2d.device
     L = _lib.lib()
@@ -109,10 +110,12 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     out.tiles_per_gauss = (torch.empty(n, dtype=torch.int32, device=dev)
                            if want_tiles_per_gauss else None)
     out.isect_ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_isect_ids else None
+    out.pair_info = torch.empty(n, 4, dtype=torch.int32, device=dev) if want_pair_info else None
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means2d), ptr(radii), ptr(depths), TILE_SIZE, tile_w, tile_h, cam_id, n_cams,
             capacity, ptr(out.tiles_per_gauss), ptr(out.n_isect), ptr(out.tile_ids),
-            ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.status)]
+            ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.pair_info),
+            ptr(out.status)]
     check(L.mgs_isect_tiles(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_isect_tiles(size query)")
     ws = _workspace(nbytes.value, dev)
@@ -162,6 +165,34 @@ def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, heig
         height, tile_w, tile_h, ptr(tile_offsets), ptr(flatten_ids), ptr(alphas), ptr(last_ids),
         ptr(v_render), ptr(v_alphas), ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats),
         ptr(v_opac), stream_handle()), "mgs_rasterize_bwd")
+    return v_means2d, v_conics, v_feats, v_opac, v_abs
+
+
+def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
+                          tile_h, tl: "TileLists", alphas, last_ids, v_render, v_alphas,
+                          absgrad=False):
+    """Atomic-free, bit-reproducible raster backward (needs tl.pair_info from the binning).
+    Returns freshly written (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None)."""
+    n = means2d.shape[0]
+    ch = feats.shape[-1]
+    dev = means2d.device
+    v_means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    v_conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    v_feats = torch.empty(n, ch, dtype=torch.float32, device=dev)
+    v_opac = torch.empty(n, dtype=torch.float32, device=dev)
+    v_abs = torch.empty(n, 2, dtype=torch.float32, device=dev) if absgrad else None
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t(0)
+    args = [n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities), ptr(background), ch, width,
+            height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
+            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(tl.pair_info), tl.capacity,
+            ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
+    check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
+          "mgs_rasterize_bwd_det(size query)")
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+    nbytes = ctypes.c_size_t(ws.numel())
+    check(L.mgs_rasterize_bwd_det(*args, ptr(ws), ctypes.byref(nbytes), stream_handle()),
+          "mgs_rasterize_bwd_det")
     return v_means2d, v_conics, v_feats, v_opac, v_abs
 
 

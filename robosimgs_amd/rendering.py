@@ -48,7 +48,8 @@ class _RenderSH(torch.autograd.Function):
             if cap is None:
                 cap = max(1, ops._upper_bound_isects(radii, tile_w, tile_h))
             tl = ops.isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, cap, c, C,
-                                     want_isect_ids=False, want_tiles_per_gauss=True)
+                                     want_isect_ids=False, want_tiles_per_gauss=True,
+                                     want_pair_info=True)
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
@@ -82,9 +83,9 @@ class _RenderSH(torch.autograd.Function):
             radii, means2d, depths, conics, opac_aa, feats, tl = ctx.per_cam[c]
             opac = opac_aa if antialiased else opacities
             bg = backgrounds[c] if backgrounds is not None else None
-            v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_raw(
-                means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl.tile_offsets,
-                tl.flatten_ids, alphas[c], last_ids[c], v_render[c], v_alphas[c], absgrad)
+            v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_det_raw(
+                means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl, alphas[c],
+                last_ids[c], v_render[c], v_alphas[c], absgrad)
             if absgrad:
                 ctx.per_cam[c] = ctx.per_cam[c] + (v_abs,)
             check(L.mgs_project_color_bwd(

@@ -197,3 +197,39 @@ def test_multi_camera_gradients_accumulate():
     both, a, b = grads(slice(0, 2)), grads(slice(0, 1)), grads(slice(1, 2))
     for x, y, z in zip(both, a, b):
         torch.testing.assert_close(x, y + z, rtol=1e-3, atol=1e-4)
+
+
+def test_deterministic_backward_matches_atomic_and_is_bit_reproducible():
+    """mgs_rasterize_bwd_det (records + per-Gaussian reduce) vs mgs_rasterize_bwd (atomics):
+    same sums up to float re-association; two det runs are bit-identical."""
+    from robosimgs_amd import ops
+    g, cam = _scene(9000, 0.08, 0, 144, 96)
+    t = g.to_torch(DEV, 0)
+    vm, K = _t(cam.viewmat()), _t(cam.K)
+    radii, m2d, dep, con, _, feats = ops.project_color_fwd_raw(
+        t["means"], t["quats"], t["scales"], t["opacities"], 0, t["colors"], vm, K, 144, 96, 0.3,
+        0.01, 1e10, 0.0, False, True)
+    tw, th = 9, 6
+    tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 400_000, want_pair_info=True)
+    bg = torch.tensor([0.3, 0.1, 0.2, 0.0], device=DEV)
+    out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], bg, 144, 96, tw, th, tl.tile_offsets,
+                                tl.flatten_ids)
+    vr, va = torch.randn(96, 144, 4, device=DEV), torch.randn(96, 144, device=DEV)
+    a = ops.rasterize_bwd_raw(m2d, con, feats, t["opacities"], bg, 144, 96, tw, th, tl.tile_offsets,
+                              tl.flatten_ids, out[1], out[2], vr, va, absgrad=True)
+    d1 = ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], bg, 144, 96, tw, th, tl, out[1],
+                                   out[2], vr, va, absgrad=True)
+    d2 = ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], bg, 144, 96, tw, th, tl, out[1],
+                                   out[2], vr, va, absgrad=True)
+    for x, y, z in zip(a, d1, d2):
+        assert torch.equal(y, z)                                     # bit-reproducible
+        scale = float(x.abs().max()) + 1e-20
+        assert float((x - y).abs().max()) / scale < 1e-4
+    # the slot map is a bijection onto [0, n_isect)
+    info = tl.pair_info.cpu().numpy().astype(np.int64)
+    cnt = (info[:, 3] & 0xffff) * (info[:, 3] >> 16)
+    assert cnt.sum() == int(tl.n_isect.item())
+    vis = cnt > 0
+    order = np.argsort(info[vis, 0])
+    starts, sizes = info[vis, 0][order], cnt[vis][order]
+    assert starts[0] == 0 and np.all(starts[1:] == starts[:-1] + sizes[:-1])
