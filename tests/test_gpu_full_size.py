@@ -1,0 +1,114 @@
+"""BASELINE.json's full-size configurations on the GPU: direct comparison with the C++ port
+(oracle/gs_cpu.cpp; it finishes in seconds on the GPU box's host cores) and size-independent
+properties of the path: sorted / complete tile lists, linearity in the colour features,
+camera-order equivariance, alpha range."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from robosimgs_amd import camera_ring, synthetic_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def config2():
+    g = synthetic_scene(1_000_000, math.log(0.012), 3, 0)
+    cam = camera_ring(1, 1920, 1080, thetas=[0.3])[0]
+    return g, cam, g.to_torch(DEV, 3)
+
+
+def test_config2_matches_cpu_port_and_survey_counts(config2):
+    """configs[1]: 1 M Gaussians, SH 3, 1920x1080 forward."""
+    from robosimgs_amd import rasterization
+    g, cam, t = config2
+    c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                               _t(cam.viewmat())[None], _t(cam.K)[None], 1920, 1080, sh_degree=3)
+    n_isect = int(meta["n_isects"][0])
+    assert int((meta["radii"] > 0).sum()) == 764_945                 # SURVEY.md 8(d) calibration
+    assert abs(n_isect - 5_019_708) <= 100                           # fp32 vs fp64 knife edges
+    ref, ra, info = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                   cam.viewmat(), cam.K, 1920, 1080, 3)
+    assert abs(info["n_isect"] - n_isect) <= 100
+    d = np.abs(c[0].cpu().numpy() - ref).max(-1)
+    da = np.abs(a[0, ..., 0].cpu().numpy() - ra)
+    bad = (d > 1e-4) | (da > 1e-4)                                   # north-star tolerance
+    assert bad.mean() <= 5e-4, f"{bad.sum()} of {bad.size} pixels (max {d.max():.2e})"
+    al = a[0, ..., 0]
+    assert float(al.min()) >= 0.0 and float(al.max()) < 1.0
+
+
+def test_config2_tile_lists_sorted_and_complete(config2):
+    from robosimgs_amd import ops
+    g, cam, t = config2
+    radii, m2d, dep, con, _, feats = ops.project_color_fwd_raw(
+        t["means"], t["quats"], t["scales"], t["opacities"], 3, t["colors"], _t(cam.viewmat()),
+        _t(cam.K), 1920, 1080, 0.3, 0.01, 1e10, 0.0, False, False)
+    tl = ops.isect_tiles_raw(m2d, radii, dep, 120, 68, 6_500_000, want_isect_ids=True,
+                             want_pair_info=True)
+    n = int(tl.n_isect.item())
+    assert int(tl.status.item()) == 0 and n == int(tl.tiles_per_gauss.sum().item())
+    keys = tl.isect_ids[:n]
+    assert bool((keys[1:] >= keys[:-1]).all())                        # globally sorted by (tile, depth)
+    ids = tl.flatten_ids[:n].long()
+    tiles = (keys >> 32)
+    assert bool((tiles == tl.tile_ids[:n].long()).all())
+    assert bool(((keys & 0xffffffff) == dep[ids].view(torch.int32).long()).all())
+    # ties in (tile, depth) keep Gaussian-index order
+    same = keys[1:] == keys[:-1]
+    assert bool((ids[1:][same] > ids[:-1][same]).all())
+    # offsets are the first index of each tile, checksum of ids is order independent
+    offs = tl.tile_offsets.long()
+    assert int(offs[-1]) == n and bool((offs[1:] >= offs[:-1]).all())
+    counts = torch.bincount(tiles, minlength=120 * 68)
+    assert bool((counts == (offs[1:] - offs[:-1])).all())
+    per_gauss = torch.bincount(ids, minlength=len(g))
+    assert bool((per_gauss == tl.tiles_per_gauss.long()).all())
+
+
+def test_linearity_and_camera_equivariance():
+    """Blend is linear in the colour features; a camera batch equals the cameras one by one."""
+    from robosimgs_amd import rasterization
+    g = synthetic_scene(200_000, math.log(0.02), 0, 5)
+    cams = camera_ring(4, 640, 360)
+    t = g.to_torch(DEV, 0)
+    vm = _t(np.stack([c.viewmat() for c in cams]))
+    Ks = _t(np.stack([c.K for c in cams]))
+    fa, fb = torch.rand(len(g), 5, device=DEV), torch.rand(len(g), 5, device=DEV)
+    args = (t["means"], t["quats"], t["scales"], t["opacities"])
+    ra, al, _ = rasterization(*args, fa, vm, Ks, 640, 360)
+    rb, _, _ = rasterization(*args, fb, vm, Ks, 640, 360)
+    rab, _, _ = rasterization(*args, 2.0 * fa - 0.5 * fb, vm, Ks, 640, 360)
+    torch.testing.assert_close(rab, 2.0 * ra - 0.5 * rb, rtol=1e-4, atol=2e-5)
+    perm = [2, 0, 3, 1]
+    rp, ap, _ = rasterization(*args, fa, vm[perm], Ks[perm], 640, 360)
+    assert torch.equal(rp, ra[perm]) and torch.equal(ap, al[perm])
+
+
+@pytest.mark.timeout(600)
+def test_config5_stress_matches_cpu_port():
+    """configs[4]: 5 M Gaussians, SH 3, 3840x2160 (mean 1,105 Gaussians per tile)."""
+    from robosimgs_amd import rasterization, check_isect_status
+    g = synthetic_scene(5_000_000, math.log(0.008), 3, 0)
+    cam = camera_ring(1, 3840, 2160, thetas=[0.3])[0]
+    t = g.to_torch(DEV, 3)
+    c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                               _t(cam.viewmat())[None], _t(cam.K)[None], 3840, 2160, sh_degree=3,
+                               isect_capacity=40_000_000)
+    check_isect_status(meta)
+    assert int((meta["radii"] > 0).sum()) == 3_797_688
+    assert abs(int(meta["n_isects"][0]) - 35_799_376) <= 600
+    ref, ra, info = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                   cam.viewmat(), cam.K, 3840, 2160, 3)
+    d = np.abs(c[0].cpu().numpy() - ref).max(-1)
+    da = np.abs(a[0, ..., 0].cpu().numpy() - ra)
+    bad = (d > 1e-4) | (da > 1e-4)
+    assert bad.mean() <= 5e-4, f"{bad.sum()} of {bad.size} pixels"
