@@ -129,7 +129,8 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * never cleared, by the library).
  * pair_info[N,4] (nullable): per Gaussian {slot_base, x0, y0, w | h << 16} of its tile
  * rectangle; the pair (g, tile (tx,ty)) owns slot slot_base + (ty - y0) * w + (tx - x0) in
- * [0, n_isect).  Consumed by mgs_rasterize_bwd_det.
+ * [0, n_isect); slot bases ascend with the Gaussian index.  Consumed by
+ * mgs_rasterize_bwd_det.
  * ----------------------------------------------------------------------------------- */
 int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const float *depths,
                     int tile_size, int tile_w, int tile_h, int cam_id, int n_cams,

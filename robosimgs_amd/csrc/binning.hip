@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void rank_blocksum_kernel(
     uint32_t* __restrict__ blocksums) {
   __shared__ uint32_t ws[kBlock / 64];
   int r = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t c = r < n ? tcount[sorted_ids[r]] : 0u;
+  uint32_t c = r < n ? tcount[sorted_ids ? sorted_ids[r] : (uint32_t)r] : 0u;
   c = wave_sum(c);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -101,10 +101,47 @@ __global__ __launch_bounds__(kBlock) void scan_blocksums_kernel(
     if (b < nblk) blocksums[b] = running + off + incl - v;
     running += tot;
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && n_isect) {
     *n_isect = running;
     if (running > capacity) atomicOr(status, MGS_STATUS_ISECT_OVERFLOW);
   }
+}
+
+// Slots for the deterministic backward, Gaussian-index-major: Gaussian g owns the slots
+// [base, base + w*h) with base = exclusive scan of the tile counts in INDEX order, so that the
+// per-Gaussian reduction reads contiguous memory from consecutive lanes.
+__global__ __launch_bounds__(kBlock) void pair_info_kernel(
+    int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+    float tile_size, int tile_w, int tile_h, const uint32_t* __restrict__ blockbase,
+    int4* __restrict__ pair_info) {
+  __shared__ uint32_t ws[kBlock / 64];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int g = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t cnt = 0;
+  TileRect rect = {0, 0, 0, 0};
+  if (g < n) {
+    int radius = radii[g];
+    if (radius > 0) {
+      float2 m = reinterpret_cast<const float2*>(means2d)[g];
+      rect = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
+      cnt = (uint32_t)(rect.w * rect.h);
+    }
+  }
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(incl, d);
+    if (lane >= (unsigned)d) incl += t;
+  }
+  if (lane == 63) ws[wave] = incl;
+  __syncthreads();
+  uint32_t off = 0;
+  for (int w = 0; w < kBlock / 64; ++w)
+    if ((unsigned)w < wave) off += ws[w];
+  if (g < n)
+    pair_info[g] = cnt ? make_int4((int)(blockbase[blockIdx.x] + off + incl - cnt), rect.x0, rect.y0,
+                                   rect.w | (rect.h << 16))
+                       : make_int4(0, 0, 0, 0);
 }
 
 // Load-balanced emit: a workgroup owns 256 consecutive depth ranks; its output range is
@@ -113,8 +150,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
     int n, const uint32_t* __restrict__ sorted_ids, const float* __restrict__ means2d,
     const int32_t* __restrict__ radii, float tile_size, int tile_w, int tile_h,
     const uint32_t* __restrict__ blockbase, uint32_t capacity,
-    uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out,
-    int4* __restrict__ pair_info) {
+    uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out) {
   __shared__ uint32_t prefix[kBlock + 1];
   __shared__ uint32_t gid[kBlock];
   __shared__ int rx0[kBlock], ry0[kBlock], rw[kBlock];
@@ -153,10 +189,6 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
   rw[threadIdx.x] = max(rect.w, 1);
   __syncthreads();
   const uint32_t base = blockbase[blockIdx.x];
-  // slot of the pair (g, tile (tx,ty)) in emit order: slot_base + (ty - y0) * w + (tx - x0)
-  if (pair_info && r < n)
-    pair_info[g] = cnt ? make_int4((int)(base + off + incl - cnt), rect.x0, rect.y0, rect.w | (rect.h << 16))
-                       : make_int4(0, 0, 0, 0);
   for (uint32_t k = threadIdx.x; k < total; k += kBlock) {
     // largest j with prefix[j] <= k
     int lo = 0, hi = kBlock;   // invariant: prefix[lo] <= k < prefix[hi]
@@ -234,7 +266,7 @@ int bits_for(uint32_t count) {   // bits needed to hold values 0..count-1
 
 struct Workspace {
   size_t total;
-  size_t keys_a, vals_a, keys_b, vals_b, tcount, blocksums, n_gauss, tile_alt, id_alt, radix;
+  size_t keys_a, vals_a, keys_b, vals_b, tcount, blocksums, blocksums2, n_gauss, tile_alt, id_alt, radix;
   Workspace(int n, uint32_t cap) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
@@ -242,6 +274,7 @@ struct Workspace {
     keys_a = take(nn * 4); vals_a = take(nn * 4); keys_b = take(nn * 4); vals_b = take(nn * 4);
     tcount = take(nn * 4);
     blocksums = take((size_t)div_up((unsigned)nn, kBlock) * 4);
+    blocksums2 = take((size_t)div_up((unsigned)nn, kBlock) * 4);
     n_gauss = take(4);
     tile_alt = take(cc * 4); id_alt = take(cc * 4);
     size_t r1 = radix_sort_temp_bytes((uint32_t)nn), r2 = radix_sort_temp_bytes((uint32_t)cc);
@@ -308,8 +341,16 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     uint32_t *a_t = user_t, *a_i = user_i, *b_t = u32(ws.tile_alt), *b_i = u32(ws.id_alt);
     if (passes & 1) { a_t = u32(ws.tile_alt); a_i = u32(ws.id_alt); b_t = user_t; b_i = user_i; }
     hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a), means2d,
-                       radii, (float)tile_size, tile_w, tile_h, u32(ws.blocksums), cap, a_t, a_i,
-                       reinterpret_cast<int4*>(pair_info));
+                       radii, (float)tile_size, tile_w, tile_h, u32(ws.blocksums), cap, a_t, a_i);
+    if (pair_info) {   // training only: index-major slot bases (three small kernels)
+      hipLaunchKernelGGL(rank_blocksum_kernel, dim3(nblk), dim3(kBlock), 0, s, n,
+                         (const uint32_t*)nullptr, u32(ws.tcount), u32(ws.blocksums2));
+      hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kBlock), 0, s, nblk,
+                         u32(ws.blocksums2), cap, (uint32_t*)nullptr, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,
+                         (float)tile_size, tile_w, tile_h, u32(ws.blocksums2),
+                         reinterpret_cast<int4*>(pair_info));
+    }
     rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
     if (rc) return rc;
   }

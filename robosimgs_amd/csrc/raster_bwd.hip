@@ -200,26 +200,52 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
                                           g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, gi);
       }
       if (__ballot(any) == 0ull) continue;
-      // wave reduction, then one atomic per component from lane 63
-      float rx = wave_reduce_to_lane63(gg.v_x), ry = wave_reduce_to_lane63(gg.v_y);
-      float ra = wave_reduce_to_lane63(gg.v_ca), rb = wave_reduce_to_lane63(gg.v_cb);
-      float rc = wave_reduce_to_lane63(gg.v_cc), ro = wave_reduce_to_lane63(gg.v_op);
-      float rf[CHT];
+      if constexpr (RECORDS) {
+        // reduce-scatter butterfly: 8 values at a time, totals land in 8 lanes that store the
+        // record slice with one instruction
+        constexpr int NV = 6 + CHT + (ABSGRAD ? 2 : 0);
+        float vals[NV];
+        vals[0] = gg.v_x; vals[1] = gg.v_y; vals[2] = gg.v_ca; vals[3] = gg.v_cb;
+        vals[4] = gg.v_cc; vals[5] = gg.v_op;
 #pragma unroll
-      for (int c = 0; c < CHT; ++c) rf[c] = wave_reduce_to_lane63(gg.v_f[c]);
-      float ax = 0.f, ay = 0.f;
-      if (ABSGRAD) { ax = wave_reduce_to_lane63(gg.a_x); ay = wave_reduce_to_lane63(gg.a_y); }
-      if (lane == 63) {
-        if (RECORDS) {
-          const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
-          float* rec = records + (size_t)gid * rs;
-          rec[0] = rx; rec[1] = ry; rec[2] = ra; rec[3] = rb; rec[4] = rc; rec[5] = ro;
+        for (int c = 0; c < CHT; ++c) vals[6 + c] = gg.v_f[c];
+        if (ABSGRAD) { vals[6 + CHT] = gg.a_x; vals[7 + CHT] = gg.a_y; }
+        const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
+        float* rec = records + (size_t)gid * rs;
+        // record position of value j: channels above `channels` are padding and are dropped,
+        // the absgrad pair follows the real channels
+        auto rec_pos = [&](int j) {
+          if (j < 6 + CHT) return j < 6 + channels ? j : -1;
+          return j - CHT + channels;
+        };
+        int done = 0;
+#define MGS_RS_CHUNK(V)                                                        \
+        while (NV - done >= V) {                                               \
+          float t = wave_reduce_scatter<V>(vals + done, lane);                 \
+          int i = wave_reduce_scatter_index<V>(lane);                          \
+          if (i >= 0) {                                                        \
+            int pos = rec_pos(done + i);                                       \
+            if (pos >= 0) rec[pos] = t;                                        \
+          }                                                                    \
+          done += V;                                                           \
+        }
+        MGS_RS_CHUNK(8)
+        MGS_RS_CHUNK(4)
+        MGS_RS_CHUNK(2)
+        MGS_RS_CHUNK(1)
+#undef MGS_RS_CHUNK
+        if (lane == 0) flags[gid] = 1;
+      } else {
+        // plain wave reduction, then one atomic per component from lane 63
+        float rx = wave_reduce_to_lane63(gg.v_x), ry = wave_reduce_to_lane63(gg.v_y);
+        float ra = wave_reduce_to_lane63(gg.v_ca), rb = wave_reduce_to_lane63(gg.v_cb);
+        float rc = wave_reduce_to_lane63(gg.v_cc), ro = wave_reduce_to_lane63(gg.v_op);
+        float rf[CHT];
 #pragma unroll
-          for (int c = 0; c < CHT; ++c)
-            if (c < channels) rec[6 + c] = rf[c];
-          if (ABSGRAD) { rec[6 + channels] = ax; rec[7 + channels] = ay; }
-          flags[gid] = 1;
-        } else {
+        for (int c = 0; c < CHT; ++c) rf[c] = wave_reduce_to_lane63(gg.v_f[c]);
+        float ax = 0.f, ay = 0.f;
+        if (ABSGRAD) { ax = wave_reduce_to_lane63(gg.a_x); ay = wave_reduce_to_lane63(gg.a_y); }
+        if (lane == 63) {
           unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 0], rx);
           unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 1], ry);
           unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 0], ra);

@@ -90,5 +90,67 @@ __device__ __forceinline__ float wave_reduce_to_lane63(float v) {
   return v;
 }
 
+
+// ---- reduce-scatter butterfly over the wave ----------------------------------------------
+// Sums V values (V = 8, 4, 2 or 1) held by every lane over all 64 lanes in about 3V + 5
+// instructions instead of 6V.  Scatter steps halve the value count while pairing lanes over
+// lane bits 0, 1 and 3 (xor 1 / xor 2 via quad_perm, xor 8 via row_ror:8): a lane keeps the
+// half selected by its own bit and adds the partner's copy of that half.  The remaining lane
+// bits are then summed with plain shifted adds.  The total of value i ends in the lane of row 0
+// with (bit0, bit1, bit3) spelling i as  i = bit3 + 2*bit1 + 4*bit0  (V = 8),
+// i = bit1 + 2*bit0 (V = 4), i = bit0 (V = 2), lane 0 (V = 1), and lane bits 2, 4, 5 clear.
+__device__ __forceinline__ float dpp_f(float x, int ctrl) {   // ctrl must fold to a constant
+  switch (ctrl) {
+    case 0xB1: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
+    case 0x4E: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));
+    case 0x128: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0xf, false));
+  }
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor8 = 0x128, kDppShl4 = 0x104;
+
+template <int V>
+__device__ __forceinline__ float wave_reduce_scatter(const float* v, unsigned lane) {
+  static_assert(V == 8 || V == 4 || V == 2 || V == 1, "V must be 8, 4, 2 or 1");
+  const bool b0 = lane & 1u, b1 = lane & 2u, b3 = lane & 8u;
+  float t;
+  if constexpr (V == 8) {
+    float w[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (b0 ? v[i + 4] : v[i]) + dpp_f(b0 ? v[i] : v[i + 4], kDppXor1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (b1 ? w[i + 2] : w[i]) + dpp_f(b1 ? w[i] : w[i + 2], kDppXor2);
+    t = (b3 ? u[1] : u[0]) + dpp_f(b3 ? u[0] : u[1], kDppRor8);
+  } else if constexpr (V == 4) {
+    float u[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (b0 ? v[i + 2] : v[i]) + dpp_f(b0 ? v[i] : v[i + 2], kDppXor1);
+    t = (b1 ? u[1] : u[0]) + dpp_f(b1 ? u[0] : u[1], kDppXor2);
+    t += dpp_f(t, kDppRor8);
+  } else if constexpr (V == 2) {
+    t = (b0 ? v[1] : v[0]) + dpp_f(b0 ? v[0] : v[1], kDppXor1);
+    t += dpp_f(t, kDppXor2);
+    t += dpp_f(t, kDppRor8);
+  } else {
+    t = v[0] + dpp_f(v[0], kDppXor1);
+    t += dpp_f(t, kDppXor2);
+    t += dpp_f(t, kDppRor8);
+  }
+  t += dpp_f(t, kDppShl4);             // lane bit 2 (valid where bit 2 is clear)
+  t += __shfl_down(t, 16);             // rows 1,3 into rows 0,2
+  t += __shfl_down(t, 32);             // row 2 into row 0
+  return t;
+}
+// which value index a holder lane (row 0, bit 2 clear) carries; -1 for other lanes
+template <int V>
+__device__ __forceinline__ int wave_reduce_scatter_index(unsigned lane) {
+  if (lane & ~0xBu) return -1;         // only lanes 0,1,2,3,8,9,10,11 can hold a total
+  const int b0 = lane & 1, b1 = (lane >> 1) & 1, b3 = (lane >> 3) & 1;
+  if (V == 8) return b3 + 2 * b1 + 4 * b0;
+  if (V == 4) return b3 ? -1 : b1 + 2 * b0;
+  if (V == 2) return (b3 || b1) ? -1 : b0;
+  return lane == 0 ? 0 : -1;
+}
+
 }  // namespace mgs
 #endif
