@@ -75,13 +75,14 @@ __global__ __launch_bounds__(kBlock) void rank_blocksum_kernel(
 }
 
 // single workgroup: exclusive scan of the block sums in place; publishes n_isect / overflow
-__global__ __launch_bounds__(kBlock) void scan_blocksums_kernel(
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
     uint32_t nblk, uint32_t* __restrict__ blocksums, uint32_t capacity,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
-  __shared__ uint32_t ws[kBlock / 64];
+  __shared__ uint32_t ws[kScanThreads / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t running = 0;
-  for (uint32_t b0 = 0; b0 < nblk; b0 += kBlock) {
+  for (uint32_t b0 = 0; b0 < nblk; b0 += kScanThreads) {
     uint32_t b = b0 + threadIdx.x;
     uint32_t v = b < nblk ? blocksums[b] : 0u;
     uint32_t incl = v;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void scan_blocksums_kernel(
     if (lane == 63) ws[wave] = incl;
     __syncthreads();
     uint32_t off = 0, tot = 0;
-    for (int w = 0; w < kBlock / 64; ++w) {
+    for (int w = 0; w < kScanThreads / 64; ++w) {
       if ((unsigned)w < wave) off += ws[w];
       tot += ws[w];
     }
@@ -189,21 +190,33 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
   rw[threadIdx.x] = max(rect.w, 1);
   __syncthreads();
   const uint32_t base = blockbase[blockIdx.x];
-  for (uint32_t k = threadIdx.x; k < total; k += kBlock) {
-    // largest j with prefix[j] <= k
-    int lo = 0, hi = kBlock;   // invariant: prefix[lo] <= k < prefix[hi]
+  // each thread emits four consecutive slots: one binary search, then a linear walk
+  for (uint32_t k0 = threadIdx.x * 4u; k0 < total; k0 += kBlock * 4u) {
+    int lo = 0, hi = kBlock;   // invariant: prefix[lo] <= k0 < prefix[hi]
     while (hi - lo > 1) {
       int mid = (lo + hi) >> 1;
-      if (prefix[mid] <= k) lo = mid; else hi = mid;
+      if (prefix[mid] <= k0) lo = mid; else hi = mid;
     }
-    uint32_t local = k - prefix[lo];
-    int w = rw[lo];
-    int dy = (int)(local / (uint32_t)w);
-    int dx = (int)local - dy * w;
-    uint32_t out = base + k;
-    if (out < capacity) {
-      tile_out[out] = (uint32_t)((ry0[lo] + dy) * tile_w + rx0[lo] + dx);
-      id_out[out] = gid[lo];
+    uint32_t next = prefix[lo + 1];
+    uint32_t tiles4[4], ids4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t k = k0 + i;
+      while (k >= next && lo < kBlock - 1) next = prefix[++lo + 1];   // skips empty Gaussians
+      uint32_t local = k - prefix[lo];
+      int w = rw[lo];
+      int dy = (int)(local / (uint32_t)w);
+      int dx = (int)local - dy * w;
+      tiles4[i] = (uint32_t)((ry0[lo] + dy) * tile_w + rx0[lo] + dx);
+      ids4[i] = gid[lo];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t out = base + k0 + i;
+      if (k0 + i < total && out < capacity) {
+        tile_out[out] = tiles4[i];
+        id_out[out] = ids4[i];
+      }
     }
   }
 }
@@ -331,7 +344,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     if (rc) return rc;
     hipLaunchKernelGGL(rank_blocksum_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a),
                        u32(ws.tcount), u32(ws.blocksums));
-    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kBlock), 0, s, nblk,
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
                        u32(ws.blocksums), cap, n_isect, status);
     // tile sort: result must land in the caller's buffers
     const int tile_bits = bits_for((uint32_t)n_tiles);
@@ -345,7 +358,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     if (pair_info) {   // training only: index-major slot bases (three small kernels)
       hipLaunchKernelGGL(rank_blocksum_kernel, dim3(nblk), dim3(kBlock), 0, s, n,
                          (const uint32_t*)nullptr, u32(ws.tcount), u32(ws.blocksums2));
-      hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kBlock), 0, s, nblk,
+      hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
                          u32(ws.blocksums2), cap, (uint32_t*)nullptr, (uint32_t*)nullptr);
       hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,
                          (float)tile_size, tile_w, tile_h, u32(ws.blocksums2),
