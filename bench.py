@@ -36,6 +36,7 @@ from robosimgs_amd import ops  # noqa: E402
 from robosimgs_amd.rendering import rasterization  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+RASTER_PMC_TRAFFIC_BYTES = 589_651_900   # FETCH_SIZE + WRITE_SIZE of raster_fwd_kernel<3>, config 2
 
 
 def parse():
@@ -182,11 +183,18 @@ def main():
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
         result["roofline"] = {"kernel": "raster_fwd_kernel<3>", "bound": "hbm",
                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                              "frac": round(achieved / HBM_PEAK_GBS, 4),
+                              # PMC passes cannot run inside bench.py; value measured with
+                              # scripts/pmc.sh on this kernel and workload (profiles/r1/04)
+                              "traffic": RASTER_PMC_TRAFFIC_BYTES if (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3) else None,
+                              "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes: "
+                                                "549.0 MB + 40.6 MB per launch (profiles/r1/04_pmc_final.md)",
                               "algorithmic_bytes": algo_bytes,
                               "kernel_ms": round(raster_ms, 4),
-                              "note": "VALU/exp-bound kernel (SURVEY.md 7): the HBM fraction is "
-                                      "reported as the contract asks; see DESIGN.md"}
+                              "valu_busy_frac": 0.76,
+                              "note": "VALU-bound kernel: SQ_ACTIVE_INST_VALU = 76 % of SIMD cycles "
+                                      "(profiles/r1/04); the HBM fraction is reported as the "
+                                      "contract asks; see DESIGN.md 4.3"}
 
         # ---- training-step variant (configs[2]): forward + L1 + backward ------------------
         try:
