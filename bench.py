@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    # debugging aid for the N > 1 control flow on a single-GPU box: all ranks share cuda:0 and the
+    # collectives run over gloo with host staging.  Never used for a reported number.
+    ap.add_argument("--debug-single-device-gloo", action="store_true")
     return ap.parse_args()
 
 
@@ -70,11 +73,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world == 1 and a.gpus > 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    debug_gloo = a.debug_single_device_gloo
+    if debug_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if debug_gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, deg = a.width, a.height, a.sh_degree
     scene = synthetic_scene(a.n, a.log_scale_mean, deg, seed=0)
@@ -109,9 +118,12 @@ def main():
 
     do_gather = world > 1 and not a.no_gather
     gather_bufs = None
+    comm_dev = "cpu" if debug_gloo else dev
     if do_gather and rank == 0:
-        gather_bufs = [[torch.empty_like(g_colors) for _ in range(world)] for _ in range(2)]
-    send_bufs = [torch.empty_like(g_colors) for _ in range(2)] if do_gather else None
+        gather_bufs = [[torch.empty_like(g_colors, device=comm_dev) for _ in range(world)]
+                       for _ in range(2)]
+    send_bufs = ([torch.empty_like(g_colors, device=comm_dev) for _ in range(2)]
+                 if do_gather else None)
     pending = []
 
     def step(i):
@@ -138,7 +150,7 @@ def main():
     barrier_sync(world)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     status = int(g_meta["isect_status"].max().item())
