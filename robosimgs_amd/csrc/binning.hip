@@ -321,8 +321,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     return set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "isect_tiles: workspace %zu < %zu bytes",
                      *workspace_bytes, ws.total);
   MGS_REQUIRE(isect_capacity > 0, "isect_tiles: zero capacity");
-  MGS_REQUIRE(means2d && radii && depths && n_isect && tile_ids && flatten_ids && tile_offsets &&
-                  status, "isect_tiles: null pointer");
+  MGS_REQUIRE((n == 0 || (means2d && radii && depths)) && n_isect && tile_ids && flatten_ids &&
+                  tile_offsets && status, "isect_tiles: null pointer");
   hipStream_t s = (hipStream_t)stream;
   char* w = static_cast<char*>(workspace);
   auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(w + off); };

@@ -323,6 +323,7 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
   MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_bwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
               "rasterize_bwd: tile grid does not match the image at tile size 16");
+  if (n == 0) return MGS_OK;
   MGS_REQUIRE(means2d && conics && feats && opacities && tile_offsets && flatten_ids && alphas &&
                   last_ids && v_render && v_alphas && v_means2d && v_conics && v_feats &&
                   v_opacities, "rasterize_bwd: null pointer");
@@ -374,10 +375,10 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   if (*workspace_bytes < need)
     return set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "rasterize_bwd_det: workspace %zu < %zu bytes",
                      *workspace_bytes, need);
+  if (n == 0) return MGS_OK;
   MGS_REQUIRE(means2d && conics && feats && opacities && tile_offsets && flatten_ids && alphas &&
                   last_ids && v_render && v_alphas && pair_info && v_means2d && v_conics &&
                   v_feats && v_opacities, "rasterize_bwd_det: null pointer");
-  if (n == 0) return MGS_OK;
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
   float* records = static_cast<float*>(workspace);

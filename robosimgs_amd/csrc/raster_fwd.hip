@@ -207,8 +207,8 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_fwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
               "rasterize_fwd: tile grid %dx%d does not match %dx%d at tile size 16", tile_w, tile_h, width, height);
-  MGS_REQUIRE(means2d && conics && feats && opacities && tile_offsets && flatten_ids && render &&
-                  alphas && last_ids, "rasterize_fwd: null pointer");
+  MGS_REQUIRE((n == 0 || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
+                  render && alphas && last_ids, "rasterize_fwd: null pointer");
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
 #define MGS_RF_LAUNCH(C)                                                                       \

@@ -219,3 +219,40 @@ def test_cpu_tensors_are_rejected():
     with pytest.raises(_lib.MgsError):
         rasterization(z, torch.zeros(4, 4), z, torch.zeros(4), z, torch.eye(4)[None],
                       torch.eye(3)[None], 16, 16)
+
+
+def test_empty_and_fully_culled_scenes():
+    """Edge cases: no Gaussians at all, and Gaussians that are all behind the camera."""
+    from robosimgs_amd import rasterization
+    vm, K = torch.eye(4, device=DEV)[None], torch.tensor([[[50.0, 0, 20], [0, 50.0, 12], [0, 0, 1]]], device=DEV)
+    bg = torch.tensor([[0.25, 0.5, 0.75]], device=DEV)
+    z3, z4 = torch.zeros(0, 3, device=DEV), torch.zeros(0, 4, device=DEV)
+    c, a, meta = rasterization(z3, z4, z3, torch.zeros(0, device=DEV), torch.zeros(0, 1, 3, device=DEV),
+                               vm, K, 40, 24, sh_degree=0, backgrounds=bg)
+    assert c.shape == (1, 24, 40, 3) and float(a.abs().max()) == 0.0
+    assert torch.allclose(c[0], bg[0].expand(24, 40, 3))
+    n = 100
+    means = torch.randn(n, 3, device=DEV) - torch.tensor([0.0, 0.0, 10.0], device=DEV)   # z < 0: behind
+    quats = torch.randn(n, 4, device=DEV)
+    c, a, meta = rasterization(means, quats, torch.full((n, 3), 0.1, device=DEV), torch.full((n,), 0.5, device=DEV),
+                               torch.rand(n, 4, 3, device=DEV), vm, K, 40, 24, sh_degree=1, backgrounds=bg)
+    assert int(meta["radii"].sum()) == 0 and int(meta["n_isects"][0]) == 0
+    assert torch.allclose(c[0], bg[0].expand(24, 40, 3)) and float(a.abs().max()) == 0.0
+
+
+def test_single_huge_gaussian_covers_every_tile():
+    """A Gaussian whose rectangle is the whole tile grid (the per-Gaussian emit loop's extreme)."""
+    from robosimgs_amd import rasterization
+    vm = torch.eye(4, device=DEV)[None]
+    K = torch.tensor([[[100.0, 0, 128], [0, 100.0, 72], [0, 0, 1]]], device=DEV)
+    means = torch.tensor([[0.0, 0.0, 2.0], [0.3, 0.1, 1.5]], device=DEV)
+    quats = torch.tensor([[1.0, 0, 0, 0], [1.0, 0, 0, 0]], device=DEV)
+    scales = torch.tensor([[3.0, 3.0, 3.0], [0.05, 0.05, 0.05]], device=DEV)
+    opac = torch.tensor([0.6, 0.9], device=DEV)
+    cols = torch.tensor([[1.0, 0.5, 0.25], [0.0, 1.0, 0.0]], device=DEV)
+    c, a, meta = rasterization(means, quats, scales, opac, cols, vm, K, 256, 144)
+    assert int(meta["tiles_per_gauss"][0, 0]) == 16 * 9
+    ref, ra, _ = O.render(means.cpu().numpy(), quats.cpu().numpy(), scales.cpu().numpy(), opac.cpu().numpy(),
+                          cols.cpu().numpy(), np.eye(4), K[0].cpu().numpy(), 256, 144)
+    np.testing.assert_allclose(c[0].cpu().numpy(), ref, atol=1e-4)
+    np.testing.assert_allclose(a[0].cpu().numpy(), ra, atol=1e-4)
