@@ -62,3 +62,27 @@ with torch.cuda.stream(s):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
 print("graph replay: %.3f ms/frame  (%.1f frames/s)" % (dt * 1e3, 1 / dt))
+
+# two frames in flight: independent graphs (own buffers) replayed on two streams, so the
+# latency-bound binning kernels of one frame overlap the VALU-bound raster of the other
+for nstreams in (2, 3):
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    graphs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            for _ in range(2): frame(cap)
+            torch.cuda.synchronize()
+            gr2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr2, stream=st):
+                keep = frame(cap)
+            graphs.append((gr2, keep))
+    torch.cuda.synchronize()
+    iters = a.iters * 4
+    t0 = time.perf_counter()
+    for i in range(iters):
+        st = streams[i % nstreams]
+        with torch.cuda.stream(st):
+            graphs[i % nstreams][0].replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    print("%d frames in flight: %.3f ms/frame  (%.1f frames/s)" % (nstreams, dt * 1e3, 1 / dt))
