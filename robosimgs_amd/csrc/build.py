@@ -21,6 +21,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"] + os.environ.get("MGS_EXTRA_FLAGS", "").split()
 
 
+# per-source additions (A/B-measured, see profiles/r1/05); overridable for experiments
+PER_SOURCE_FLAGS = {
+    "raster_bwd.hip": os.environ.get("MGS_RASTER_BWD_FLAGS", "").split(),
+    "raster_fwd.hip": os.environ.get("MGS_RASTER_FWD_FLAGS", "").split(),
+}
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -29,7 +36,7 @@ def _hipcc() -> str:
 
 
 def _stamp() -> str:
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_SOURCE_FLAGS.items()))).encode())
     for f in SOURCES + HEADERS:
         p = os.path.join(HERE, f)
         if os.path.exists(p):
@@ -50,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *PER_SOURCE_FLAGS.get(src, []), "-c", os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

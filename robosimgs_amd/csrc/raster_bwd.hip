@@ -36,6 +36,10 @@ struct GaussGrad {
   float v_f[CHT];
 };
 
+// One Gaussian against the 64 pixels of one quadrant, backward.  Wave-uniform skip when no lane
+// contributes; inside, the per-lane condition is folded into two masked factors (alpha_eff and
+// the opacity*vis product) so that every update is an unconditional FMA into the accumulators --
+// the branchy form made the compiler zero-initialise and merge nine temporaries per quadrant.
 template <int CHT, bool ABSGRAD>
 __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, float pxf,
                                            float pyf, float mx, float my, float ca, float cb,
@@ -43,32 +47,33 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   float dx = mx - pxf, dy = my - pyf;
   float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
   float vis = __expf(-sigma);
-  float alpha = fminf(kAlphaMax, opac * vis);
+  float ov = opac * vis;
+  float alpha = fminf(kAlphaMax, ov);
   bool valid = idx <= px.last && sigma >= 0.f && alpha >= kAlphaMin;
-  if (valid) {
-    float ra = __builtin_amdgcn_rcpf(1.0f - alpha);   // v_rcp_f32 (1 ulp); an IEEE divide is 11 instructions
-    px.T *= ra;
-    float fac = alpha * px.T;
-    float v_alpha = 0.f;
+  if (__ballot(valid) == 0ull) return false;
+  float a_eff = valid ? alpha : 0.f;                       // 0 => T, buf and v_f stay untouched
+  bool grad_geo = valid && ov <= kAlphaMax;                // alpha not clamped: sigma/opacity get grads
+  float vis_eff = grad_geo ? vis : 0.f;
+  float ra = __builtin_amdgcn_rcpf(1.0f - a_eff);          // v_rcp_f32; an IEEE divide is 11 instructions
+  px.T *= ra;
+  float fac = a_eff * px.T;
+  float v_alpha = px.T_final * ra * px.v_alpha;
 #pragma unroll
-    for (int c = 0; c < CHT; ++c) {
-      gg.v_f[c] += fac * px.v_c[c];
-      v_alpha += (feat[c] * px.T - px.buf[c] * ra) * px.v_c[c];
-      px.buf[c] += feat[c] * fac;
-    }
-    v_alpha += px.T_final * ra * px.v_alpha;
-    if (opac * vis <= kAlphaMax) {
-      float v_sigma = -opac * vis * v_alpha;
-      gg.v_ca += 0.5f * v_sigma * dx * dx;
-      gg.v_cb += v_sigma * dx * dy;
-      gg.v_cc += 0.5f * v_sigma * dy * dy;
-      float gx = v_sigma * (ca * dx + cb * dy), gy = v_sigma * (cb * dx + cc * dy);
-      gg.v_x += gx;
-      gg.v_y += gy;
-      if (ABSGRAD) { gg.a_x += fabsf(gx); gg.a_y += fabsf(gy); }
-      gg.v_op += vis * v_alpha;
-    }
+  for (int c = 0; c < CHT; ++c) {
+    gg.v_f[c] = fmaf(fac, px.v_c[c], gg.v_f[c]);
+    v_alpha = fmaf(fmaf(feat[c], px.T, -px.buf[c] * ra), px.v_c[c], v_alpha);
+    px.buf[c] = fmaf(feat[c], fac, px.buf[c]);
   }
+  float v_sigma = -(opac * vis_eff) * v_alpha;
+  float hx = 0.5f * v_sigma * dx, hy = 0.5f * v_sigma * dy;
+  gg.v_ca = fmaf(hx, dx, gg.v_ca);
+  gg.v_cb = fmaf(v_sigma * dx, dy, gg.v_cb);
+  gg.v_cc = fmaf(hy, dy, gg.v_cc);
+  float gx = v_sigma * fmaf(cb, dy, ca * dx), gy = v_sigma * fmaf(cc, dy, cb * dx);
+  gg.v_x += gx;
+  gg.v_y += gy;
+  if (ABSGRAD) { gg.a_x += fabsf(gx); gg.a_y += fabsf(gy); }
+  gg.v_op = fmaf(vis_eff, v_alpha, gg.v_op);
   return valid;
 }
 
