@@ -8,14 +8,13 @@
 #include "mgs_common.h"
 #include "mgs_math.h"
 #include "raster_common.h"
+#include "sh_staging.h"
 
 namespace mgs {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kWave = 64;
-constexpr int kShRowF4 = 12;
-constexpr int kShPitchF4 = 13;
+constexpr int kWave = kShWave;
 
 __device__ __forceinline__ void load3(const float* p, float v[3]) {
   v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
@@ -76,45 +75,6 @@ __global__ __launch_bounds__(kBlock) void projection_bwd_kernel(
   if (v_viewmat) reduce_viewmat(r, active, v_viewmat);
 }
 
-// ---- SH row staging (mirror of projection.hip) -------------------------------------------
-// read: 64 rows of 48 floats, lane-linear from HBM, through LDS, into per-lane registers
-__device__ __forceinline__ void stage_rows_in(const float* __restrict__ coeffs, int g0, int n,
-                                              unsigned long long wave_mask, float4* lds) {
-  const unsigned lane = threadIdx.x & (kWave - 1);
-  const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)g0 * 48);
-  float4 piece[kShRowF4];
-#pragma unroll
-  for (int m = 0; m < kShRowF4; ++m) {
-    unsigned f = m * kWave + lane, owner = f / kShRowF4;
-    bool need = ((wave_mask >> owner) & 1ull) && (g0 + (int)owner < n);
-    piece[m] = need ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int m = 0; m < kShRowF4; ++m) {
-    unsigned f = m * kWave + lane, owner = f / kShRowF4;
-    lds[owner * kShPitchF4 + (f - owner * kShRowF4)] = piece[m];
-  }
-}
-// write: per-lane rows parked in LDS go out lane-linear; ACCUM adds to what is there
-template <bool ACCUM>
-__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst_base, int g0, int n,
-                                               const float4* lds) {
-  const unsigned lane = threadIdx.x & (kWave - 1);
-  float4* dst = reinterpret_cast<float4*>(dst_base + (size_t)g0 * 48);
-#pragma unroll
-  for (int m = 0; m < kShRowF4; ++m) {
-    unsigned f = m * kWave + lane, owner = f / kShRowF4;
-    if (g0 + (int)owner < n) {
-      float4 v = lds[owner * kShPitchF4 + (f - owner * kShRowF4)];
-      if (ACCUM) {
-        float4 o = dst[f];
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
-      dst[f] = v;
-    }
-  }
-}
-
 // Per-lane SH backward.  Coefficients come from `crow` (registers or global row pointer
 // semantics hidden by the caller); v_coeff rows go to `vrow` (LDS row or global row).
 template <int DEG, typename CoeffAt, typename StoreV>
@@ -158,7 +118,7 @@ __device__ __forceinline__ void sh_bwd_rows(int n, int stride_f, int g, bool act
     const unsigned lane = threadIdx.x & (kWave - 1);
     const int g0 = g - (int)lane;
     unsigned long long wave_mask = __ballot(active);
-    stage_rows_in(coeffs, g0, n, wave_mask, lds_wave);
+    sh_rows_to_lds(coeffs, g0, n, wave_mask, lds_wave);
     __syncthreads();
     float* row = reinterpret_cast<float*>(lds_wave + lane * kShPitchF4);
     if (active) {
@@ -171,7 +131,7 @@ __device__ __forceinline__ void sh_bwd_rows(int n, int stride_f, int g, bool act
       for (int i = 0; i < 48; ++i) row[i] = 0.f;
     }
     __syncthreads();
-    stage_rows_out<ACCUM>(v_coeffs, g0, n, lds_wave);
+    sh_rows_from_lds<ACCUM>(v_coeffs, g0, n, lds_wave);
   } else {
     if (g < n) {
       const float* crow = coeffs + (size_t)g * stride_f;

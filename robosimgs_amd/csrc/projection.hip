@@ -11,14 +11,13 @@
 // of a b128 service group land on 16 distinct 4-bank slots).
 #include "mgs_common.h"
 #include "mgs_math.h"
+#include "sh_staging.h"
 
 namespace mgs {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kShRowF4 = 12;      // 48 floats
-constexpr int kShPitchF4 = 13;    // 52 dwords
-constexpr int kWave = 64;
+constexpr int kWave = kShWave;
 
 __device__ __forceinline__ void load3(const float* p, float v[3]) {
   v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
@@ -80,21 +79,7 @@ __device__ __forceinline__ void fetch_sh_row(const float* __restrict__ coeffs, i
   constexpr int KC = (DEG + 1) * (DEG + 1);
   if constexpr (STAGED) {
     const unsigned lane = threadIdx.x & (kWave - 1);
-    const float4* src = reinterpret_cast<const float4*>(coeffs + (size_t)g0 * 48);
-    float4 piece[kShRowF4];
-#pragma unroll
-    for (int m = 0; m < kShRowF4; ++m) {
-      unsigned f = m * kWave + lane;           // float4 index inside the wave's 64 rows
-      unsigned owner = f / kShRowF4;
-      bool need = ((wave_mask >> owner) & 1ull) && (g0 + (int)owner < n);
-      piece[m] = need ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int m = 0; m < kShRowF4; ++m) {
-      unsigned f = m * kWave + lane;
-      unsigned owner = f / kShRowF4;
-      lds[owner * kShPitchF4 + (f - owner * kShRowF4)] = piece[m];
-    }
+    sh_rows_to_lds(coeffs, g0, n, wave_mask, lds);
     __syncthreads();
     constexpr int NF4 = (KC * 3 + 3) / 4;
 #pragma unroll

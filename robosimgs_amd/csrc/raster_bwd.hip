@@ -288,16 +288,33 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   for (int i = 0; i < 6; ++i) acc[i] = 0.f;
 #pragma unroll
   for (int c = 0; c < CHT; ++c) af[c] = 0.f;
-  for (int sl = 0; sl < cnt; ++sl) {
-    const size_t slot = (size_t)info.x + sl;
-    if (!flags[slot]) continue;
-    const float* rec = records + slot * rs;
+  // four slots per trip with predicated loads: the flag and record loads of a trip are all in
+  // flight together instead of one dependent round trip per slot (summation order is unchanged)
+  for (int sl = 0; sl < cnt; sl += 4) {
+    bool on[4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] += rec[i];
+    for (int i = 0; i < 4; ++i) on[i] = sl + i < cnt && flags[(size_t)info.x + sl + i] != 0;
+    float r[4][6], rf[4][CHT], ra[4][2];
 #pragma unroll
-    for (int c = 0; c < CHT; ++c)
-      if (c < channels) af[c] += rec[6 + c];
-    if (ABSGRAD) { ab[0] += rec[6 + channels]; ab[1] += rec[7 + channels]; }
+    for (int i = 0; i < 4; ++i) {
+      const float* rec = records + ((size_t)info.x + sl + i) * rs;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) r[i][k] = on[i] ? rec[k] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) rf[i][c] = (on[i] && c < channels) ? rec[6 + c] : 0.f;
+      if (ABSGRAD) {
+        ra[i][0] = on[i] ? rec[6 + channels] : 0.f;
+        ra[i][1] = on[i] ? rec[7 + channels] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += r[i][k];
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) af[c] += rf[i][c];
+      if (ABSGRAD) { ab[0] += ra[i][0]; ab[1] += ra[i][1]; }
+    }
   }
   reinterpret_cast<float2*>(v_means2d)[g] = make_float2(acc[0], acc[1]);
   v_conics[3 * (size_t)g + 0] = acc[2];

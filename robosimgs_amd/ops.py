@@ -13,7 +13,6 @@ are enqueued on torch's current stream.  Nothing here computes on the CPU.
 from __future__ import annotations
 
 import ctypes
-import math
 from typing import Optional, Tuple
 
 import torch

@@ -61,6 +61,7 @@ class _RenderSH(torch.autograd.Function):
         ctx.cfg = (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
                    absgrad)
         meta_out["per_cam"] = per_cam
+        ctx.meta_out = meta_out
         return render, alphas.unsqueeze(-1)
 
     @staticmethod
@@ -86,8 +87,11 @@ class _RenderSH(torch.autograd.Function):
             v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_det_raw(
                 means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl, alphas[c],
                 last_ids[c], v_render[c], v_alphas[c], absgrad)
+            # screen-space gradients for densification strategies (gsplat exposes them through
+            # means2d.grad / means2d.absgrad; here they are published in the meta dict)
+            ctx.meta_out.setdefault("means2d_grad", [None] * C)[c] = v_means2d
             if absgrad:
-                ctx.per_cam[c] = ctx.per_cam[c] + (v_abs,)
+                ctx.meta_out.setdefault("means2d_absgrad", [None] * C)[c] = v_abs
             check(L.mgs_project_color_bwd(
                 n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), sh_degree,
                 sh_coeffs.shape[1], ptr(sh_coeffs), ptr(viewmats[c]), ptr(Ks[c]), width, height,
@@ -151,12 +155,13 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             raise ValueError("sh_degree outside 0..3 or too few coefficients")
         if backgrounds is not None and backgrounds.shape != (C, 4 if want_depth else 3):
             raise ValueError("backgrounds must be [C, channels]")
-        store: Dict = {}
+        store = meta        # the autograd function publishes per-camera intermediates (and, after
+        #                     backward, "means2d_grad" / "means2d_absgrad" lists) into the meta dict
         render, alphas = _RenderSH.apply(
             means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height,
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store)
-        per_cam = store["per_cam"]
+        per_cam = store.pop("per_cam")
 
         def _stk(xs):                 # no copy for the common single-camera call
             return xs[0].unsqueeze(0) if len(xs) == 1 else torch.stack(xs)

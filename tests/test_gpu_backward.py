@@ -233,3 +233,19 @@ def test_deterministic_backward_matches_atomic_and_is_bit_reproducible():
     order = np.argsort(info[vis, 0])
     starts, sizes = info[vis, 0][order], cnt[vis][order]
     assert starts[0] == 0 and np.all(starts[1:] == starts[:-1] + sizes[:-1])
+
+
+def test_screen_space_gradients_are_published():
+    """meta["means2d_grad"] / ["means2d_absgrad"] after backward (densification inputs)."""
+    from robosimgs_amd import rasterization
+    g, cam = _scene(3000, 0.1, 1, 96, 64)
+    t = g.to_torch(DEV, 1)
+    t["means"].requires_grad_(True)
+    c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                               _t(cam.viewmat()[None]), _t(cam.K[None]), 96, 64, sh_degree=1, absgrad=True)
+    assert "means2d_grad" not in meta
+    c.sum().backward()
+    g2d, gabs = meta["means2d_grad"][0], meta["means2d_absgrad"][0]
+    assert g2d.shape == (3000, 2) and float(g2d.abs().sum()) > 0
+    assert bool((gabs + 1e-6 >= g2d.abs()).all())
+    assert bool((g2d[meta["radii"][0] == 0] == 0).all())
