@@ -107,55 +107,52 @@ def main():
     n_vis = int((meta["radii"] > 0).sum())
     cap = int(n_isect * 1.25) + 4096
 
-    # ---- forward frame as one HIP graph; `inflight` independent copies on their own streams ---
-    # Frames of a novel-view batch are independent, so consecutive steps may overlap: the
-    # latency-bound binning kernels of one frame run under the VALU-bound raster of another.
-    # Every step still executes the whole path and the timed region ends with a full sync.
+    # ---- forward frames through the library's FrameRenderer ---------------------------------
+    # One HIP graph per in-flight slot, camera in device buffers, `inflight` independent frames
+    # on their own streams: the latency-bound binning kernels of one frame run under the
+    # VALU-bound raster of another.  Every step submits one whole frame (projection + binning +
+    # raster) and the timed region ends with a full sync.
+    from robosimgs_amd import FrameRenderer
     n_fl = max(1, a.inflight)
-    streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
-    graphs, outs = [], []
-    for st in streams:
-        with torch.cuda.stream(st):
-            for _ in range(3):
-                forward(cap)
-            torch.cuda.synchronize()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=st):
-                out = forward(cap)
-        graphs.append(gr)
-        outs.append(out)
-    torch.cuda.synchronize()
-    g_colors, g_alphas, g_meta = outs[0]
+    fr = FrameRenderer(t, W, H, render_mode="RGB", frames_in_flight=n_fl, isect_capacity=cap)
+    vm_np, K_np = vm[0].cpu().numpy(), K[0].cpu().numpy()
+    vm_dev, K_dev = vm[0].contiguous(), K[0].contiguous()
 
     do_gather = world > 1 and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
+    frame_shape = (H, W, 3)
     gather_bufs = None
     if do_gather and rank == 0:
-        gather_bufs = [[torch.empty_like(g_colors, device=comm_dev) for _ in range(world)]
+        gather_bufs = [[torch.empty(frame_shape, device=comm_dev) for _ in range(world)]
                        for _ in range(n_fl)]
-    send_bufs = ([torch.empty_like(g_colors, device=comm_dev) for _ in range(n_fl)]
+    send_bufs = ([torch.empty(frame_shape, device=comm_dev) for _ in range(n_fl)]
                  if do_gather else None)
     pending = [None] * n_fl
+    tickets = []
+
+    def retire():
+        """Fetch the oldest frame; with N > 1 hand it to the (asynchronous) RCCL gather."""
+        tk = tickets.pop(0)
+        f = fr.fetch(tk, check=False)
+        if do_gather:
+            if pending[tk] is not None:            # this slot's previous collective has drained
+                pending[tk].wait()
+            send_bufs[tk].copy_(f["colors"], non_blocking=True)
+            pending[tk] = dist.gather(send_bufs[tk], gather_bufs[tk] if rank == 0 else None,
+                                      dst=0, async_op=True)
+        fr.release(tk)
 
     def step(i):
-        slot = i % n_fl
-        with torch.cuda.stream(streams[slot]):
-            if pending[slot] is not None:          # the slot's previous gather must have drained
-                pending[slot].wait()
-                pending[slot] = None
-            graphs[slot].replay()
-            if do_gather:
-                # the collective of this frame overlaps the renders on the other streams
-                send_bufs[slot].copy_(outs[slot][0], non_blocking=True)
-                pending[slot] = dist.gather(send_bufs[slot],
-                                            gather_bufs[slot] if rank == 0 else None, dst=0,
-                                            async_op=True)
+        if len(tickets) == n_fl:
+            retire()
+        tickets.append(fr.submit(vm_dev, K_dev))
 
     def drain():
+        while tickets:
+            retire()
         for k in range(n_fl):
             if pending[k] is not None:
-                with torch.cuda.stream(streams[k]):
-                    pending[k].wait()
+                pending[k].wait()
                 pending[k] = None
 
     for i in range(a.warmup):
@@ -172,14 +169,16 @@ def main():
         tt = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # single-frame latency (one stream, nothing else in flight), for reference
+    # single-frame latency (one slot, nothing else in flight), for reference
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    with torch.cuda.stream(streams[0]):
-        for _ in range(20):
-            graphs[0].replay()
-    torch.cuda.synchronize()
+    for _ in range(20):
+        tk = fr.submit(vm_dev, K_dev)
+        fr.fetch(tk, check=False)
+        fr.release(tk)
+        torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / 20 * 1e3
+    outs = [(None, None, s["meta"]) for s in fr._slots]
     status = max(int(o[2]["isect_status"].max().item()) for o in outs)
     assert status == 0, "tile-intersection capacity overflow inside the timed region"
     frames_per_s = world * a.steps / elapsed

@@ -26,6 +26,9 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
                 "isect_offset_encode", "rasterize_to_pixels"):
         from . import ops
         return getattr(ops, name)
+    if name == "FrameRenderer":
+        from . import pipeline
+        return pipeline.FrameRenderer
     if name in ("render_sharded", "gather_frames", "shard_cameras"):
         from . import distributed
         return getattr(distributed, name)
