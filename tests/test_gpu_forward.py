@@ -256,3 +256,35 @@ def test_single_huge_gaussian_covers_every_tile():
                           cols.cpu().numpy(), np.eye(4), K[0].cpu().numpy(), 256, 144)
     np.testing.assert_allclose(c[0].cpu().numpy(), ref, atol=1e-4)
     np.testing.assert_allclose(a[0].cpu().numpy(), ra, atol=1e-4)
+
+
+def test_degenerate_inputs_do_not_crash_or_leak():
+    """NaN / Inf / absurd parameters: such Gaussians are culled or inert, the rest of the frame is
+    identical to the frame without them, and nothing hangs or writes out of bounds."""
+    from robosimgs_amd import rasterization, check_isect_status
+    g, cam = _scene(4000, 0.1, 1, 128, 96)
+    t = g.to_torch(DEV, 1)
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    base, base_a, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                                    vm, K, 128, 96, sh_degree=1)
+    bad = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in t.items()}
+    n_bad = 6
+    pad = lambda x, rows: torch.cat([x, rows.to(x)], 0)
+    nan, inf = float("nan"), float("inf")
+    bad["means"] = pad(t["means"], torch.tensor([[nan, 0, 0], [0, 0, 0], [0, 0, 0], [inf, 0, 0], [0, 0, 0], [0, 0, 0]]))
+    bad["quats"] = pad(t["quats"], torch.tensor([[1.0, 0, 0, 0], [nan, 0, 0, 0], [0, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0]]))
+    bad["scales"] = pad(t["scales"], torch.tensor([[.1, .1, .1], [.1, .1, .1], [.1, .1, .1], [.1, .1, .1], [nan, .1, .1], [.1, .1, .1]]))
+    bad["opacities"] = pad(t["opacities"], torch.tensor([.5, .5, .5, .5, .5, nan]))
+    bad["colors"] = pad(t["colors"], torch.zeros(n_bad, 4, 3))
+    out, out_a, meta = rasterization(bad["means"], bad["quats"], bad["scales"], bad["opacities"], bad["colors"],
+                                     vm, K, 128, 96, sh_degree=1, isect_capacity=200_000)
+    check_isect_status(meta)
+    assert torch.isfinite(out).all() and torch.isfinite(out_a).all()
+    assert torch.equal(out, base) and torch.equal(out_a, base_a)
+    # an absurdly large Gaussian covers every tile; a tiny capacity is flagged, never overrun
+    huge = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in t.items()}
+    huge["scales"][:50] = 1e6
+    _, _, meta = rasterization(huge["means"], huge["quats"], huge["scales"], huge["opacities"], huge["colors"],
+                               vm, K, 128, 96, sh_degree=1, isect_capacity=5_000)
+    assert int(meta["isect_status"][0]) != 0
+    torch.cuda.synchronize()
