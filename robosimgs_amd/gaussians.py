@@ -87,15 +87,23 @@ class Gaussians:
     # -- world-frame alignment ---------------------------------------------------------
     def transformed(self, rotation: np.ndarray, translation: np.ndarray,
                     scale: float = 1.0) -> "Gaussians":
-        """Apply the similarity x -> scale * R x + t to means, orientations and extents.
-        SH coefficients of degree >= 1 are view-dependent in the *old* frame and are
-        left untouched (exact for degree 0)."""
+        """Apply the similarity x -> scale * R x + t to means, orientations and extents, and
+        rotate the view-dependent colour with it: the SH coefficients of every degree l are
+        multiplied by the (2l+1)x(2l+1) real-SH rotation matrix of R, so that the transformed
+        scene seen from a transformed camera renders the same image."""
         R = np.asarray(rotation, dtype=np.float64)
         means = scale * (self.means.astype(np.float64) @ R.T) + np.asarray(translation)
         qR = _rotmat_to_quat(R)
         quats = _quat_mul(qR[None], self.quats.astype(np.float64))
+        rest = self.sh_rest
+        if rest.shape[1]:
+            coeffs = self.sh_coeffs.astype(np.float64)
+            for l, M in enumerate(sh_rotation_matrices(R, self.sh_degree)):
+                lo, hi = l * l, (l + 1) * (l + 1)
+                coeffs[:, lo:hi, :] = np.einsum("kj,njc->nkc", M, coeffs[:, lo:hi, :])
+            rest = coeffs[:, 1:, :]
         return Gaussians(means, self.log_scales + np.float32(np.log(scale)), quats,
-                         self.opacity_logits, self.sh_dc, self.sh_rest)
+                         self.opacity_logits, self.sh_dc, rest)
 
     def undo_dataparser_transform(self, transform: np.ndarray, scale: float) -> "Gaussians":
         """nerfstudio-normalised space -> original world (nerf2physic_utils.py:68-74):
@@ -237,6 +245,49 @@ def synthetic_scene(n: int, log_scale_mean: float, sh_degree: int = 3, seed: int
 
 
 # --------------------------------------------------------------------------------------
+# rotating spherical harmonics (host side; used by the world-frame alignment)
+# --------------------------------------------------------------------------------------
+def _sh_basis_np(degree: int, dirs: np.ndarray) -> np.ndarray:
+    """Real SH basis in the renderer's ordering and sign convention,
+    float64, for unit `dirs` [M,3] -> [M,(degree+1)^2]."""
+    x, y, z = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    Y = [np.full_like(x, SH_C0)]
+    if degree >= 1:
+        c1 = 0.48860251190292
+        Y += [-c1 * y, c1 * z, -c1 * x]
+    if degree >= 2:
+        z2, fC1, fS1 = z * z, x * x - y * y, 2 * x * y
+        t = -1.092548430592079 * z
+        Y += [0.5462742152960395 * fS1, t * y, 0.9461746957575601 * z2 - 0.3153915652525201, t * x,
+              0.5462742152960395 * fC1]
+    if degree >= 3:
+        u = -2.285228997322329 * z2 + 0.4570457994644658
+        w = 1.445305721320277 * z
+        fC2, fS2 = x * fC1 - y * fS1, x * fS1 + y * fC1
+        Y += [-0.5900435899266435 * fS2, w * fS1, u * y, z * (1.865881662950577 * z2 - 1.119528997770346),
+              u * x, w * fC1, -0.5900435899266435 * fC2]
+    return np.stack(Y, axis=-1)
+
+
+def sh_rotation_matrices(R: np.ndarray, degree: int):
+    """Per-degree matrices M_l with  c'_l = M_l c_l  such that
+    sum_k Y_k(d) c'_k == sum_k Y_k(R^T d) c_k  for every direction d (the colour field rotated
+    by R).  Each degree-l band is invariant under rotation, so M_l is found exactly by a
+    least-squares fit on a fixed set of sample directions."""
+    rng = np.random.default_rng(12345)
+    d = rng.normal(size=(64, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    Y_new = _sh_basis_np(degree, d)               # basis at the new-frame directions
+    Y_old = _sh_basis_np(degree, d @ R)           # rows are (R^T d)^T
+    out = []
+    for l in range(degree + 1):
+        lo, hi = l * l, (l + 1) * (l + 1)
+        # Y_new[:, band] @ M = Y_old[:, band]  ->  c' = M c
+        M, *_ = np.linalg.lstsq(Y_new[:, lo:hi], Y_old[:, lo:hi], rcond=None)
+        out.append(M)
+    return out
+
+
 def _rotmat_to_quat(R: np.ndarray) -> np.ndarray:
     t = np.trace(R)
     if t > 0:

@@ -82,3 +82,39 @@ def test_activations_and_transform():
     from oracle import gs_oracle_np as O
     S0, S1 = O.covar_world(g.quats, g.scales), O.covar_world(h.quats, h.scales)
     np.testing.assert_allclose(S1, 4 * R @ S0 @ R.T, rtol=2e-5, atol=1e-9)
+
+
+def test_rotating_the_scene_rotates_the_sh_colour_field():
+    """Rigidly moving scene AND camera must not change the image: checks means / quats / extents
+    and the per-degree SH rotation together, through the oracle (CPU)."""
+    import math
+    from oracle import gs_oracle_np as O
+    from robosimgs_amd import Camera, camera_ring
+    from robosimgs_amd.gaussians import sh_rotation_matrices, _sh_basis_np
+    g = synthetic_scene(1500, math.log(0.12), 3, seed=4)
+    g.sh_rest[:] *= 6.0                                     # make view dependence large
+    cam = camera_ring(1, 96, 64, thetas=[0.8], radius=6.0)[0]
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    R = Q * np.sign(np.linalg.det(Q))                        # proper rotation
+    t, s = np.array([0.4, -1.0, 0.3]), 1.7
+    # M_l are orthogonal and reproduce the rotated basis
+    d = rng.normal(size=(10, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for l, M in enumerate(sh_rotation_matrices(R, 3)):
+        np.testing.assert_allclose(M @ M.T, np.eye(2 * l + 1), atol=1e-10)
+        np.testing.assert_allclose(_sh_basis_np(3, d)[:, l * l:(l + 1) ** 2] @ M,
+                                   _sh_basis_np(3, d @ R)[:, l * l:(l + 1) ** 2], atol=1e-10)
+    h = g.transformed(R, t, s)
+    S = np.eye(4)
+    S[:3, :3], S[:3, 3] = s * R, t
+    c2w = S @ cam.c2w
+    c2w[:3, :3] /= s                                         # camera keeps unit axes
+    cam2 = Camera(c2w, cam.fx, cam.fy, cam.cx, cam.cy, 96, 64)
+    a, aa, _ = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, cam.viewmat(), cam.K, 96, 64, sh_degree=3)
+    # the moved scene is s times larger and s times farther: same pixels
+    b, ba, _ = O.render(h.means, h.quats, h.scales, h.opacities, h.sh_coeffs, cam2.viewmat(), cam2.K, 96, 64,
+                        sh_degree=3, near_plane=0.01 * s)
+    assert np.abs(a).max() > 0.5
+    np.testing.assert_allclose(b, a, atol=5e-4)
+    np.testing.assert_allclose(ba, aa, atol=5e-4)
