@@ -207,6 +207,22 @@ int mgs_project_color_bwd(int n, const float *means, const float *quats, const f
                           float *v_scales, float *v_sh_coeffs, float *v_opacities,
                           int accumulate, mgs_stream_t stream);
 
+/* -------------------------------------------------------------------------------------
+ * Compositing (the step downstream of the render path): depth-tested
+ * alpha-over of the splat background (premultiplied bg_rgb[P,3], bg_alpha[P], z-depth
+ * bg_depth[P]) with an opaque foreground layer (fg_rgb[P,3], z-depth fg_depth[P], optional
+ * uint8 fg_mask[P]; without a mask a pixel has foreground iff 0 < fg_depth < inf) and an
+ * optional backdrop colour[3].  Rule per pixel:
+ *   foreground in front (no splats, or fg_depth <= bg_depth): out = fg,  depth = fg_depth
+ *   foreground behind the splats:        out = bg + (1 - alpha) fg,       depth = bg_depth
+ *   no foreground:                       out = bg + (1 - alpha) backdrop, depth = bg_depth | +inf
+ * The reference names this step (README.md:53-56) but has not released it.
+ * ----------------------------------------------------------------------------------- */
+int mgs_composite_over(int n_px, const float *bg_rgb, const float *bg_alpha,
+                       const float *bg_depth, const float *fg_rgb, const float *fg_depth,
+                       const uint8_t *fg_mask, const float *backdrop, float *out_rgb,
+                       float *out_depth, mgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

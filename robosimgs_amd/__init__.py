@@ -26,6 +26,9 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
                 "isect_offset_encode", "rasterize_to_pixels"):
         from . import ops
         return getattr(ops, name)
+    if name == "composite_over":
+        from . import compositing
+        return compositing.composite_over
     if name == "FrameRenderer":
         from . import pipeline
         return pipeline.FrameRenderer

@@ -43,6 +43,7 @@ def _load() -> ctypes.CDLL:
         "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
         "mgs_rasterize_fwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p], c_int),
         "mgs_rasterize_bwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
+        "mgs_composite_over": ([i, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, u32, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
     }
     for name, (argtypes, restype) in sig.items():
@@ -65,7 +66,7 @@ def lib() -> ctypes.CDLL:
 EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_projection_fwd", "mgs_projection_bwd",
            "mgs_sh_fwd", "mgs_sh_bwd", "mgs_project_color_fwd", "mgs_project_color_bwd",
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
-           "mgs_rasterize_bwd_det"]
+           "mgs_rasterize_bwd_det", "mgs_composite_over"]
 
 
 def check(rc: int, what: str) -> None:
