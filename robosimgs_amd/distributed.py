@@ -71,9 +71,12 @@ def all_reduce_gradients(params: Sequence[torch.Tensor], group=None, average: bo
 
 
 def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, width: int,
-                   height: int, dst: int = 0, group=None, gather: bool = True,
+                   height: int, dst: int = 0, group=None, gather: bool = True, renderer=None,
                    **kw) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], range]:
     """Render this rank's block of the C cameras and (optionally) gather all frames on `dst`.
+    `renderer`: a persistent `FrameRenderer` built for this scene / resolution / render mode;
+    when given (inference only), the rank's cameras go through it with several frames in flight
+    instead of one `rasterization` call per block.
 
     tensors: dict(means, quats, scales, opacities, colors, sh_degree) as from
     Gaussians.to_torch().  viewmats [C,4,4] / Ks [C,3,3] hold ALL cameras on every rank.
@@ -85,7 +88,19 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
     C = viewmats.shape[0]
     mine = shard_cameras(C, world, rank)
     sel = slice(mine.start, mine.stop)
-    if len(mine):
+    if len(mine) and renderer is not None:
+        cs, als = [None] * len(mine), [None] * len(mine)
+        tickets, nxt = [], 0
+        for i in range(len(mine)):
+            while nxt < len(mine) and len(tickets) < renderer.n_slots:
+                tickets.append(renderer.submit(viewmats[mine.start + nxt], Ks[mine.start + nxt]))
+                nxt += 1
+            tk = tickets.pop(0)
+            f = renderer.fetch(tk)
+            cs[i], als[i] = f["colors"].clone(), f["alphas"].clone()
+            renderer.release(tk)
+        colors, alphas = torch.stack(cs), torch.stack(als)
+    elif len(mine):
         colors, alphas, _ = rasterization(tensors["means"], tensors["quats"], tensors["scales"],
                                           tensors["opacities"], tensors["colors"], viewmats[sel],
                                           Ks[sel], width, height,

@@ -102,6 +102,15 @@ class _RenderSH(torch.autograd.Function):
                 "mgs_project_color_bwd")
             if not antialiased:
                 v_opacities = v_opac if v_opacities is None else v_opacities + v_opac
+        # gsplat users call meta["means2d"].retain_grad() and read .grad / .absgrad after backward
+        # (densification).  meta["means2d"] is handed out as a leaf that receives them here.
+        m2d = ctx.meta_out.get("means2d")
+        if m2d is not None and m2d.requires_grad:
+            gl = ctx.meta_out["means2d_grad"]
+            m2d.grad = gl[0].unsqueeze(0) if C == 1 else torch.stack(gl)
+            if absgrad:
+                al = ctx.meta_out["means2d_absgrad"]
+                m2d.absgrad = al[0].unsqueeze(0) if C == 1 else torch.stack(al)
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[7]:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
@@ -180,6 +189,8 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             isect_status=_cat([p[6].status for p in per_cam]),
             isect_offsets=_stk([p[6].tile_offsets[:-1].view(tile_h, tile_w) for p in per_cam]),
             tile_lists=[p[6] for p in per_cam])
+        if torch.is_grad_enabled() and render.requires_grad:
+            meta["means2d"] = meta["means2d"].detach().requires_grad_(True)   # see _RenderSH.backward
     else:
         # feature path: colours are given per Gaussian (or evaluated from SH for "D"/"ED")
         radii, means2d, depths, conics, comps = ops.fully_fused_projection(

@@ -244,8 +244,10 @@ def test_screen_space_gradients_are_published():
     c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
                                _t(cam.viewmat()[None]), _t(cam.K[None]), 96, 64, sh_degree=1, absgrad=True)
     assert "means2d_grad" not in meta
+    meta["means2d"].retain_grad()                      # what splatfacto does; must not raise
     c.sum().backward()
     g2d, gabs = meta["means2d_grad"][0], meta["means2d_absgrad"][0]
+    assert torch.equal(meta["means2d"].grad[0], g2d) and torch.equal(meta["means2d"].absgrad[0], gabs)
     assert g2d.shape == (3000, 2) and float(g2d.abs().sum()) > 0
     assert bool((gabs + 1e-6 >= g2d.abs()).all())
     assert bool((g2d[meta["radii"][0] == 0] == 0).all())

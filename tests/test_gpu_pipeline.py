@@ -45,3 +45,17 @@ def test_sequence_equals_direct_calls_and_overflow_is_reported():
     small = FrameRenderer(t, 320, 192, frames_in_flight=1, isect_capacity=1000)
     with pytest.raises(_lib.MgsError, match="capacity"):
         small.render(cams[0].viewmat(), cams[0].K)
+
+
+def test_render_sharded_single_rank_with_and_without_renderer():
+    from robosimgs_amd import FrameRenderer
+    from robosimgs_amd.distributed import render_sharded
+    g = synthetic_scene(20_000, math.log(0.06), 1, 3)
+    cams = camera_ring(5, 192, 128)
+    t = g.to_torch(DEV, 1)
+    vm, Ks = _t(np.stack([c.viewmat() for c in cams])), _t(np.stack([c.K for c in cams]))
+    a, aa, mine = render_sharded(t, vm, Ks, 192, 128)
+    assert list(mine) == [0, 1, 2, 3, 4] and a.shape == (5, 128, 192, 3)
+    r = FrameRenderer(t, 192, 128, frames_in_flight=2, sizing_camera=(cams[0].viewmat(), cams[0].K))
+    b, ba, _ = render_sharded(t, vm, Ks, 192, 128, renderer=r)
+    assert torch.equal(a, b) and torch.equal(aa, ba)
