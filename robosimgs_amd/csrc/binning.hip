@@ -36,22 +36,23 @@ __device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, fl
 __global__ __launch_bounds__(kBlock) void depth_key_kernel(
     int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float* __restrict__ depths, float tile_size, int tile_w, int tile_h,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ tcount,
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ ginfo,
     int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ n_gauss_dev) {
   int g = blockIdx.x * kBlock + threadIdx.x;
   if (g == 0) *n_gauss_dev = (uint32_t)n;
   if (g >= n) return;
   int radius = radii[g];
-  uint32_t key = 0xffffffffu, cnt = 0;
+  uint32_t key = 0xffffffffu, cnt = 0, pack = 1u << 20;
   if (radius > 0) {
     float2 m = reinterpret_cast<const float2*>(means2d)[g];
     TileRect r = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
     cnt = (uint32_t)(r.w * r.h);
+    pack = (uint32_t)r.x0 | ((uint32_t)r.y0 << 10) | ((uint32_t)max(r.w, 1) << 20);
     key = __float_as_uint(depths[g]);
   }
   keys[g] = key;
   vals[g] = (uint32_t)g;
-  tcount[g] = cnt;
+  ginfo[g] = make_uint2(pack, cnt);       // tile rectangle (x0 | y0 << 10 | w << 20) and tile count
   if (tiles_per_gauss) tiles_per_gauss[g] = (int32_t)cnt;
 }
 
@@ -61,13 +62,20 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
-// sum of tile counts of the 256 depth-ranks owned by each workgroup
+// sum of tile counts of the 256 depth-ranks owned by each workgroup.  With sorted_ids the
+// per-Gaussian (rectangle, count) record is gathered ONCE here and re-written in rank order, so
+// the emit pass reads it lane-linear instead of chasing ids again.
 __global__ __launch_bounds__(kBlock) void rank_blocksum_kernel(
-    int n, const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ tcount,
-    uint32_t* __restrict__ blocksums) {
+    int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ ginfo,
+    uint2* __restrict__ rank_info, uint32_t* __restrict__ blocksums) {
   __shared__ uint32_t ws[kBlock / 64];
   int r = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t c = r < n ? tcount[sorted_ids ? sorted_ids[r] : (uint32_t)r] : 0u;
+  uint32_t c = 0;
+  if (r < n) {
+    uint2 info = ginfo[sorted_ids ? sorted_ids[r] : (uint32_t)r];
+    if (rank_info) rank_info[r] = info;
+    c = info.y;
+  }
   c = wave_sum(c);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -112,22 +120,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
 // [base, base + w*h) with base = exclusive scan of the tile counts in INDEX order, so that the
 // per-Gaussian reduction reads contiguous memory from consecutive lanes.
 __global__ __launch_bounds__(kBlock) void pair_info_kernel(
-    int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-    float tile_size, int tile_w, int tile_h, const uint32_t* __restrict__ blockbase,
+    int n, const uint2* __restrict__ ginfo, int tile_h, const uint32_t* __restrict__ blockbase,
     int4* __restrict__ pair_info) {
   __shared__ uint32_t ws[kBlock / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int g = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t cnt = 0;
-  TileRect rect = {0, 0, 0, 0};
-  if (g < n) {
-    int radius = radii[g];
-    if (radius > 0) {
-      float2 m = reinterpret_cast<const float2*>(means2d)[g];
-      rect = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
-      cnt = (uint32_t)(rect.w * rect.h);
-    }
-  }
+  uint2 info = g < n ? ginfo[g] : make_uint2(1u << 20, 0u);
+  uint32_t cnt = info.y;
   uint32_t incl = cnt;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -139,35 +138,32 @@ __global__ __launch_bounds__(kBlock) void pair_info_kernel(
   uint32_t off = 0;
   for (int w = 0; w < kBlock / 64; ++w)
     if ((unsigned)w < wave) off += ws[w];
-  if (g < n)
-    pair_info[g] = cnt ? make_int4((int)(blockbase[blockIdx.x] + off + incl - cnt), rect.x0, rect.y0,
-                                   rect.w | (rect.h << 16))
+  if (g < n) {
+    const uint32_t w = info.x >> 20;
+    pair_info[g] = cnt ? make_int4((int)(blockbase[blockIdx.x] + off + incl - cnt), (int)(info.x & 1023u),
+                                   (int)((info.x >> 10) & 1023u), (int)(w | ((cnt / w) << 16)))
                        : make_int4(0, 0, 0, 0);
+  }
 }
 
 // Load-balanced emit: a workgroup owns 256 consecutive depth ranks; its output range is
 // walked lane-linearly and each slot finds its Gaussian by binary search in LDS.
 __global__ __launch_bounds__(kBlock) void emit_kernel(
-    int n, const uint32_t* __restrict__ sorted_ids, const float* __restrict__ means2d,
-    const int32_t* __restrict__ radii, float tile_size, int tile_w, int tile_h,
-    const uint32_t* __restrict__ blockbase, uint32_t capacity,
+    int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ rank_info,
+    int tile_w, const uint32_t* __restrict__ blockbase, uint32_t capacity,
     uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out) {
   __shared__ uint32_t prefix[kBlock + 1];
   __shared__ uint32_t gid[kBlock];
-  __shared__ int rx0[kBlock], ry0[kBlock], rw[kBlock];
+  __shared__ uint32_t rpack[kBlock];
   __shared__ uint32_t ws[kBlock / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int r = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t cnt = 0, g = 0;
-  TileRect rect = {0, 0, 1, 0};
+  uint32_t cnt = 0, g = 0, pack = 1u << 20;
   if (r < n) {
     g = sorted_ids[r];
-    int radius = radii[g];
-    if (radius > 0) {
-      float2 m = reinterpret_cast<const float2*>(means2d)[g];
-      rect = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
-      cnt = (uint32_t)(rect.w * rect.h);
-    }
+    uint2 info = rank_info[r];
+    pack = info.x;
+    cnt = info.y;
   }
   uint32_t incl = cnt;
 #pragma unroll
@@ -185,9 +181,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
   prefix[threadIdx.x] = off + incl - cnt;
   if (threadIdx.x == 0) prefix[kBlock] = total;
   gid[threadIdx.x] = g;
-  rx0[threadIdx.x] = rect.x0;
-  ry0[threadIdx.x] = rect.y0;
-  rw[threadIdx.x] = max(rect.w, 1);
+  rpack[threadIdx.x] = pack;
   __syncthreads();
   const uint32_t base = blockbase[blockIdx.x];
   // each thread emits four consecutive slots: one binary search, then a linear walk
@@ -204,10 +198,11 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
       uint32_t k = k0 + i;
       while (k >= next && lo < kBlock - 1) next = prefix[++lo + 1];   // skips empty Gaussians
       uint32_t local = k - prefix[lo];
-      int w = rw[lo];
-      int dy = (int)(local / (uint32_t)w);
-      int dx = (int)local - dy * w;
-      tiles4[i] = (uint32_t)((ry0[lo] + dy) * tile_w + rx0[lo] + dx);
+      uint32_t p = rpack[lo];
+      uint32_t w = p >> 20;
+      uint32_t dy = local / w;
+      uint32_t dx = local - dy * w;
+      tiles4[i] = (((p >> 10) & 1023u) + dy) * (uint32_t)tile_w + (p & 1023u) + dx;
       ids4[i] = gid[lo];
     }
 #pragma unroll
@@ -279,13 +274,14 @@ int bits_for(uint32_t count) {   // bits needed to hold values 0..count-1
 
 struct Workspace {
   size_t total;
-  size_t keys_a, vals_a, keys_b, vals_b, tcount, blocksums, blocksums2, n_gauss, tile_alt, id_alt, radix;
+  size_t keys_a, vals_a, keys_b, vals_b, ginfo, rank_info, blocksums, blocksums2, n_gauss, tile_alt, id_alt, radix;
   Workspace(int n, uint32_t cap) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     size_t nn = (size_t)(n > 0 ? n : 1), cc = cap ? cap : 1;
     keys_a = take(nn * 4); vals_a = take(nn * 4); keys_b = take(nn * 4); vals_b = take(nn * 4);
-    tcount = take(nn * 4);
+    ginfo = take(nn * 8);
+    rank_info = take(nn * 8);
     blocksums = take((size_t)div_up((unsigned)nn, kBlock) * 4);
     blocksums2 = take((size_t)div_up((unsigned)nn, kBlock) * 4);
     n_gauss = take(4);
@@ -309,7 +305,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                                int32_t* pair_info, uint32_t* status, void* workspace,
                                size_t* workspace_bytes, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "isect_tiles: bad sizes");
-  MGS_REQUIRE((long long)tile_w * tile_h < (1ll << 30), "isect_tiles: too many tiles");
+  MGS_REQUIRE(tile_w <= 1023 && tile_h <= 1023, "isect_tiles: tile grid %dx%d exceeds 1023x1023", tile_w, tile_h);
   MGS_REQUIRE(workspace_bytes, "isect_tiles: workspace_bytes is null");
   MGS_REQUIRE(cam_id >= 0 && n_cams > cam_id, "isect_tiles: cam_id %d outside 0..%d", cam_id, n_cams);
   Workspace ws(n, isect_capacity);
@@ -337,13 +333,14 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     const unsigned nblk = div_up(n, kBlock);
     hipLaunchKernelGGL(depth_key_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,
                        depths, (float)tile_size, tile_w, tile_h, u32(ws.keys_a), u32(ws.vals_a),
-                       u32(ws.tcount), tiles_per_gauss, n_gauss_dev);
+                       reinterpret_cast<uint2*>(w + ws.ginfo), tiles_per_gauss, n_gauss_dev);
     // 4 passes (even): the depth order ends in (keys_a, vals_a)
     rc = radix_sort_pairs(n_gauss_dev, (uint32_t)n, 32, u32(ws.keys_a), u32(ws.vals_a),
                           u32(ws.keys_b), u32(ws.vals_b), w + ws.radix, s);
     if (rc) return rc;
     hipLaunchKernelGGL(rank_blocksum_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a),
-                       u32(ws.tcount), u32(ws.blocksums));
+                       reinterpret_cast<const uint2*>(w + ws.ginfo),
+                       reinterpret_cast<uint2*>(w + ws.rank_info), u32(ws.blocksums));
     hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
                        u32(ws.blocksums), cap, n_isect, status);
     // tile sort: result must land in the caller's buffers
@@ -353,15 +350,17 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     uint32_t* user_i = reinterpret_cast<uint32_t*>(flatten_ids);
     uint32_t *a_t = user_t, *a_i = user_i, *b_t = u32(ws.tile_alt), *b_i = u32(ws.id_alt);
     if (passes & 1) { a_t = u32(ws.tile_alt); a_i = u32(ws.id_alt); b_t = user_t; b_i = user_i; }
-    hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a), means2d,
-                       radii, (float)tile_size, tile_w, tile_h, u32(ws.blocksums), cap, a_t, a_i);
+    hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a),
+                       reinterpret_cast<const uint2*>(w + ws.rank_info), tile_w, u32(ws.blocksums), cap,
+                       a_t, a_i);
     if (pair_info) {   // training only: index-major slot bases (three small kernels)
       hipLaunchKernelGGL(rank_blocksum_kernel, dim3(nblk), dim3(kBlock), 0, s, n,
-                         (const uint32_t*)nullptr, u32(ws.tcount), u32(ws.blocksums2));
+                         (const uint32_t*)nullptr, reinterpret_cast<const uint2*>(w + ws.ginfo),
+                         (uint2*)nullptr, u32(ws.blocksums2));
       hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
                          u32(ws.blocksums2), cap, (uint32_t*)nullptr, (uint32_t*)nullptr);
-      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,
-                         (float)tile_size, tile_w, tile_h, u32(ws.blocksums2),
+      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n,
+                         reinterpret_cast<const uint2*>(w + ws.ginfo), tile_h, u32(ws.blocksums2),
                          reinterpret_cast<int4*>(pair_info));
     }
     rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
