@@ -53,6 +53,9 @@ typedef void *mgs_stream_t; /* hipStream_t */
 int mgs_version(void);
 /* Thread-local, human-readable description of the last non-zero return value. */
 const char *mgs_last_error_string(void);
+/* Test hook (process-global, not for production): 0 disables the raster forward's exact
+ * per-quadrant cull so that tests can prove the cull never changes a pixel. */
+void mgs_debug_set_raster_cull(int enabled);
 
 /* -------------------------------------------------------------------------------------
  * Projection  (gsplat `fully_fused_projection` forward, packed=False, one camera)

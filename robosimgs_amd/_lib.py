@@ -33,6 +33,7 @@ def _load() -> ctypes.CDLL:
     sig = {
         "mgs_version": ([], c_int),
         "mgs_last_error_string": ([], c_char_p),
+        "mgs_debug_set_raster_cull": ([i], None),
         "mgs_projection_fwd": ([i, p, p, p, p, p, i, i, f, f, f, f, p, p, p, p, p, p], c_int),
         "mgs_projection_bwd": ([i, p, p, p, p, p, i, i, f, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_sh_fwd": ([i, i, i, p, p, p, p, p], c_int),
@@ -63,7 +64,7 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
-EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_projection_fwd", "mgs_projection_bwd",
+EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_debug_set_raster_cull", "mgs_projection_fwd", "mgs_projection_bwd",
            "mgs_sh_fwd", "mgs_sh_bwd", "mgs_project_color_fwd", "mgs_project_color_bwd",
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
            "mgs_rasterize_bwd_det", "mgs_composite_over"]

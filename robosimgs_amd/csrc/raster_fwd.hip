@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
     const float* __restrict__ background, int channels, int width, int height, int tile_w,
     int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
-    float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull) {
   __shared__ QueueEntry<CHT> queue[kQueue + 1];
   const int tile = blockIdx.x;
   if (tile >= n_tiles) return;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
     fetch(r_idx, r_ok);
 
     unsigned qmask = 0;
-    if (c_ok) qmask = quadrant_mask(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, c_op, tile_x, tile_y) & live;
+    if (c_ok) qmask = (cull ? quadrant_mask(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, c_op, tile_x, tile_y) : 0xfu) & live;
     const unsigned long long keep = __ballot(qmask != 0u);
     const int count = __popcll(keep);
     if (qmask != 0u) {
@@ -197,6 +197,11 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
 
 using namespace mgs;
 
+// Test hook: 0 disables the exact quadrant cull (every listed Gaussian is evaluated against every
+// live quadrant).  The image must not change; tests/test_gpu_forward.py checks that bit for bit.
+static int g_raster_cull = 1;
+extern "C" void mgs_debug_set_raster_cull(int enabled) { g_raster_cull = enabled; }
+
 extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conics,
                                  const float* feats, const float* opacities,
                                  const float* background, int channels, int width, int height,
@@ -214,7 +219,7 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
 #define MGS_RF_LAUNCH(C)                                                                       \
   hipLaunchKernelGGL((raster_fwd_kernel<C>), dim3(n_tiles), dim3(64), 0, s, means2d, conics,   \
                      feats, opacities, background, channels, width, height, tile_w, n_tiles,   \
-                     tile_offsets, flatten_ids, render, alphas, last_ids)
+                     tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull)
   if (channels == 1) MGS_RF_LAUNCH(1);
   else if (channels == 2) MGS_RF_LAUNCH(2);
   else if (channels == 3) MGS_RF_LAUNCH(3);

@@ -13,7 +13,7 @@ HEADER = os.path.join(ROOT, "include", "mgs.h")
 def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    decls = re.findall(r"\b(?:int|const char \*)\s*\*?\s*(mgs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    decls = re.findall(r"\b(?:int|void|const char \*)\s*\*?\s*(mgs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
     return {name: 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
             for name, args in decls}
 
@@ -21,7 +21,7 @@ def _declared():
 def test_header_symbols_are_exported_and_bound():
     from robosimgs_amd import _lib
     decl = _declared()
-    assert len(decl) == 14, sorted(decl)
+    assert len(decl) == 15, sorted(decl)
     assert sorted(decl) == sorted(_lib.EXPORTS)
     L = _lib.lib()
     for name, nargs in decl.items():

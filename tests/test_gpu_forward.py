@@ -288,3 +288,29 @@ def test_degenerate_inputs_do_not_crash_or_leak():
                                vm, K, 128, 96, sh_degree=1, isect_capacity=5_000)
     assert int(meta["isect_status"][0]) != 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("aniso", [1.0, 30.0, 300.0])
+def test_quadrant_cull_never_changes_a_pixel(ops, aniso):
+    """The raster forward drops (Gaussian, quadrant) pairs that cannot reach alpha >= 1/255.  With
+    the cull disabled every pair is evaluated; render, alpha and last_ids must be bit-identical --
+    also for needle-like Gaussians (axis ratio up to 300) and sub-threshold opacities, where the
+    quadratic form's rounding is worst."""
+    from robosimgs_amd import _lib
+    g, cam = _scene(20_000, 0.06, 1, 208, 144, seed=13)
+    rng = np.random.default_rng(1)
+    g.log_scales[:, 0] += math.log(aniso)                       # stretch one axis
+    g.opacity_logits[::7] = rng.uniform(-6.5, -5.0, size=len(g.opacity_logits[::7]))   # around 1/255
+    t, radii, means2d, depths, conics, feats, tl, tw, th = _raster_inputs(ops, g, cam, 208, 144, 1)
+    try:
+        _lib.lib().mgs_debug_set_raster_cull(1)
+        a = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
+                                  tl.tile_offsets, tl.flatten_ids)
+        _lib.lib().mgs_debug_set_raster_cull(0)
+        b = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
+                                  tl.tile_offsets, tl.flatten_ids)
+    finally:
+        _lib.lib().mgs_debug_set_raster_cull(1)
+    assert float(a[1].max()) > 0.5
+    for x, y, name in zip(a, b, ("render", "alphas", "last_ids")):
+        assert torch.equal(x, y), f"{name}: cull changed {int((x != y).sum())} values"
