@@ -205,11 +205,12 @@ def main():
             t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W,
             H, 0.3, 0.01, 1e10, 0.0, False, False)
         tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False)
+        # the inference variant (no last_ids), i.e. the kernel the timed frames above run
         out = None
         reps = 50
         for _ in range(5):
             out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
-                                        tl.tile_offsets, tl.flatten_ids, out=out)
+                                        tl.tile_offsets, tl.flatten_ids, out=out, track_last=False)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -219,9 +220,10 @@ def main():
         torch.cuda.synchronize()
         raster_ms = e0.elapsed_time(e1) / reps
         n_px = W * H
-        algo_bytes = n_isect * 44 + n_px * 24 + tile_w * tile_h * 8
+        algo_bytes = n_isect * 44 + n_px * 24 + tile_w * tile_h * 8     # SURVEY.md 8(d) (kept as is: the
+        # inference variant skips the 4 B/px last_ids store the formula includes)
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
-        result["roofline"] = {"kernel": "raster_fwd_kernel<3>", "bound": "hbm",
+        result["roofline"] = {"kernel": "raster_fwd_kernel<3, false>", "bound": "hbm",
                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4),
                               # PMC passes cannot run inside bench.py; value measured with

@@ -153,7 +153,8 @@ int mgs_isect_offset_encode(uint32_t n_isect, const int64_t *isect_ids, int n_ca
  *   means2d[N,2] conics[N,3] feats[N,channels] opacities[N]; background[channels]
  *   nullable; tile_offsets[tile_h*tile_w + 1]; flatten_ids[n_isect].
  *   out: render[H,W,channels], alphas[H,W], last_ids[H,W] i32 (sorted-list index of the
- *   last Gaussian blended into the pixel; needed by the backward).
+ *   last Gaussian blended into the pixel; needed by the backward; pass NULL for an
+ *   inference render, which saves one select per pixel-Gaussian pair).
  *   channels in 1..MGS_MAX_CHANNELS.
  * ----------------------------------------------------------------------------------- */
 int mgs_rasterize_fwd(int n, const float *means2d, const float *conics, const float *feats,

@@ -33,7 +33,9 @@ constexpr float kLog2e = 1.4426950408889634f;
 // One Gaussian against the 64 pixels of one quadrant (one pixel per lane).
 //   power = -sigma * log2(e) = A dx^2 + C dy^2 + B dx dy  with  A = -0.5 log2e a, B = -log2e b,
 //   C = -0.5 log2e c, so exp(-sigma) is a single v_exp_f32 and "sigma >= 0" is "power <= 0".
-template <int CHT>
+// TRACK_LAST: record the list index of the last blended Gaussian (the backward starts there);
+// an inference render drops that select (compares / selects issue at half the FMA rate on gfx950).
+template <int CHT, bool TRACK_LAST>
 __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, float pyf, float mx,
                                             float my, float A, float B, float C, float opac,
                                             const float* feat, int idx) {
@@ -48,10 +50,10 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
   for (int c = 0; c < CHT; ++c) px.C[c] = fmaf(w, feat[c], px.C[c]);
   float closed = valid ? -fabsf(px.T) : px.T;     // valid but not accumulated: the pixel finishes
   px.T = acc ? next_T : closed;
-  px.last = acc ? idx : px.last;
+  if (TRACK_LAST) px.last = acc ? idx : px.last;
 }
 
-template <int CHT>
+template <int CHT, bool TRACK_LAST>
 __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_fwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (m & (1u << k))
-          blend_pixel<CHT>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y, g0.z, g0.w,
+          blend_pixel<CHT, TRACK_LAST>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y, g0.z, g0.w,
                            g1.x, g1.y, feat, idx);
       }
     };
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
         if (c < channels)
           render[p * channels + c] = st[k].C[c] + (background ? fabsf(st[k].T) * background[c] : 0.f);
       alphas[p] = 1.0f - fabsf(st[k].T);
-      last_ids[p] = st[k].last;
+      if (TRACK_LAST) last_ids[p] = st[k].last;
     }
   }
 }
@@ -213,13 +215,14 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
               "rasterize_fwd: tile grid %dx%d does not match %dx%d at tile size 16", tile_w, tile_h, width, height);
   MGS_REQUIRE((n == 0 || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
-                  render && alphas && last_ids, "rasterize_fwd: null pointer");
+                  render && alphas, "rasterize_fwd: null pointer");
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
-#define MGS_RF_LAUNCH(C)                                                                       \
-  hipLaunchKernelGGL((raster_fwd_kernel<C>), dim3(n_tiles), dim3(64), 0, s, means2d, conics,   \
+#define MGS_RF_LAUNCH_T(C, T)                                                                  \
+  hipLaunchKernelGGL((raster_fwd_kernel<C, T>), dim3(n_tiles), dim3(64), 0, s, means2d, conics, \
                      feats, opacities, background, channels, width, height, tile_w, n_tiles,   \
                      tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull)
+#define MGS_RF_LAUNCH(C) do { if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)
   if (channels == 1) MGS_RF_LAUNCH(1);
   else if (channels == 2) MGS_RF_LAUNCH(2);
   else if (channels == 3) MGS_RF_LAUNCH(3);
@@ -228,5 +231,6 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   else if (channels <= 16) MGS_RF_LAUNCH(16);
   else MGS_RF_LAUNCH(32);
 #undef MGS_RF_LAUNCH
+#undef MGS_RF_LAUNCH_T
   return check_launch("rasterize_fwd");
 }

@@ -125,14 +125,17 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
-                      tile_h, tile_offsets, flatten_ids, out=None):
+                      tile_h, tile_offsets, flatten_ids, out=None, track_last=True):
+    """out = (render, alphas, last_ids|None) to write into existing buffers.  track_last=False (or
+    last_ids None) is the inference variant: no last_ids, one select less per pair."""
     n = means2d.shape[0]
     ch = feats.shape[-1]
     dev = means2d.device
     if out is None:
         render = torch.empty(height, width, ch, dtype=torch.float32, device=dev)
         alphas = torch.empty(height, width, dtype=torch.float32, device=dev)
-        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        last_ids = (torch.empty(height, width, dtype=torch.int32, device=dev) if track_last
+                    else None)
     else:
         render, alphas, last_ids = out
     check(_lib.lib().mgs_rasterize_fwd(n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities),

@@ -37,7 +37,10 @@ class _RenderSH(torch.autograd.Function):
         ch = 4 if with_depth else 3
         render = torch.empty(C, height, width, ch, dtype=torch.float32, device=dev)
         alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
-        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        # last_ids (and the backward's slot map) only when some input wants a gradient
+        training = any(ctx.needs_input_grad[:5]) or ctx.needs_input_grad[7]
+        last_ids = (torch.empty(C, height, width, dtype=torch.int32, device=dev) if training
+                    else None)
         per_cam = []
         for c in range(C):
             radii, means2d, depths, conics, opac_aa, feats = ops.project_color_fwd_raw(
@@ -49,11 +52,11 @@ class _RenderSH(torch.autograd.Function):
                 cap = max(1, ops._upper_bound_isects(radii, tile_w, tile_h))
             tl = ops.isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, cap, c, C,
                                      want_isect_ids=False, want_tiles_per_gauss=True,
-                                     want_pair_info=True)
+                                     want_pair_info=training)
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
-                                  out=(render[c], alphas[c], last_ids[c]))
+                                  out=(render[c], alphas[c], last_ids[c] if training else None))
             per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl))
         ctx.per_cam = per_cam
         ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks,
