@@ -4,10 +4,12 @@
 // per (Gaussian, tile) pair and radix-sorts all n_isect pairs on ~45 bits: six 8-bit passes
 // over 12-byte elements.  The same ordering is produced here with ~4.5x less sort traffic:
 //   1. radix-sort the N Gaussians by their 32 depth bits (culled ones keyed 0xffffffff);
-//   2. exclusive-scan the tile counts in that order (total = n_isect, kept on the device);
+//   2. gather each Gaussian's (tile rectangle, count) into depth order and exclusive-scan the
+//      counts (total = n_isect, kept on the device);
 //   3. emit (tile, gaussian) pairs in depth order with a load-balanced search so that stores
 //      are lane-linear;
-//   4. stable radix sort on the tile bits only (13 bits at 1080p: two passes, 8-byte pairs).
+//   4. stable radix sort on the tile bits only (13 bits at 1080p: a 7-bit and a 6-bit pass over
+//      8-byte pairs).
 // Stable sort on tile of a depth-ordered stream == stable sort on (tile, depth); ties in
 // depth keep Gaussian-index order in both formulations.
 #include "mgs_common.h"

@@ -1,11 +1,13 @@
 // raster_fwd.hip -- per-tile depth-ordered alpha compositing, forward (A.2 step 9), gfx950.
-// Geometry, queue and culling: raster_common.h.  VALU / v_exp bound (about 20 vector ops per
-// pixel-Gaussian pair against 44 bytes per tile-Gaussian pair), so the design spends its
-// effort on evaluating fewer pairs, not on moving bytes.
+// Geometry, queue and culling: raster_common.h.  VALU-bound: 13 FMA-class + 7 compare/select-class
+// instructions + one v_exp per 64 pixel-Gaussian pairs against 44 bytes per tile-Gaussian pair
+// (SQ_ACTIVE_INST_VALU ~ 76 % of SIMD cycles, HBM at ~2 TB/s), so the design spends its effort on
+// evaluating fewer pairs and on cheaper evaluations, not on moving bytes.
 #include "raster_common.h"
 
 #ifndef MGS_RASTER_WAVES
-#define MGS_RASTER_WAVES 4   // min waves per SIMD asked of the register allocator; measured: 8/6/5 spill and lose (522/356/313 us), 4 = 292 us
+// min waves per SIMD asked of the register allocator; 8 / 6 / 5 spill and lose (profiles/r1/05)
+#define MGS_RASTER_WAVES 4
 #endif
 
 namespace mgs {
