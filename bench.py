@@ -179,6 +179,10 @@ def main():
         torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / 20 * 1e3
     outs = [(None, None, s["meta"]) for s in fr._slots]
+    if do_gather and rank == 0:
+        # the collective really delivered every rank's frame (all cameras see the scene)
+        for r_ in range(world):
+            assert float(gather_bufs[0][r_].abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
     status = max(int(o[2]["isect_status"].max().item()) for o in outs)
     assert status == 0, "tile-intersection capacity overflow inside the timed region"
     frames_per_s = world * a.steps / elapsed
