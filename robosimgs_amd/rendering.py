@@ -24,6 +24,30 @@ from .ops import TILE_SIZE, _f32c
 _MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 
 
+class _Meta(dict):
+    """The `meta` dict of `rasterization`.  The render path keeps the per-camera tile lists on
+    the device at their capacity; gsplat's flat `flatten_ids` / `isect_ids` tensors are
+    materialised only if somebody asks for them (one read-back of the intersection counts)."""
+
+    def __missing__(self, key):
+        if key not in ("flatten_ids", "isect_ids") or "tile_lists" not in self:
+            raise KeyError(key)
+        lists = self["tile_lists"]
+        n_tiles = self["tile_width"] * self["tile_height"]
+        tile_bits = int(n_tiles).bit_length()             # floor(log2(n_tiles)) + 1
+        N = self["radii"].shape[1]
+        counts = [int(c) for c in self["n_isects"].tolist()]
+        flat, keys = [], []
+        for c, (tl, n) in enumerate(zip(lists, counts)):
+            ids = tl.flatten_ids[:n]
+            flat.append(ids + c * N)
+            depth_bits = self["depths"][c][ids.long()].view(torch.int32).long() & 0xFFFFFFFF
+            keys.append((((c << tile_bits) | tl.tile_ids[:n].long()) << 32) | depth_bits)
+        self["flatten_ids"] = torch.cat(flat)
+        self["isect_ids"] = torch.cat(keys)
+        return self[key]
+
+
 class _RenderSH(torch.autograd.Function):
     """SH-coloured frames for C cameras: fused projection+colour, binning, raster."""
 
@@ -157,8 +181,9 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
     want_rgb = render_mode.startswith("RGB")
     want_depth = render_mode != "RGB"
     tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
-    meta: Dict = {"width": width, "height": height, "tile_size": TILE_SIZE,
-                  "tile_width": tile_w, "tile_height": tile_h, "n_cameras": C}
+    meta: Dict = _Meta({"width": width, "height": height, "tile_size": TILE_SIZE,
+                        "tile_width": tile_w, "tile_height": tile_h, "n_cameras": C,
+                        "camera_ids": None, "gaussian_ids": None})
 
     if sh_degree is not None and want_rgb:
         if colors.dim() != 3 or colors.shape[0] != N or colors.shape[2] != 3:

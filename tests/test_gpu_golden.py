@@ -68,3 +68,23 @@ def test_tile_lists_bit_exact_vs_golden_inputs():
     np.testing.assert_array_equal(tl.flatten_ids[:n].cpu().numpy(), g["flatten_ids"])
     np.testing.assert_array_equal(tl.isect_ids[:n].cpu().numpy(), g["isect_ids"])
     np.testing.assert_array_equal(tl.tile_offsets[:-1].cpu().numpy().reshape(th, tw), g["isect_offsets"])
+
+
+def test_meta_offers_gsplat_flat_lists_on_demand():
+    from robosimgs_amd import rasterization
+    g = GOLD
+    W, H, deg = int(g["width"]), int(g["height"]), int(g["sh_degree"])
+    _, _, meta = rasterization(_t(g["means"]), _t(g["quats"]), _t(g["scales"]), _t(g["opacities"]),
+                               _t(g["sh_coeffs"]), _t(g["viewmat"])[None], _t(g["K"])[None], W, H,
+                               sh_degree=deg)
+    assert "flatten_ids" not in dict.keys(meta)            # not materialised until asked for
+    np.testing.assert_array_equal(meta["flatten_ids"].cpu().numpy(), g["flatten_ids"])
+    keys = meta["isect_ids"].cpu().numpy()
+    np.testing.assert_array_equal(keys >> 32, g["isect_ids"] >> 32)              # (camera | tile) part
+    # depth part: float bits of the fp32 device depth vs the fp64 oracle's depth cast to fp32
+    assert np.abs((keys & 0xffffffff) - (g["isect_ids"] & 0xffffffff)).max() <= 4
+    for k in ("radii", "means2d", "depths", "conics", "opacities", "tile_width", "tile_height",
+              "tiles_per_gauss", "isect_offsets", "width", "height", "tile_size", "n_cameras"):
+        assert k in meta
+    with pytest.raises(KeyError):
+        meta["no_such_key"]
