@@ -205,21 +205,23 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel (tile raster forward), HIP events on the stream
-        radii, m2d, depths, con, _, feats = ops.project_color_fwd_raw(
+        radii, m2d, depths, con, _, feats, splats = ops.project_color_fwd_raw(
             t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W,
-            H, 0.3, 0.01, 1e10, 0.0, False, False)
+            H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
         tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False)
         # the inference variant (no last_ids), i.e. the kernel the timed frames above run
         out = None
         reps = 50
         for _ in range(5):
             out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
-                                        tl.tile_offsets, tl.flatten_ids, out=out, track_last=False)
+                                        tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
+                                        splats=splats)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
             ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
-                                  tl.tile_offsets, tl.flatten_ids, out=out)
+                                  tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
+                                  splats=splats)
         e1.record()
         torch.cuda.synchronize()
         raster_ms = e0.elapsed_time(e1) / reps

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     const float* __restrict__ Kmat, float W, float H, float eps2d, float near_plane,
     float far_plane, float radius_clip, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ conics,
-    float* __restrict__ opac_out, int feat_stride, float* __restrict__ feats) {
+    float* __restrict__ opac_out, int feat_stride, float* __restrict__ feats,
+    float4* __restrict__ splats) {
   __shared__ float4 lds[STAGED ? (kBlock / kWave) * kWave * kShPitchF4 : 1];
   int g = blockIdx.x * kBlock + threadIdx.x;
   CameraParams cam = load_camera(viewmat, Kmat);
@@ -174,6 +175,12 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     rgb[0] = fmaxf(rgb[0] + 0.5f, 0.f);
     rgb[1] = fmaxf(rgb[1] + 0.5f, 0.f);
     rgb[2] = fmaxf(rgb[2] + 0.5f, 0.f);
+  }
+  if (splats) {   // one 48-byte record per Gaussian for the raster kernels' list gathers
+    float op = opacities ? opacities[g] * (opac_out ? p.compensation : 1.f) : 0.f;
+    splats[3 * (size_t)g + 0] = make_float4(p.mean2d[0], p.mean2d[1], p.conic[0], p.conic[1]);
+    splats[3 * (size_t)g + 1] = make_float4(p.conic[2], active ? op : 0.f, rgb[0], rgb[1]);
+    splats[3 * (size_t)g + 2] = make_float4(rgb[2], feat_stride == 4 ? p.depth : 0.f, 0.f, 0.f);
   }
   if (feat_stride == 4) {
     reinterpret_cast<float4*>(feats)[g] = make_float4(rgb[0], rgb[1], rgb[2], p.depth);
@@ -237,7 +244,7 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
                                      float far_plane, float radius_clip, int32_t* radii,
                                      float* means2d, float* depths, float* conics,
                                      float* opac_out, int feat_stride, float* feats,
-                                     mgs_stream_t stream) {
+                                     float* splats, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "project_color_fwd: bad sizes");
   MGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_color_fwd: sh_degree %d not in 0..3", sh_degree);
   MGS_REQUIRE(coeff_stride >= (sh_degree + 1) * (sh_degree + 1), "project_color_fwd: coeff_stride too small");
@@ -246,6 +253,7 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
   MGS_REQUIRE(means && quats && scales && sh_coeffs && viewmat && K && radii && means2d &&
                   depths && conics && feats, "project_color_fwd: null pointer");
   MGS_REQUIRE(!opac_out || opacities, "project_color_fwd: opac_out needs opacities");
+  MGS_REQUIRE(!splats || opacities, "project_color_fwd: splats needs opacities");
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   int sf = coeff_stride * 3;
@@ -254,7 +262,8 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
   hipLaunchKernelGGL((project_color_fwd_kernel<D, S>), grid, block, 0, s, n, means, quats,    \
                      scales, opacities, sf, sh_coeffs, viewmat, K, (float)width,              \
                      (float)height, eps2d, near_plane, far_plane, radius_clip, radii,         \
-                     means2d, depths, conics, opac_out, feat_stride, feats)
+                     means2d, depths, conics, opac_out, feat_stride, feats,                    \
+                     reinterpret_cast<float4*>(splats))
   switch (sh_degree) {
     case 0: MGS_PC_LAUNCH(0, false); break;
     case 1: MGS_PC_LAUNCH(1, false); break;

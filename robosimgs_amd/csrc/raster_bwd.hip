@@ -91,8 +91,8 @@ template <int CHT, bool ABSGRAD, bool RECORDS>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
-    const float* __restrict__ background, int channels, int width, int height, int tile_w,
-    int n_tiles, const int32_t* __restrict__ tile_offsets,
+    const float4* __restrict__ splats, const float* __restrict__ background, int channels,
+    int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
     const float* __restrict__ v_alphas, float* __restrict__ v_means2d,
@@ -151,13 +151,22 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
     int g = 0;
     float2 xy = make_float2(0.f, 0.f);
     float ca = 1.f, cb = 0.f, cc = 1.f, op = 0.f;
+    float pf[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool packed = CHT <= 4 && splats != nullptr;
     if (idx <= hi) {
       g = flatten_ids[idx];
-      xy = reinterpret_cast<const float2*>(means2d)[g];
-      ca = conics[3 * (size_t)g + 0];
-      cb = conics[3 * (size_t)g + 1];
-      cc = conics[3 * (size_t)g + 2];
-      op = opacities[g];
+      if (packed) {
+        const float4 p0 = splats[3 * (size_t)g], p1 = splats[3 * (size_t)g + 1], p2 = splats[3 * (size_t)g + 2];
+        xy = make_float2(p0.x, p0.y);
+        ca = p0.z; cb = p0.w; cc = p1.x; op = p1.y;
+        pf[0] = p1.z; pf[1] = p1.w; pf[2] = p2.x; pf[3] = p2.y;
+      } else {
+        xy = reinterpret_cast<const float2*>(means2d)[g];
+        ca = conics[3 * (size_t)g + 0];
+        cb = conics[3 * (size_t)g + 1];
+        cc = conics[3 * (size_t)g + 2];
+        op = opacities[g];
+      }
       qmask = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, tile_x, tile_y) & live;
     }
     const unsigned long long keep = __ballot(qmask != 0u);
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
       float f[((CHT + 3) / 4) * 4];
 #pragma unroll
       for (int c = 0; c < ((CHT + 3) / 4) * 4; ++c)
-        f[c] = (c < CHT && c < channels) ? feats[(size_t)g * channels + c] : 0.f;
+        f[c] = (c < CHT && c < channels) ? (packed ? pf[c & 3] : feats[(size_t)g * channels + c]) : 0.f;
 #pragma unroll
       for (int j = 0; j < (CHT + 3) / 4; ++j)
         e.feat[j] = make_float4(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]);
@@ -359,7 +368,8 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
   hipStream_t s = (hipStream_t)stream;
 #define MGS_RB_LAUNCH(C, A)                                                                    \
   hipLaunchKernelGGL((raster_bwd_kernel<C, A, false>), dim3(n_tiles), dim3(64), 0, s, means2d,  \
-                     conics, feats, opacities, background, channels, width, height, tile_w,    \
+                     conics, feats, opacities, (const float4*)nullptr, background, channels,   \
+                     width, height, tile_w,                                                    \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities,                 \
                      (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr)
@@ -378,7 +388,8 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
 
 extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* conics,
                                      const float* feats, const float* opacities,
-                                     const float* background, int channels, int width,
+                                     const float* splats, const float* background, int channels,
+                                     int width,
                                      int height, int tile_w, int tile_h,
                                      const int32_t* tile_offsets, const int32_t* flatten_ids,
                                      const float* alphas, const int32_t* last_ids,
@@ -404,8 +415,9 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
     return set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "rasterize_bwd_det: workspace %zu < %zu bytes",
                      *workspace_bytes, need);
   if (n == 0) return MGS_OK;
-  MGS_REQUIRE(means2d && conics && feats && opacities && tile_offsets && flatten_ids && alphas &&
-                  last_ids && v_render && v_alphas && pair_info && v_means2d && v_conics &&
+  MGS_REQUIRE(!splats || channels <= 4, "rasterize_bwd_det: packed splats carry at most 4 channels");
+  MGS_REQUIRE((splats || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
+                  alphas && last_ids && v_render && v_alphas && pair_info && v_means2d && v_conics &&
                   v_feats && v_opacities, "rasterize_bwd_det: null pointer");
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
@@ -416,7 +428,8 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   const int4* info = reinterpret_cast<const int4*>(pair_info);
 #define MGS_RD_LAUNCH(C, A)                                                                     \
   hipLaunchKernelGGL((raster_bwd_kernel<C, A, true>), dim3(n_tiles), dim3(64), 0, s, means2d,   \
-                     conics, feats, opacities, background, channels, width, height, tile_w,    \
+                     conics, feats, opacities, reinterpret_cast<const float4*>(splats),        \
+                     background, channels, width, height, tile_w,                              \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
                      (float*)nullptr, info, records, flags);                                   \

@@ -59,8 +59,8 @@ template <int CHT, bool TRACK_LAST>
 __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_fwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
-    const float* __restrict__ background, int channels, int width, int height, int tile_w,
-    int n_tiles, const int32_t* __restrict__ tile_offsets,
+    const float4* __restrict__ splats, const float* __restrict__ background, int channels,
+    int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
     float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull) {
   __shared__ QueueEntry<CHT> queue[kQueue + 1];
@@ -94,7 +94,15 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
 #pragma unroll
   for (int c = 0; c < CHT; ++c) r_feat[c] = 0.f;
   auto fetch = [&](int idx, bool ok) {
-    if (ok) {
+    if (ok && CHT <= 4 && splats) {   // one packed 48-byte record instead of four gathers
+      int g = flatten_ids[idx];
+      const float4 p0 = splats[3 * (size_t)g], p1 = splats[3 * (size_t)g + 1], p2 = splats[3 * (size_t)g + 2];
+      r_xy = make_float2(p0.x, p0.y);
+      r_ca = p0.z; r_cb = p0.w; r_cc = p1.x; r_op = p1.y;
+      const float ff[4] = {p1.z, p1.w, p2.x, p2.y};
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) r_feat[c] = ff[c & 3];
+    } else if (ok) {
       int g = flatten_ids[idx];
       r_xy = reinterpret_cast<const float2*>(means2d)[g];
       r_ca = conics[3 * (size_t)g + 0];
@@ -207,7 +215,7 @@ static int g_raster_cull = 1;
 extern "C" void mgs_debug_set_raster_cull(int enabled) { g_raster_cull = enabled; }
 
 extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conics,
-                                 const float* feats, const float* opacities,
+                                 const float* feats, const float* opacities, const float* splats,
                                  const float* background, int channels, int width, int height,
                                  int tile_w, int tile_h, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, float* render, float* alphas,
@@ -216,13 +224,15 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_fwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
               "rasterize_fwd: tile grid %dx%d does not match %dx%d at tile size 16", tile_w, tile_h, width, height);
-  MGS_REQUIRE((n == 0 || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
-                  render && alphas, "rasterize_fwd: null pointer");
+  MGS_REQUIRE(!splats || channels <= 4, "rasterize_fwd: packed splats carry at most 4 channels");
+  MGS_REQUIRE((n == 0 || splats || (means2d && conics && feats && opacities)) && tile_offsets &&
+                  flatten_ids && render && alphas, "rasterize_fwd: null pointer");
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
 #define MGS_RF_LAUNCH_T(C, T)                                                                  \
   hipLaunchKernelGGL((raster_fwd_kernel<C, T>), dim3(n_tiles), dim3(64), 0, s, means2d, conics, \
-                     feats, opacities, background, channels, width, height, tile_w, n_tiles,   \
+                     feats, opacities, reinterpret_cast<const float4*>(splats), background,     \
+                     channels, width, height, tile_w, n_tiles,                                 \
                      tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull)
 #define MGS_RF_LAUNCH(C) do { if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)
   if (channels == 1) MGS_RF_LAUNCH(1);

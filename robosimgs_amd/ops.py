@@ -54,7 +54,9 @@ def projection_fwd_raw(means, quats, scales, viewmat, K, width, height, eps2d, n
 
 def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmat, K,
                           width, height, eps2d, near_plane, far_plane, radius_clip,
-                          antialiased, with_depth):
+                          antialiased, with_depth, want_splats=False):
+    """Returns (radii, means2d, depths, conics, opac_aa|None, feats) and, with want_splats, a 7th
+    item: the packed [N,12] records the raster kernels gather from."""
     n = means.shape[0]
     dev = means.device
     radii = torch.empty(n, dtype=torch.int32, device=dev)
@@ -64,11 +66,14 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
     opac = torch.empty(n, dtype=torch.float32, device=dev) if antialiased else None
     stride = 4 if with_depth else 3
     feats = torch.empty(n, stride, dtype=torch.float32, device=dev)
+    splats = torch.empty(n, 12, dtype=torch.float32, device=dev) if want_splats else None
     check(_lib.lib().mgs_project_color_fwd(
         n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), sh_degree, sh_coeffs.shape[1],
         ptr(sh_coeffs), ptr(viewmat), ptr(K), width, height, eps2d, near_plane, far_plane,
         radius_clip, ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(opac), stride,
-        ptr(feats), stream_handle()), "mgs_project_color_fwd")
+        ptr(feats), ptr(splats), stream_handle()), "mgs_project_color_fwd")
+    if want_splats:
+        return radii, means2d, depths, conics, opac, feats, splats
     return radii, means2d, depths, conics, opac, feats
 
 
@@ -125,7 +130,7 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
-                      tile_h, tile_offsets, flatten_ids, out=None, track_last=True):
+                      tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None):
     """out = (render, alphas, last_ids|None) to write into existing buffers.  track_last=False (or
     last_ids None) is the inference variant: no last_ids, one select less per pair."""
     n = means2d.shape[0]
@@ -139,7 +144,7 @@ def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, heig
     else:
         render, alphas, last_ids = out
     check(_lib.lib().mgs_rasterize_fwd(n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities),
-                                       ptr(background), ch, width, height, tile_w, tile_h,
+                                       ptr(splats), ptr(background), ch, width, height, tile_w, tile_h,
                                        ptr(tile_offsets), ptr(flatten_ids), ptr(render),
                                        ptr(alphas), ptr(last_ids), stream_handle()),
           "mgs_rasterize_fwd")
@@ -172,7 +177,7 @@ def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, heig
 
 def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                           tile_h, tl: "TileLists", alphas, last_ids, v_render, v_alphas,
-                          absgrad=False):
+                          absgrad=False, splats=None):
     """Atomic-free, bit-reproducible raster backward (needs tl.pair_info from the binning).
     Returns freshly written (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None)."""
     n = means2d.shape[0]
@@ -185,8 +190,8 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
     v_abs = torch.empty(n, 2, dtype=torch.float32, device=dev) if absgrad else None
     L = _lib.lib()
     nbytes = ctypes.c_size_t(0)
-    args = [n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities), ptr(background), ch, width,
-            height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
+    args = [n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities), ptr(splats), ptr(background),
+            ch, width, height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
             ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(tl.pair_info), tl.capacity,
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),

@@ -67,9 +67,10 @@ class _RenderSH(torch.autograd.Function):
                     else None)
         per_cam = []
         for c in range(C):
-            radii, means2d, depths, conics, opac_aa, feats = ops.project_color_fwd_raw(
+            radii, means2d, depths, conics, opac_aa, feats, splats = ops.project_color_fwd_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats[c], Ks[c], width,
-                height, eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth)
+                height, eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth,
+                want_splats=True)
             opac = opac_aa if antialiased else opacities
             cap = isect_capacity
             if cap is None:
@@ -80,8 +81,9 @@ class _RenderSH(torch.autograd.Function):
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
-                                  out=(render[c], alphas[c], last_ids[c] if training else None))
-            per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl))
+                                  out=(render[c], alphas[c], last_ids[c] if training else None),
+                                  splats=splats)
+            per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl, splats))
         ctx.per_cam = per_cam
         ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks,
                               backgrounds, alphas, last_ids)
@@ -108,12 +110,12 @@ class _RenderSH(torch.autograd.Function):
         v_opacities = torch.empty_like(opacities) if antialiased else None
         L = _lib.lib()
         for c in range(C):
-            radii, means2d, depths, conics, opac_aa, feats, tl = ctx.per_cam[c]
+            radii, means2d, depths, conics, opac_aa, feats, tl, splats = ctx.per_cam[c]
             opac = opac_aa if antialiased else opacities
             bg = backgrounds[c] if backgrounds is not None else None
             v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_det_raw(
                 means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl, alphas[c],
-                last_ids[c], v_render[c], v_alphas[c], absgrad)
+                last_ids[c], v_render[c], v_alphas[c], absgrad, splats=splats)
             # screen-space gradients for densification strategies (gsplat exposes them through
             # means2d.grad / means2d.absgrad; here they are published in the meta dict)
             ctx.meta_out.setdefault("means2d_grad", [None] * C)[c] = v_means2d

@@ -15,20 +15,20 @@ vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)
 K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)
 tw, th = -(-W // 16), -(-H // 16)
 def project():
-    return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, False)
-radii, m2d, dep, con, _, feats = project()
+    return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
+radii, m2d, dep, con, _, feats, splats = project()
 tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 else 8_000_000, want_tiles_per_gauss=False, want_pair_info=True)
-out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids)
+out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats)
 torch.cuda.synchronize()
 print("n_isect", int(tl.n_isect))
 vr = torch.rand(H, W, 3, device=dev); va = torch.rand(H, W, device=dev)
 for _ in range(reps):
     if stage == "raster":
-        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out)
+        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out, splats=splats)
     elif stage == "raster_bwd":
         ops.rasterize_bwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out[1], out[2], vr, va)
     elif stage == "raster_bwd_det":
-        ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl, out[1], out[2], vr, va)
+        ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl, out[1], out[2], vr, va, splats=splats)
     elif stage == "train":
         from robosimgs_amd.rendering import rasterization
         ps = {k: t[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}

@@ -24,14 +24,14 @@ def frame(cap, rec=None):
     def ev():
         e = torch.cuda.Event(enable_timing=True); e.record(); return e
     e0 = ev()
-    radii, means2d, depths, conics, opac, feats = ops.project_color_fwd_raw(
+    radii, means2d, depths, conics, opac, feats, splats = ops.project_color_fwd_raw(
         t["means"], t["quats"], t["scales"], t["opacities"], a.deg, t["colors"], vm, K, a.w, a.h,
-        0.3, 0.01, 1e10, 0.0, False, False)
+        0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
     e1 = ev()
     tl = ops.isect_tiles_raw(means2d, radii, depths, tw, th, cap, want_tiles_per_gauss=False)
     e2 = ev()
     out = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, a.w, a.h, tw, th,
-                                tl.tile_offsets, tl.flatten_ids)
+                                tl.tile_offsets, tl.flatten_ids, splats=splats, track_last=False)
     e3 = ev()
     if rec is not None:
         rec.append((e0, e1, e2, e3))
