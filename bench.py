@@ -96,16 +96,23 @@ def main():
     K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)[None]
     tile_w, tile_h = -(-W // 16), -(-H // 16)
 
-    def forward(cap=None):
+    def forward(cap=None, bounds="tight"):
         return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
-                             vm, K, W, H, sh_degree=deg, render_mode="RGB", isect_capacity=cap)
+                             vm, K, W, H, sh_degree=deg, render_mode="RGB", isect_capacity=cap,
+                             tile_bounds=bounds)
 
-    # sizing pass (reads n_isect back once, outside every timed region)
-    colors, alphas, meta = forward()
+    # sizing passes (read n_isect back, outside every timed region).  n_isect is the classic
+    # mean +- radius count SURVEY.md 8(d) calibrates (5,019,7xx at config 2) and the algorithmic
+    # bytes are priced on; the frames run on the tightened lists (n_isect_binned, same image).
+    colors, alphas, meta = forward(bounds="classic")
     torch.cuda.synchronize()
     n_isect = int(meta["n_isects"][0])
     n_vis = int((meta["radii"] > 0).sum())
-    cap = int(n_isect * 1.25) + 4096
+    colors_t, alphas_t, meta_t = forward()
+    assert torch.equal(colors_t, colors) and torch.equal(alphas_t, alphas), "tight tile bounds changed the image"
+    n_isect_binned = int(meta_t["n_isects"][0])
+    del colors_t, alphas_t, meta_t
+    cap = int(n_isect_binned * 1.25) + 4096
 
     # ---- forward frames through the library's FrameRenderer ---------------------------------
     # One HIP graph per in-flight slot, camera in device buffers, `inflight` independent frames
@@ -196,6 +203,7 @@ def main():
         "config": {"workload": f"configs[1]: {a.n} Gaussians, SH degree {deg}, {W}x{H} forward "
                                "render, one camera per GPU",
                    "n_gaussians": a.n, "n_visible": n_vis, "n_isect": n_isect,
+                   "n_isect_binned": n_isect_binned,
                    "tiles": tile_w * tile_h, "cameras_per_step": world,
                    "gather": "fp32 RGB frames to rank 0 (RCCL)" if do_gather else "none",
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
@@ -208,7 +216,8 @@ def main():
         radii, m2d, depths, con, _, feats, splats = ops.project_color_fwd_raw(
             t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W,
             H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
-        tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False)
+        tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False,
+                                 conics=con, opacities=t["opacities"])
         # the inference variant (no last_ids), i.e. the kernel the timed frames above run
         out = None
         reps = 50

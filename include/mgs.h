@@ -132,6 +132,13 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * Internally: 32-bit radix sort of the Gaussians by depth, an exclusive scan of tile
  * counts in that order, a load-balanced emit, and a radix sort on the tile bits only.
  *
+ * conics[N,3], opacities[N] (both nullable): when given, each Gaussian's tile rectangle is
+ * tightened to the tiles holding a pixel centre it can reach with alpha >= 1/255 (bounding
+ * box of the ellipse sigma <= ln(255 opacity), intersected with the classic mean +- radius
+ * rectangle).  The dropped pairs fail the raster's alpha test at every pixel, so images and
+ * gradients are bit-identical while the lists are ~27 % shorter at 1 M Gaussians / 1080p;
+ * tiles_per_gauss / n_isect then count the tightened lists.  NULL: gsplat's classic lists.
+ *
  * Workspace: call with workspace == NULL to get the byte count in *workspace_bytes.
  * tiles_per_gauss[N] nullable.  n_isect, status: device uint32 scalars (status is OR-ed,
  * never cleared, by the library).
@@ -141,7 +148,8 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * mgs_rasterize_bwd_det.
  * ----------------------------------------------------------------------------------- */
 int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const float *depths,
-                    int tile_size, int tile_w, int tile_h, int cam_id, int n_cams,
+                    const float *conics, const float *opacities, int tile_size, int tile_w,
+                    int tile_h, int cam_id, int n_cams,
                     uint32_t isect_capacity, int32_t *tiles_per_gauss, uint32_t *n_isect,
                     uint32_t *tile_ids, int32_t *flatten_ids, int64_t *isect_ids,
                     int32_t *tile_offsets, int32_t *pair_info, uint32_t *status,

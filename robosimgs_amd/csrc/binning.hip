@@ -35,9 +35,46 @@ __device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, fl
   return r;
 }
 
+// Tiles that hold a pixel centre the Gaussian can reach with alpha >= 1/255: the bounding box of
+// the ellipse sigma <= ln(255 opacity) (half extents sqrt(2 lim Sigma_xx), sqrt(2 lim Sigma_yy)),
+// intersected with the classic rectangle `r`.  Every dropped (tile, Gaussian) pair fails the
+// raster's alpha test at all 256 pixels, so the image and the gradients do not change by a bit
+// (tests/test_gpu_forward.py, test_gpu_backward.py) while the lists shrink by ~27 % at config 2.
+// Sigma = conic^-1 is taken from the fp32 conic in double: the blend evaluates exactly that
+// rounded quadratic form, and a*c - b*b in fp32 loses everything for elongated footprints.
+// `lim` carries the same fp32 slack as the raster's own quadrant cull (raster_common.h).
+__device__ __forceinline__ TileRect tighten_rect(TileRect r, float mx, float my, float a, float b,
+                                                 float c, float opac, float tile_size) {
+  if (!(opac >= 1.0f / 255.0f)) { r.w = 0; r.h = 0; return r; }   // alpha <= opacity < 1/255
+  const double det = (double)a * (double)c - (double)b * (double)b;
+  if (!(det > 0.0) || !(a > 0.f) || !(c > 0.f)) return r;          // degenerate: keep classic
+  const double sxx = (double)c / det, syy = (double)a / det;
+  const float thr = __logf(255.0f * opac);
+  const float e2 = (float)(2.0 * (double)(thr + 0.05f) * (sxx + syy));
+  const float slack = 0.05f + 8e-6f * (fabsf(a) + fabsf(c) + 2.f * fabsf(b)) * (e2 + 512.f);
+  const double lim = 2.0 * (double)(thr + slack);
+  const float ex = (float)sqrt(lim * sxx) * 1.0001f + 0.01f;
+  const float ey = (float)sqrt(lim * syy) * 1.0001f + 0.01f;
+  // pixel centres are i + 0.5: first / last pixel column and row inside the box
+  const float plx = ceilf(mx - ex - 0.5f), phx = floorf(mx + ex - 0.5f);
+  const float ply = ceilf(my - ey - 0.5f), phy = floorf(my + ey - 0.5f);
+  if (!(phx >= plx) || !(phy >= ply)) {
+    if (phx < plx || phy < ply) { r.w = 0; r.h = 0; }               // no pixel centre inside
+    return r;                                                      // NaN: keep classic
+  }
+  const int x0 = max(r.x0, (int)fmaxf(floorf(plx / tile_size), -1.f));
+  const int y0 = max(r.y0, (int)fmaxf(floorf(ply / tile_size), -1.f));
+  const int x1 = min(r.x0 + r.w, (int)fminf(floorf(phx / tile_size), 65535.f) + 1);
+  const int y1 = min(r.y0 + r.h, (int)fminf(floorf(phy / tile_size), 65535.f) + 1);
+  if (x1 <= x0 || y1 <= y0) { r.w = 0; r.h = 0; return r; }
+  r.x0 = x0; r.y0 = y0; r.w = x1 - x0; r.h = y1 - y0;
+  return r;
+}
+
 __global__ __launch_bounds__(kBlock) void depth_key_kernel(
     int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-    const float* __restrict__ depths, float tile_size, int tile_w, int tile_h,
+    const float* __restrict__ depths, const float* __restrict__ conics,
+    const float* __restrict__ opacities, float tile_size, int tile_w, int tile_h,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ ginfo,
     int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ n_gauss_dev) {
   int g = blockIdx.x * kBlock + threadIdx.x;
@@ -48,6 +85,9 @@ __global__ __launch_bounds__(kBlock) void depth_key_kernel(
   if (radius > 0) {
     float2 m = reinterpret_cast<const float2*>(means2d)[g];
     TileRect r = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
+    if (conics)
+      r = tighten_rect(r, m.x, m.y, conics[3 * (size_t)g], conics[3 * (size_t)g + 1],
+                       conics[3 * (size_t)g + 2], opacities[g], tile_size);
     cnt = (uint32_t)(r.w * r.h);
     pack = (uint32_t)r.x0 | ((uint32_t)r.y0 << 10) | ((uint32_t)max(r.w, 1) << 20);
     key = __float_as_uint(depths[g]);
@@ -300,7 +340,8 @@ struct Workspace {
 using namespace mgs;
 
 extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii,
-                               const float* depths, int tile_size, int tile_w, int tile_h,
+                               const float* depths, const float* conics, const float* opacities,
+                               int tile_size, int tile_w, int tile_h,
                                int cam_id, int n_cams, uint32_t isect_capacity,
                                int32_t* tiles_per_gauss, uint32_t* n_isect, uint32_t* tile_ids,
                                int32_t* flatten_ids, int64_t* isect_ids, int32_t* tile_offsets,
@@ -319,6 +360,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     return set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "isect_tiles: workspace %zu < %zu bytes",
                      *workspace_bytes, ws.total);
   MGS_REQUIRE(isect_capacity > 0, "isect_tiles: zero capacity");
+  MGS_REQUIRE((conics == nullptr) == (opacities == nullptr),
+              "isect_tiles: tight tile bounds need both conics and opacities");
   MGS_REQUIRE((n == 0 || (means2d && radii && depths)) && n_isect && tile_ids && flatten_ids &&
                   tile_offsets && status, "isect_tiles: null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -334,7 +377,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   } else {
     const unsigned nblk = div_up(n, kBlock);
     hipLaunchKernelGGL(depth_key_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,
-                       depths, (float)tile_size, tile_w, tile_h, u32(ws.keys_a), u32(ws.vals_a),
+                       depths, conics, opacities, (float)tile_size, tile_w, tile_h, u32(ws.keys_a),
+                       u32(ws.vals_a),
                        reinterpret_cast<uint2*>(w + ws.ginfo), tiles_per_gauss, n_gauss_dev);
     // 4 passes (even): the depth order ends in (keys_a, vals_a)
     rc = radix_sort_pairs(n_gauss_dev, (uint32_t)n, 32, u32(ws.keys_a), u32(ws.vals_a),

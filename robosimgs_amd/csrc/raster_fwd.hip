@@ -28,9 +28,23 @@ struct PixelState {
   float T;
   float C[CHT];
   int last;
+#ifdef MGS_RASTER_STATS
+  unsigned n_valid = 0, n_acc = 0;
+#endif
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
+
+#ifdef MGS_RASTER_STATS
+// Instrumented build only (python robosimgs_amd/csrc/build.py with MGS_EXTRA_FLAGS=-DMGS_RASTER_STATS):
+// counts the work the forward raster really does; read back with mgs_debug_read_raster_stats().
+//   0 list entries fetched   1 entries queued after the cull   2 quadrant evaluations (x64 lanes)
+//   3 lanes with a valid alpha   4 lanes accumulated   5 batches processed   6 batches in lists
+__device__ unsigned long long g_raster_stats[8];
+#define MGS_STAT(i, v) stat[i] += (v)
+#else
+#define MGS_STAT(i, v)
+#endif
 
 // One Gaussian against the 64 pixels of one quadrant (one pixel per lane).
 //   power = -sigma * log2(e) = A dx^2 + C dy^2 + B dx dy  with  A = -0.5 log2e a, B = -log2e b,
@@ -47,6 +61,10 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
   bool valid = power <= 0.f && alpha >= kAlphaMin;
   float next_T = fmaf(-alpha, px.T, px.T);
   bool acc = valid && next_T > kTStop;            // false for finished pixels (T < 0)
+#ifdef MGS_RASTER_STATS
+  px.n_valid += valid && px.T > 0.f;
+  px.n_acc += acc;
+#endif
   float w = acc ? alpha * px.T : 0.f;
 #pragma unroll
   for (int c = 0; c < CHT; ++c) px.C[c] = fmaf(w, feat[c], px.C[c]);
@@ -75,6 +93,10 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
   const int ix = tx * 16 + (int)(lane & 7), iy = ty * 16 + (int)(lane >> 3);
   const float px0 = (float)ix + 0.5f, py0 = (float)iy + 0.5f;
 
+#ifdef MGS_RASTER_STATS
+  unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  stat[6] = (unsigned)(end - start + kQueue - 1) / kQueue;
+#endif
   PixelState<CHT> st[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -139,6 +161,9 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
     if (c_ok) qmask = (cull ? quadrant_mask(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, c_op, tile_x, tile_y) : 0xfu) & live;
     const unsigned long long keep = __ballot(qmask != 0u);
     const int count = __popcll(keep);
+    MGS_STAT(0, __popcll(__ballot(c_ok)));
+    MGS_STAT(1, count);
+    MGS_STAT(5, 1);
     if (qmask != 0u) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
@@ -170,6 +195,7 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
       }
       const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z));
       const int idx = __float_as_int(g1.w);
+      MGS_STAT(2, __popc(m));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (m & (1u << k))
@@ -189,6 +215,16 @@ __global__ __launch_bounds__(64, (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_
     __builtin_amdgcn_wave_barrier();   // queue is rewritten by the next batch
   }
 
+#ifdef MGS_RASTER_STATS
+  {
+    unsigned nv = 0, na = 0;
+    for (int k = 0; k < 4; ++k) { nv += st[k].n_valid; na += st[k].n_acc; }
+    for (int d = 32; d >= 1; d >>= 1) { nv += __shfl_xor(nv, d); na += __shfl_xor(na, d); }
+    stat[3] = nv; stat[4] = na;
+    if (lane == 0)
+      for (int i = 0; i < 7; ++i) atomicAdd(&g_raster_stats[i], stat[i]);
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int x = ix + 8 * (k & 1), y = iy + 8 * (k >> 1);
@@ -213,6 +249,16 @@ using namespace mgs;
 // live quadrant).  The image must not change; tests/test_gpu_forward.py checks that bit for bit.
 static int g_raster_cull = 1;
 extern "C" void mgs_debug_set_raster_cull(int enabled) { g_raster_cull = enabled; }
+
+#ifdef MGS_RASTER_STATS
+// instrumented build only: copy the counters out (synchronous) and zero them
+extern "C" int mgs_debug_read_raster_stats(unsigned long long* out8) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_raster_stats), sizeof(zero)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_raster_stats), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
 
 extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conics,
                                  const float* feats, const float* opacities, const float* splats,

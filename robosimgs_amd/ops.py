@@ -100,7 +100,9 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_id=0, n_cams=1,
                     want_isect_ids=False, want_tiles_per_gauss=True,
-                    want_pair_info=False) -> TileLists:
+                    want_pair_info=False, conics=None, opacities=None) -> TileLists:
+    """conics + opacities given: tile rectangles tightened to the tiles a Gaussian can reach with
+    alpha >= 1/255 (shorter lists, bit-identical render); None: gsplat's classic rectangles."""
     n = means2d.shape[0]
     dev = means2d.device
     L = _lib.lib()
@@ -116,7 +118,8 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     out.isect_ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_isect_ids else None
     out.pair_info = torch.empty(n, 4, dtype=torch.int32, device=dev) if want_pair_info else None
     nbytes = ctypes.c_size_t(0)
-    args = [n, ptr(means2d), ptr(radii), ptr(depths), TILE_SIZE, tile_w, tile_h, cam_id, n_cams,
+    args = [n, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), TILE_SIZE,
+            tile_w, tile_h, cam_id, n_cams,
             capacity, ptr(out.tiles_per_gauss), ptr(out.n_isect), ptr(out.tile_ids),
             ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.pair_info),
             ptr(out.status)]

@@ -54,7 +54,7 @@ class _RenderSH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds,
                 width, height, sh_degree, eps2d, near_plane, far_plane, radius_clip,
-                antialiased, with_depth, isect_capacity, absgrad, meta_out):
+                antialiased, with_depth, isect_capacity, absgrad, meta_out, tight):
         C = viewmats.shape[0]
         dev = means.device
         tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
@@ -77,7 +77,9 @@ class _RenderSH(torch.autograd.Function):
                 cap = max(1, ops._upper_bound_isects(radii, tile_w, tile_h))
             tl = ops.isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, cap, c, C,
                                      want_isect_ids=False, want_tiles_per_gauss=True,
-                                     want_pair_info=training)
+                                     want_pair_info=training,
+                                     conics=conics if tight else None,
+                                     opacities=opac if tight else None)
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
@@ -143,7 +145,7 @@ class _RenderSH(torch.autograd.Function):
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[7]:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return (v_means, v_quats, v_scales, v_opacities, v_sh, None, None, v_bg) + (None,) * 12
+        return (v_means, v_quats, v_scales, v_opacities, v_sh, None, None, v_bg) + (None,) * 13
 
 
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
@@ -153,8 +155,14 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                   tile_size: int = TILE_SIZE, backgrounds: Optional[Tensor] = None,
                   render_mode: str = "RGB", sparse_grad: bool = False, absgrad: bool = False,
                   rasterize_mode: str = "classic", channel_chunk: int = 32,
-                  isect_capacity: Optional[int] = None) -> Tuple[Tensor, Tensor, Dict]:
+                  isect_capacity: Optional[int] = None,
+                  tile_bounds: str = "tight") -> Tuple[Tensor, Tensor, Dict]:
     """Render N Gaussians from C cameras.
+
+    tile_bounds (SH path): "tight" bins each Gaussian only into the tiles it can reach with
+    alpha >= 1/255 (mgs_isect_tiles with conics + opacities): same image and gradients bit for
+    bit, shorter lists; meta["tiles_per_gauss"] / ["n_isects"] then count those lists.
+    "classic" reproduces gsplat's mean +- radius rectangles in the meta outputs as well.
 
     means [N,3], quats [N,4] (wxyz), scales [N,3], opacities [N] (post-activation);
     colors [N,K,3] SH coefficients when sh_degree is given, else [N,D] / [C,N,D] features;
@@ -169,6 +177,8 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
         raise NotImplementedError("packed / sparse_grad are not supported")
     if tile_size != TILE_SIZE:
         raise NotImplementedError(f"tile_size must be {TILE_SIZE}")
+    if tile_bounds not in ("tight", "classic"):
+        raise ValueError(f"tile_bounds {tile_bounds!r} not in ('tight', 'classic')")
     require_device(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
     N, C = means.shape[0], viewmats.shape[0]
     if means.shape != (N, 3) or quats.shape != (N, 4) or scales.shape != (N, 3) \
@@ -199,7 +209,8 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
         render, alphas = _RenderSH.apply(
             means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height,
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
-            float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store)
+            float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store,
+            tile_bounds == "tight")
         per_cam = store.pop("per_cam")
 
         def _stk(xs):                 # no copy for the common single-camera call

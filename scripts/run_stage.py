@@ -17,7 +17,9 @@ tw, th = -(-W // 16), -(-H // 16)
 def project():
     return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
 radii, m2d, dep, con, _, feats, splats = project()
-tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 else 8_000_000, want_tiles_per_gauss=False, want_pair_info=True)
+TIGHT = os.environ.get("TIGHT", "1") != "0"      # tightened tile rectangles (the render path's default)
+tkw = dict(conics=con, opacities=t["opacities"]) if TIGHT else {}
+tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 else 8_000_000, want_tiles_per_gauss=False, want_pair_info=True, **tkw)
 out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats)
 torch.cuda.synchronize()
 print("n_isect", int(tl.n_isect))
@@ -32,10 +34,10 @@ for _ in range(reps):
     elif stage == "train":
         from robosimgs_amd.rendering import rasterization
         ps = {k: t[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
-        c, a_, _ = rasterization(ps["means"], ps["quats"], ps["scales"], ps["opacities"], ps["colors"], vm[None], K[None], W, H, sh_degree=deg, isect_capacity=8_000_000)
+        c, a_, _ = rasterization(ps["means"], ps["quats"], ps["scales"], ps["opacities"], ps["colors"], vm[None], K[None], W, H, sh_degree=deg, isect_capacity=8_000_000, tile_bounds="tight" if TIGHT else "classic")
         (c - vr[None]).abs().mean().backward()
     elif stage == "binning":
-        ops.isect_tiles_raw(m2d, radii, dep, tw, th, 8_000_000, want_tiles_per_gauss=False)
+        ops.isect_tiles_raw(m2d, radii, dep, tw, th, 8_000_000, want_tiles_per_gauss=False, **tkw)
     elif stage == "project":
         project()
 torch.cuda.synchronize()

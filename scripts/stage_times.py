@@ -11,6 +11,7 @@ ap.add_argument("--w", type=int, default=1920)
 ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--deg", type=int, default=3)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--classic", action="store_true", help="classic mean +- radius tile rectangles")
 a = ap.parse_args()
 dev = "cuda"
 g = synthetic_scene(a.n, math.log(a.mu), a.deg, 0)
@@ -28,7 +29,8 @@ def frame(cap, rec=None):
         t["means"], t["quats"], t["scales"], t["opacities"], a.deg, t["colors"], vm, K, a.w, a.h,
         0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
     e1 = ev()
-    tl = ops.isect_tiles_raw(means2d, radii, depths, tw, th, cap, want_tiles_per_gauss=False)
+    tkw = {} if a.classic else dict(conics=conics, opacities=t["opacities"])
+    tl = ops.isect_tiles_raw(means2d, radii, depths, tw, th, cap, want_tiles_per_gauss=False, **tkw)
     e2 = ev()
     out = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, a.w, a.h, tw, th,
                                 tl.tile_offsets, tl.flatten_ids, splats=splats, track_last=False)

@@ -6,6 +6,8 @@
 template <int KIND>
 __global__ void k(float* out, int iters, float seed) {
   float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 1.0001f, c = 0.5f;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 p0 = {a0, a1}, p1 = {a1, a2}, p2 = {a2, a3}, p3 = {a3, a0}, pb = {b, b}, pc = {c, c};
   unsigned long long m = iters & 1 ? 0xffffffff00000000ull : 0x00000000ffffffffull;
   for (int i = 0; i < iters; ++i) {
     if (KIND == 0) { REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
@@ -18,8 +20,15 @@ __global__ void k(float* out, int iters, float seed) {
     if (KIND == 7) { REP16(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
     if (KIND == 8) { REP16(asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
     if (KIND == 9) { REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n s_and_b64 s[20:21], s[20:21], s[22:23]\n v_fma_f32 %1, %1, %4, %5\n s_and_b64 s[20:21], s[20:21], s[22:23]\n v_fma_f32 %2, %2, %4, %5\n s_and_b64 s[20:21], s[20:21], s[22:23]\n v_fma_f32 %3, %3, %4, %5\n s_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "s20","s21","scc");) }
+    if (KIND == 10) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));) }
+    if (KIND == 11) { REP16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));) }
+    if (KIND == 12) { REP16(asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));) }
+    if (KIND == 13) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %1, %1, %4, %5 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %2, %2, %4, %5 op_sel_hi:[1,0,0]\n v_pk_fma_f32 %3, %3, %4, %5 op_sel_hi:[1,0,0]" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));) }
+    if (KIND == 14) { REP16(asm volatile("v_max_f32 %0, %0, %4\n v_min_f32 %1, %1, %4\n v_max_f32 %2, %2, %4\n v_min_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) }
+    if (KIND == 15) { REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_min_f32 %1, %1, %4\n v_fma_f32 %2, %2, %4, %5\n v_min_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
+    if (KIND == 16) { REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_exp_f32 %1, %1\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));) }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p1.y + p2.x + p3.y;
 }
 template <int KIND> void run(const char* name, float* d, int threads) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -44,6 +53,10 @@ int main() {
     run<3>("v_cndmask_b32 (sgpr mask)", d, threads); run<4>("v_cmp_le_f32 -> vcc", d, threads);
     run<5>("v_cmp_le_f32 -> sgpr pair", d, threads); run<8>("v_add_f32 dpp quad_perm", d, threads);
     run<9>("v_fma_f32 + s_and_b64 interleaved", d, threads);
+    run<10>("v_pk_fma_f32", d, threads); run<11>("v_pk_mul_f32", d, threads); run<12>("v_pk_add_f32", d, threads);
+    run<13>("v_pk_fma_f32 op_sel_hi broadcast", d, threads);
+    run<14>("v_max/v_min alternating", d, threads); run<15>("v_fma/v_min alternating", d, threads);
+    run<16>("3 v_fma + 1 v_exp", d, threads);
   }
   return 0;
 }

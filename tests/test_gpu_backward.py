@@ -251,3 +251,47 @@ def test_screen_space_gradients_are_published():
     assert g2d.shape == (3000, 2) and float(g2d.abs().sum()) > 0
     assert bool((gabs + 1e-6 >= g2d.abs()).all())
     assert bool((g2d[meta["radii"][0] == 0] == 0).all())
+
+
+@pytest.mark.parametrize("case", ["elongated", "faint", "huge", "config1", "antialiased"])
+def test_tight_tile_bounds_change_no_bit(case):
+    """mgs_isect_tiles with conics + opacities drops (tile, Gaussian) pairs that cannot reach
+    alpha >= 1/255 at any pixel centre.  Image, alpha and every gradient must be bit-identical to
+    the classic rectangles, for needle-like footprints (fp32 cancellation in the conic), barely
+    visible opacities, screen-filling Gaussians and the anti-aliased opacity."""
+    from robosimgs_amd import rasterization
+    W, H = 200, 136
+    rng = np.random.default_rng(7)
+    g = synthetic_scene(6000, math.log(0.05), 1, 11)
+    kw = {}
+    if case == "elongated":
+        g.log_scales[:, 0] += 2.5
+        g.log_scales[:, 1:] -= 2.0
+    elif case == "faint":
+        g.opacity_logits[:] = rng.normal(-5.3, 0.6, size=g.opacity_logits.shape)   # around 1/255
+    elif case == "huge":
+        g.log_scales[::50] += 3.5
+    elif case == "antialiased":
+        g.log_scales[:] -= 1.5
+        kw["rasterize_mode"] = "antialiased"
+    cam = camera_ring(1, W, H, thetas=[0.7])[0]
+    t = g.to_torch(DEV, 1)
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    w_img = torch.from_numpy(rng.normal(size=(H, W, 4)).astype(np.float32)).to(DEV)
+    w_a = torch.from_numpy(rng.normal(size=(H, W, 1)).astype(np.float32)).to(DEV)
+    outs = {}
+    for bounds in ("classic", "tight"):
+        p = {k: t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+        c, a, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, K,
+                                   W, H, sh_degree=1, render_mode="RGB+D", absgrad=True,
+                                   tile_bounds=bounds, **kw)
+        ((c[0] * w_img).sum() + (a[0] * w_a).sum()).backward()
+        outs[bounds] = (c.detach(), a.detach(), {k: v.grad for k, v in p.items()},
+                        meta["means2d"].absgrad, int(meta["n_isects"][0]), meta["tiles_per_gauss"])
+    cc, ca, cg, cabs, cn, ctp = outs["classic"]
+    tc, ta, tg, tabs, tn, ttp = outs["tight"]
+    assert torch.equal(cc, tc) and torch.equal(ca, ta)
+    for k in cg:
+        assert torch.equal(cg[k], tg[k]), k
+    assert torch.equal(cabs, tabs)
+    assert tn < cn and bool((ttp <= ctp).all()), (tn, cn)

@@ -176,7 +176,7 @@ def test_rasterization_end_to_end(mode):
     t = g.to_torch(DEV, 0)
     colors, alphas, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"],
                                          t["colors"], _t(cam.viewmat())[None], _t(cam.K)[None],
-                                         256, 256, sh_degree=0, render_mode=mode)
+                                         256, 256, sh_degree=0, render_mode=mode, tile_bounds="classic")
     ref, ref_alpha, rmeta = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
                                      cam.viewmat(), cam.K, 256, 256, sh_degree=0, render_mode=mode)
     assert colors.shape == (1,) + ref.shape
@@ -189,6 +189,14 @@ def test_rasterization_end_to_end(mode):
     tol = 1e-4 if "E" not in mode else 2e-3
     bad = (d > tol) | (da > 1e-4)
     assert bad.mean() <= 5e-4, f"{bad.sum()} px off (max {d.max():.3e} / alpha {da.max():.3e})"
+    # default (tight) tile bounds: shorter lists, the same image bit for bit
+    c2, a2, meta2 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                                  _t(cam.viewmat())[None], _t(cam.K)[None], 256, 256, sh_degree=0,
+                                  render_mode=mode)
+    assert torch.equal(c2, colors) and torch.equal(a2, alphas)
+    if "n_isects" in meta2:
+        assert int(meta2["n_isects"][0]) < int(meta["n_isects"][0])
+        assert bool((meta2["tiles_per_gauss"] <= meta["tiles_per_gauss"]).all())
 
 
 def test_rasterization_multi_camera_and_capacity():

@@ -31,7 +31,12 @@ def test_config2_matches_cpu_port_and_survey_counts(config2):
     from robosimgs_amd import rasterization
     g, cam, t = config2
     c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                               _t(cam.viewmat())[None], _t(cam.K)[None], 1920, 1080, sh_degree=3,
+                               tile_bounds="classic")
+    ct, at, mt = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
                                _t(cam.viewmat())[None], _t(cam.K)[None], 1920, 1080, sh_degree=3)
+    assert torch.equal(ct, c) and torch.equal(at, a)                 # tight tile bounds: same bits
+    assert int(mt["n_isects"][0]) < 0.8 * int(meta["n_isects"][0])
     n_isect = int(meta["n_isects"][0])
     assert int((meta["radii"] > 0).sum()) == 764_945                 # SURVEY.md 8(d) calibration
     assert abs(n_isect - 5_019_708) <= 100                           # fp32 vs fp64 knife edges
@@ -102,8 +107,14 @@ def test_config5_stress_matches_cpu_port():
     t = g.to_torch(DEV, 3)
     c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
                                _t(cam.viewmat())[None], _t(cam.K)[None], 3840, 2160, sh_degree=3,
-                               isect_capacity=40_000_000)
+                               isect_capacity=40_000_000, tile_bounds="classic")
     check_isect_status(meta)
+    ct, at, mt = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                               _t(cam.viewmat())[None], _t(cam.K)[None], 3840, 2160, sh_degree=3,
+                               isect_capacity=40_000_000)
+    assert torch.equal(ct, c) and torch.equal(at, a)
+    assert int(mt["n_isects"][0]) < int(meta["n_isects"][0])
+    del ct, at, mt
     assert int((meta["radii"] > 0).sum()) == 3_797_688
     assert abs(int(meta["n_isects"][0]) - 35_799_376) <= 600
     ref, ra, info = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,

@@ -21,7 +21,8 @@ def test_forward_and_backward_match_golden():
     W, H, deg = int(g["width"]), int(g["height"]), int(g["sh_degree"])
     p = {k: _t(g[k], True) for k in ("means", "quats", "scales", "opacities", "sh_coeffs")}
     img, alpha, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["sh_coeffs"],
-                                     _t(g["viewmat"])[None], _t(g["K"])[None], W, H, sh_degree=deg)
+                                     _t(g["viewmat"])[None], _t(g["K"])[None], W, H, sh_degree=deg,
+                                     tile_bounds="classic")
     assert int(meta["n_isects"][0]) == int(g["n_isect"])
     np.testing.assert_array_equal(meta["radii"][0].cpu().numpy(), g["radii"])
     np.testing.assert_array_equal(meta["tiles_per_gauss"][0].cpu().numpy(), g["tiles_per_gauss"])
@@ -76,7 +77,7 @@ def test_meta_offers_gsplat_flat_lists_on_demand():
     W, H, deg = int(g["width"]), int(g["height"]), int(g["sh_degree"])
     _, _, meta = rasterization(_t(g["means"]), _t(g["quats"]), _t(g["scales"]), _t(g["opacities"]),
                                _t(g["sh_coeffs"]), _t(g["viewmat"])[None], _t(g["K"])[None], W, H,
-                               sh_degree=deg)
+                               sh_degree=deg, tile_bounds="classic")
     assert "flatten_ids" not in dict.keys(meta)            # not materialised until asked for
     np.testing.assert_array_equal(meta["flatten_ids"].cpu().numpy(), g["flatten_ids"])
     keys = meta["isect_ids"].cpu().numpy()
