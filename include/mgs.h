@@ -105,7 +105,8 @@ int mgs_sh_bwd(int n, int degree, int coeff_stride, const float *dirs, const flo
  * never read.  feats[N,feat_stride]: channels 0..2 rgb; if feat_stride == 4 channel 3
  * receives the camera-space depth (the "RGB+D"/"RGB+ED" layout).  If `opac_out` is
  * non-null it receives opacities * compensation (rasterize_mode="antialiased").
- * splats[N,12] (nullable) additionally receives one packed 48-byte record per Gaussian,
+ * splats[N,12] (nullable) additionally receives one packed 48-byte record per VISIBLE Gaussian
+ * (rows of culled Gaussians, radii == 0, are left untouched: they never enter a tile list),
  *   { mean2d.x, mean2d.y, conic.a, conic.b | conic.c, opacity, f0, f1 | f2, f3, 0, 0 }
  * (opacity already multiplied by the compensation when antialiased; f = feats, zero padded):
  * the raster kernels gather ONE record per list entry instead of four separate arrays

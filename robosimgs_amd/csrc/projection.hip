@@ -176,10 +176,12 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     rgb[1] = fmaxf(rgb[1] + 0.5f, 0.f);
     rgb[2] = fmaxf(rgb[2] + 0.5f, 0.f);
   }
-  if (splats) {   // one 48-byte record per Gaussian for the raster kernels' list gathers
+  // one 48-byte record per visible Gaussian for the raster kernels' list gathers (culled
+  // Gaussians never enter a tile list: their records are left unwritten)
+  if (splats && active) {
     float op = opacities ? opacities[g] * (opac_out ? p.compensation : 1.f) : 0.f;
     splats[3 * (size_t)g + 0] = make_float4(p.mean2d[0], p.mean2d[1], p.conic[0], p.conic[1]);
-    splats[3 * (size_t)g + 1] = make_float4(p.conic[2], active ? op : 0.f, rgb[0], rgb[1]);
+    splats[3 * (size_t)g + 1] = make_float4(p.conic[2], op, rgb[0], rgb[1]);
     splats[3 * (size_t)g + 2] = make_float4(rgb[2], feat_stride == 4 ? p.depth : 0.f, 0.f, 0.f);
   }
   if (feat_stride == 4) {
