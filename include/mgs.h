@@ -243,6 +243,37 @@ int mgs_composite_over(int n_px, const float *bg_rgb, const float *bg_alpha,
                        const uint8_t *fg_mask, const float *backdrop, float *out_rgb,
                        float *out_depth, mgs_stream_t stream);
 
+/* -------------------------------------------------------------------------------------
+ * Point-cloud z-buffer helpers: the reference's
+ * Articulation/utils/point_utils.py, one entry point per function.
+ *
+ * mgs_points_project  = project_pcd (point_utils.py:13-26): pts[N,3] world, K[3,3],
+ *   c2w[4,4] row-major (camera looks down +z, no axis flip); pnt_cam = R^T (p - t),
+ *   uv[N,3] = (pnt_cam / z) K^T (third component 1), pnt_cam[N,3]; depth = pnt_cam[:,2].
+ * mgs_points_depth_map = get_depth_map (point_utils.py:44-73): cells_h = int(h / scale),
+ *   cells_w = int(w / scale) (computed by the caller as the reference does); every point goes
+ *   to cell (clip(round_half_even(u / scale)), clip(round_half_even(v / scale))), each cell
+ *   keeps min(bg_depth, depths) and the index of the first point attaining it (torch_scatter
+ *   scatter_min; N where no point is strictly below bg_depth).  depth_map[h,w] is the
+ *   nearest-neighbour upsample (cv2.INTER_NEAREST), index[cells_w*cells_h] (nullable) is in the
+ *   reference's cell order u * cells_h + v.  uv_stride = floats per uv row (2 or 3).
+ *   Workspace: two-phase size query (8 bytes per cell).
+ * mgs_points_sample_mask = mask_pcd_2d (point_utils.py:76-111): out[i] = bilinear(mask, uv_i)
+ *   > thresh, and, when depth_map and pnt_depth are both given, |bilinear(depth_map, uv_i) -
+ *   pnt_depth[i]| < depth_thresh.  Bilinear = grid_sample(align_corners=True, border padding)
+ *   at (uv - [w/2, h/2]) / [w/2, h/2].  mask, depth_map: float [h,w].
+ * ----------------------------------------------------------------------------------- */
+int mgs_points_project(int n, const float *pts, const float *K, const float *c2w, float *uv,
+                       float *pnt_cam, mgs_stream_t stream);
+int mgs_points_depth_map(int n, const float *uv, int uv_stride, const float *depth, int height,
+                         int width, int cells_h, int cells_w, float scale, float bg_depth,
+                         float *depth_map, int64_t *index, void *workspace,
+                         size_t *workspace_bytes, mgs_stream_t stream);
+int mgs_points_sample_mask(int n, const float *uv, int uv_stride, const float *mask, int height,
+                           int width, float thresh, const float *depth_map,
+                           const float *pnt_depth, float depth_thresh, uint8_t *out,
+                           mgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
