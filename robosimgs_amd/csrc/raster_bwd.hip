@@ -22,16 +22,14 @@ struct BwdEntry {
   float4 geo0;                       // mean.x, mean.y, conic.a, conic.b
   float4 geo1;                       // conic.c, opacity, quadrant mask (bits), list index (bits)
   float4 feat[(CHT + 3) / 4];
-  int gid;
-  int pad[3];
-};
+  float4 geo2;                       // record slot / Gaussian id (bits), then the conic pre-scaled for exp2:
+};                                   //   A = -0.5 log2e a, B = -log2e b, C = -0.5 log2e c
 
 template <int CHT>
 struct BwdPixel {
   float T;            // transmittance in front of the Gaussian being processed
-  float T_final;
-  float v_alpha;      // d loss / d alpha_out (minus the background term)
-  float buf[CHT];     // colour accumulated BEHIND the current Gaussian
+  float tfv;          // T_final * d loss / d alpha_out (minus the background term)
+  float bv;           // (colour accumulated BEHIND the current Gaussian) . v_c
   float v_c[CHT];     // d loss / d render
   int last;
 };
@@ -46,41 +44,63 @@ struct GaussGrad {
 // contributes; inside, the per-lane condition is folded into two masked factors (alpha_eff and
 // the opacity*vis product) so that every update is an unconditional FMA into the accumulators --
 // the branchy form made the compiler zero-initialise and merge nine temporaries per quadrant.
+// Two algebraic savings over the textbook per-pixel form (A.2 step 10), 38 -> 27 VALU per call:
+//   * colour only enters through dot products with the pixel's v_c, so the "colour behind"
+//     buffer is kept as the scalar bv = buffer . v_c and the Gaussian's colour as fv = feat . v_c;
+//   * with p = v_sigma dx, q = v_sigma dy the mean gradient is (ca p + cb q, cb p + cc q): the
+//     conic is constant per Gaussian, so only S0 = sum p and S1 = sum q are accumulated (v_x,
+//     v_y) and the CONSUMER applies the conic once per Gaussian (finish_geo below); likewise
+//     v_ca / v_cc hold twice the conic gradient until then.
 template <int CHT, bool ABSGRAD>
 __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, float pxf,
                                            float pyf, float mx, float my, float ca, float cb,
-                                           float cc, float opac, const float* feat, int idx) {
+                                           float cc, float A, float B, float C, float opac,
+                                           const float* feat, int idx) {
   float dx = mx - pxf, dy = my - pyf;
-  float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-  float vis = __expf(-sigma);
+  // the forward's own evaluation (raster_fwd.hip blend_pixel): power = -sigma log2(e), bit for bit
+  float power = fmaf(dx, fmaf(B, dy, A * dx), (C * dy) * dy);
+  float vis = __builtin_amdgcn_exp2f(power);
   float ov = opac * vis;
   float alpha = fminf(kAlphaMax, ov);
-  bool valid = idx <= px.last && sigma >= 0.f && alpha >= kAlphaMin;
+  bool valid = idx <= px.last && power <= 0.f && alpha >= kAlphaMin;
   if (__ballot(valid) == 0ull) return false;
-  float a_eff = valid ? alpha : 0.f;                       // 0 => T, buf and v_f stay untouched
+  float a_eff = valid ? alpha : 0.f;                       // 0 => T, bv and v_f stay untouched
   bool grad_geo = valid && ov <= kAlphaMax;                // alpha not clamped: sigma/opacity get grads
   float vis_eff = grad_geo ? vis : 0.f;
   float ra = __builtin_amdgcn_rcpf(1.0f - a_eff);          // v_rcp_f32; an IEEE divide is 11 instructions
   px.T *= ra;
   float fac = a_eff * px.T;
-  float v_alpha = px.T_final * ra * px.v_alpha;
+  float fv = feat[0] * px.v_c[0];
 #pragma unroll
-  for (int c = 0; c < CHT; ++c) {
-    gg.v_f[c] = fmaf(fac, px.v_c[c], gg.v_f[c]);
-    v_alpha = fmaf(fmaf(feat[c], px.T, -px.buf[c] * ra), px.v_c[c], v_alpha);
-    px.buf[c] = fmaf(feat[c], fac, px.buf[c]);
-  }
+  for (int c = 1; c < CHT; ++c) fv = fmaf(feat[c], px.v_c[c], fv);
+  float v_alpha = fmaf(fv, px.T, px.tfv * ra);
+  v_alpha = fmaf(-px.bv, ra, v_alpha);
+  px.bv = fmaf(fv, fac, px.bv);
+#pragma unroll
+  for (int c = 0; c < CHT; ++c) gg.v_f[c] = fmaf(fac, px.v_c[c], gg.v_f[c]);
   float v_sigma = -(opac * vis_eff) * v_alpha;
-  float hx = 0.5f * v_sigma * dx, hy = 0.5f * v_sigma * dy;
-  gg.v_ca = fmaf(hx, dx, gg.v_ca);
-  gg.v_cb = fmaf(v_sigma * dx, dy, gg.v_cb);
-  gg.v_cc = fmaf(hy, dy, gg.v_cc);
-  float gx = v_sigma * fmaf(cb, dy, ca * dx), gy = v_sigma * fmaf(cc, dy, cb * dx);
-  gg.v_x += gx;
-  gg.v_y += gy;
-  if (ABSGRAD) { gg.a_x += fabsf(gx); gg.a_y += fabsf(gy); }
+  float p = v_sigma * dx, q = v_sigma * dy;
+  gg.v_ca = fmaf(p, dx, gg.v_ca);
+  gg.v_cb = fmaf(p, dy, gg.v_cb);
+  gg.v_cc = fmaf(q, dy, gg.v_cc);
+  gg.v_x += p;
+  gg.v_y += q;
+  if (ABSGRAD) {
+    gg.a_x += fabsf(fmaf(cb, q, ca * p));
+    gg.a_y += fabsf(fmaf(cc, q, cb * p));
+  }
   gg.v_op = fmaf(vis_eff, v_alpha, gg.v_op);
   return valid;
+}
+
+// Sums of grad_pixel's raw geometric accumulators -> gradients of mean2d and conic.
+__device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& v_x, float& v_y,
+                                           float& v_ca, float& v_cc) {
+  const float s0 = v_x, s1 = v_y;
+  v_x = fmaf(cb, s1, ca * s0);
+  v_y = fmaf(cc, s1, cb * s0);
+  v_ca *= 0.5f;
+  v_cc *= 0.5f;
 }
 
 // RECORDS == false: lane 63 adds the wave-reduced sums to the per-Gaussian outputs with float
@@ -118,17 +138,16 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
     const int x = ix + 8 * (k & 1), y = iy + 8 * (k >> 1);
     const bool inside = x < width && y < height;
     const size_t p = inside ? (size_t)y * width + x : 0;
-    st[k].T_final = inside ? 1.0f - alphas[p] : 1.f;
-    st[k].T = st[k].T_final;
+    st[k].T = inside ? 1.0f - alphas[p] : 1.f;           // starts at the pixel's final transmittance
+    st[k].bv = 0.f;
     st[k].last = inside ? last_ids[p] : -1;
     float va = inside ? v_alphas[p] : 0.f;
 #pragma unroll
     for (int c = 0; c < CHT; ++c) {
-      st[k].buf[c] = 0.f;
       st[k].v_c[c] = (inside && c < channels) ? v_render[p * channels + c] : 0.f;
       if (background && c < channels) va -= background[c] * st[k].v_c[c];
     }
-    st[k].v_alpha = va;
+    st[k].tfv = st[k].T * va;
     hi = max(hi, st[k].last);
   }
   // wave-wide maximum of the last contributing index
@@ -175,12 +194,13 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
       BwdEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(xy.x, xy.y, ca, cb);
       e.geo1 = make_float4(cc, op, __uint_as_float(qmask), __int_as_float(idx));
+      int gid = g;
       if (RECORDS) {
         const int4 info = pair_info[g];
-        e.gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
-      } else {
-        e.gid = g;
+        gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
       }
+      constexpr float kLog2e = 1.4426950408889634f;
+      e.geo2 = make_float4(__int_as_float(gid), -0.5f * kLog2e * ca, -kLog2e * cb, -0.5f * kLog2e * cc);
       float f[((CHT + 3) / 4) * 4];
 #pragma unroll
       for (int c = 0; c < ((CHT + 3) / 4) * 4; ++c)
@@ -195,7 +215,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 
     for (int j = count - 1; j >= 0; --j) {
       const BwdEntry<CHT>& e = queue[j];
-      const float4 g0 = e.geo0, g1 = e.geo1;
+      const float4 g0 = e.geo0, g1 = e.geo1, g2 = e.geo2;
       float feat[CHT];
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
       }
       const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z));
       const int gi = __float_as_int(g1.w);
-      const int gid = __builtin_amdgcn_readfirstlane(e.gid);
+      const int gid = __builtin_amdgcn_readfirstlane(__float_as_int(g2.x));
       GaussGrad<CHT> gg;
       gg.v_x = gg.v_y = gg.v_ca = gg.v_cb = gg.v_cc = gg.v_op = gg.a_x = gg.a_y = 0.f;
 #pragma unroll
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
       for (int k = 0; k < 4; ++k) {
         if (m & (1u << k))
           any |= grad_pixel<CHT, ABSGRAD>(st[k], gg, px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1),
-                                          g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, gi);
+                                          g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, g2.z, g2.w, g1.y, feat, gi);
       }
       if (__ballot(any) == 0ull) continue;
       if constexpr (RECORDS) {
@@ -266,6 +286,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
         float ax = 0.f, ay = 0.f;
         if (ABSGRAD) { ax = wave_reduce_to_lane63(gg.a_x); ay = wave_reduce_to_lane63(gg.a_y); }
         if (lane == 63) {
+          finish_geo(g0.z, g0.w, g1.x, rx, ry, ra, rc);
           unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 0], rx);
           unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 1], ry);
           unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 0], ra);
@@ -290,7 +311,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
 template <int CHT, bool ABSGRAD>
 __global__ __launch_bounds__(256) void reduce_records_kernel(
     int n, const int4* __restrict__ pair_info, const float* __restrict__ records,
-    const uint8_t* __restrict__ flags, int channels, float* __restrict__ v_means2d,
+    const uint8_t* __restrict__ flags, const float* __restrict__ conics,
+    const float4* __restrict__ splats, int channels, float* __restrict__ v_means2d,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
     float* __restrict__ v_feats, float* __restrict__ v_opacities) {
   int g = blockIdx.x * 256 + threadIdx.x;
@@ -330,6 +352,16 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
       for (int c = 0; c < CHT; ++c) af[c] += rf[i][c];
       if (ABSGRAD) { ab[0] += ra[i][0]; ab[1] += ra[i][1]; }
     }
+  }
+  if (cnt > 0) {   // records hold grad_pixel's raw sums: apply the Gaussian's conic once, here
+    float ca, cb, cc;
+    if (splats) {
+      const float4 p0 = splats[3 * (size_t)g];
+      ca = p0.z; cb = p0.w; cc = splats[3 * (size_t)g + 1].x;
+    } else {
+      ca = conics[3 * (size_t)g]; cb = conics[3 * (size_t)g + 1]; cc = conics[3 * (size_t)g + 2];
+    }
+    finish_geo(ca, cb, cc, acc[0], acc[1], acc[2], acc[4]);
   }
   reinterpret_cast<float2*>(v_means2d)[g] = make_float2(acc[0], acc[1]);
   v_conics[3 * (size_t)g + 0] = acc[2];
@@ -434,8 +466,8 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
                      (float*)nullptr, info, records, flags);                                   \
   hipLaunchKernelGGL((reduce_records_kernel<C, A>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
-                     info, records, flags, channels, v_means2d, v_means2d_abs, v_conics,       \
-                     v_feats, v_opacities)
+                     info, records, flags, conics, reinterpret_cast<const float4*>(splats),    \
+                     channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities)
 #define MGS_RD(C) if (v_means2d_abs) { MGS_RD_LAUNCH(C, true); } else { MGS_RD_LAUNCH(C, false); }
   if (channels == 1) { MGS_RD(1) }
   else if (channels == 2) { MGS_RD(2) }

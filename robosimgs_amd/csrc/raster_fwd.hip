@@ -56,7 +56,7 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
                                             float my, float A, float B, float C, float opac,
                                             const float* feat, int idx) {
   float dx = mx - pxf, dy = my - pyf;
-  float power = dx * fmaf(B, dy, A * dx) + (C * dy) * dy;
+  float power = fmaf(dx, fmaf(B, dy, A * dx), (C * dy) * dy);   // spelled out: the backward repeats it bit for bit
   float alpha = fminf(kAlphaMax, opac * __builtin_amdgcn_exp2f(power));
   bool valid = power <= 0.f && alpha >= kAlphaMin;
   float next_T = fmaf(-alpha, px.T, px.T);
