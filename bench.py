@@ -269,6 +269,7 @@ def main():
 
 
 def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
+    from robosimgs_amd import l1_loss
     names = ("means", "quats", "scales", "opacities", "colors")
     params = {k: t[k].detach().clone().requires_grad_(True) for k in names}
     target = torch.rand(1, H, W, 3, device=dev, generator=torch.Generator(dev).manual_seed(1))
@@ -279,7 +280,7 @@ def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
         colors, alphas, meta = rasterization(params["means"], params["quats"], params["scales"],
                                              params["opacities"], params["colors"], vm, K, W, H,
                                              sh_degree=deg, render_mode="RGB", isect_capacity=cap)
-        loss = (colors - target).abs().mean()
+        loss = l1_loss(colors, target)      # fused HIP L1 (== (colors - target).abs().mean())
         loss.backward()
         return loss
 

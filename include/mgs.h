@@ -274,6 +274,17 @@ int mgs_points_sample_mask(int n, const float *uv, int uv_stride, const float *m
                            const float *pnt_depth, float depth_thresh, uint8_t *out,
                            mgs_stream_t stream);
 
+/* -------------------------------------------------------------------------------------
+ * Photometric L1 term of the training step (BASELINE configs[2]): loss = mean |a - b| over n
+ * floats (a = rendered image, b = target), and its gradient v_a = v_loss * sign(a - b) / n
+ * (sign(0) = 0, as torch).  loss, v_loss: device scalars (v_loss NULL = 1).  Fixed summation
+ * order: bit-reproducible.  Workspace (forward): two-phase size query.  Buffers 16-byte aligned.
+ * ----------------------------------------------------------------------------------- */
+int mgs_l1_loss_fwd(size_t n, const float *a, const float *b, float *loss, void *workspace,
+                    size_t *workspace_bytes, mgs_stream_t stream);
+int mgs_l1_loss_bwd(size_t n, const float *a, const float *b, const float *v_loss, float *v_a,
+                    mgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,49 @@
+"""Loss terms of the training step as fused HIP kernels.  `l1_loss(render, target)` is
+`(render - target).abs().mean()` with its gradient: two streaming launches forward, one backward
+(mgs_l1_loss_fwd / _bwd) instead of six elementwise / reduction kernels, bit-reproducible."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_device, stream_handle
+from .ops import _f32c
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        n = a.numel()
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        L = _lib.lib()
+        nbytes = ctypes.c_size_t(0)
+        check(L.mgs_l1_loss_fwd(n, None, None, None, None, ctypes.byref(nbytes), None), "mgs_l1_loss_fwd(size query)")
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=a.device)
+        check(L.mgs_l1_loss_fwd(n, ptr(a), ptr(b), ptr(loss), ptr(ws), ctypes.byref(nbytes),
+                                stream_handle()), "mgs_l1_loss_fwd")
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        a, b = ctx.saved_tensors
+        v_a = torch.empty_like(a)
+        g = _f32c(v_loss)
+        check(_lib.lib().mgs_l1_loss_bwd(a.numel(), ptr(a), ptr(b), ptr(g), ptr(v_a), stream_handle()),
+              "mgs_l1_loss_bwd")
+        return v_a, None
+
+
+def l1_loss(render: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """mean |render - target| (scalar tensor); gradient flows to `render` only."""
+    if render.shape != target.shape:
+        raise ValueError(f"shape mismatch {tuple(render.shape)} vs {tuple(target.shape)}")
+    require_device(render, target)
+    a, b = _f32c(render), _f32c(target.detach())
+    if a.data_ptr() % 16:            # a contiguous view at an odd offset: the kernels load float4
+        a = a.clone()
+    if b.data_ptr() % 16:
+        b = b.clone()
+    return _L1.apply(a, b)

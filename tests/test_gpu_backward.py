@@ -295,3 +295,25 @@ def test_tight_tile_bounds_change_no_bit(case):
         assert torch.equal(cg[k], tg[k]), k
     assert torch.equal(cabs, tabs)
     assert tn < cn and bool((ttp <= ctp).all()), (tn, cn)
+
+
+@pytest.mark.parametrize("shape", [(1, 37, 53, 3), (1080, 1920, 3), (7,), (4, 4)])
+def test_fused_l1_loss_matches_torch(shape):
+    from robosimgs_amd import l1_loss
+    gen = torch.Generator(DEV).manual_seed(3)
+    a = torch.rand(*shape, device=DEV, generator=gen).requires_grad_(True)
+    b = torch.rand(*shape, device=DEV, generator=gen)
+    with torch.no_grad():
+        b.view(-1)[::5] = a.view(-1)[::5]                      # exact zeros: sign(0) = 0
+    loss = l1_loss(a, b)
+    (loss * 3.0).backward()
+    a2 = a.detach().clone().requires_grad_(True)
+    ref = (a2 - b).abs().mean()
+    (ref * 3.0).backward()
+    assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, ref.item())
+    torch.testing.assert_close(a.grad, a2.grad, rtol=1e-6, atol=0)
+    assert l1_loss(a, b).item() == loss.item()                  # fixed summation order
+    # a contiguous view at an odd element offset
+    if len(shape) == 1:
+        v = torch.rand(9, device=DEV)[1:8]
+        assert abs(float(l1_loss(v, b)) - float((v - b).abs().mean())) < 1e-6
