@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
     const int4* __restrict__ pair_info, float* __restrict__ records,
     uint8_t* __restrict__ flags) {
   __shared__ BwdEntry<CHT> queue[kQueue];
+  __shared__ float red[RECORDS ? 8 : 1][64];     // wave-private transpose buffer of the record reduction
   const int tile = blockIdx.x;
   if (tile >= n_tiles) return;
   const unsigned lane = threadIdx.x;
@@ -259,6 +260,31 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
           return j - CHT + channels;
         };
         int done = 0;
+        // Eight values at a time through LDS: every lane parks its partial sums lane-linear
+        // (red[i][lane], conflict-free), lane L then reads the eight partials red[L >> 3][8 (L & 7) ..]
+        // with two ds_read_b128, adds them, and three DPP steps finish the sum over the eight lanes
+        // that share a value: 10 VALU per eight values against 26 for the all-DPP butterfly (LDS
+        // instructions of one wave execute in order, so the wave-private buffer needs no barrier
+        // beyond the compiler fences).
+        while (NV - done >= 8) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) red[i][lane] = vals[done + i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const float4* src = reinterpret_cast<const float4*>(&red[lane >> 3][(lane & 7) * 8]);
+          const float4 a = src[0], b = src[1];
+          float t = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+          t += dpp_f(t, kDppXor1);
+          t += dpp_f(t, kDppXor2);
+          t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x141, 0xf, 0xf, false));  // row_half_mirror
+          if ((lane & 7) == 0) {
+            int pos = rec_pos(done + (int)(lane >> 3));
+            if (pos >= 0) rec[pos] = t;
+          }
+          __builtin_amdgcn_wave_barrier();          // the next round overwrites red
+          done += 8;
+        }
 #define MGS_RS_CHUNK(V)                                                        \
         while (NV - done >= V) {                                               \
           float t = wave_reduce_scatter<V>(vals + done, lane);                 \
@@ -269,7 +295,6 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(
           }                                                                    \
           done += V;                                                           \
         }
-        MGS_RS_CHUNK(8)
         MGS_RS_CHUNK(4)
         MGS_RS_CHUNK(2)
         MGS_RS_CHUNK(1)
