@@ -322,3 +322,34 @@ def test_quadrant_cull_never_changes_a_pixel(ops, aniso):
     assert float(a[1].max()) > 0.5
     for x, y, name in zip(a, b, ("render", "alphas", "last_ids")):
         assert torch.equal(x, y), f"{name}: cull changed {int((x != y).sum())} values"
+
+
+def test_equal_depths_keep_gaussian_index_order():
+    """Collisions of the sort key: Gaussians at exactly the same camera depth must be blended in
+    Gaussian-index order (stable sort), in the lists and in the image."""
+    from robosimgs_amd import rasterization
+    n = 40
+    rng = np.random.default_rng(2)
+    vm = np.eye(4)
+    K = np.array([[120.0, 0, 48], [0, 120.0, 40], [0, 0, 1]])
+    means = np.column_stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.4, 0.4, n), np.full(n, 2.0)])
+    means[n // 2:, 2] = 3.0                                # two depth planes, 20 exact ties each
+    quats = np.tile([1.0, 0, 0, 0], (n, 1))
+    scales = np.full((n, 3), 0.15)
+    opac = rng.uniform(0.3, 0.95, n)
+    cols = rng.uniform(0, 1, (n, 3))
+    perm = rng.permutation(n)                              # index order unrelated to position
+    means, opac, cols = means[perm], opac[perm], cols[perm]
+    c, a, meta = rasterization(_t(means), _t(quats), _t(scales), _t(opac), _t(cols), _t(vm)[None],
+                               _t(K)[None], 96, 80, tile_bounds="classic")
+    ref, ra, rmeta = O.render(means, quats, scales, opac, cols, vm, K, 96, 80)
+    np.testing.assert_allclose(c[0].cpu().numpy(), ref, atol=1e-4)
+    np.testing.assert_allclose(a[0].cpu().numpy(), ra, atol=1e-4)
+    ids = meta["flatten_ids"].cpu().numpy()
+    off = meta["isect_offsets"].cpu().numpy().reshape(-1)
+    depth = means[:, 2]
+    for t0, t1 in zip(off, list(off[1:]) + [len(ids)]):
+        tile = ids[t0:t1]
+        key = depth[tile] * 1000 + tile                    # depth-major, then Gaussian index
+        assert np.all(np.diff(key) > 0)
+    assert len(ids) == rmeta["n_isect"]
