@@ -215,7 +215,10 @@ int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, cons
  *   v_means[N,3], v_quats[N,4], v_scales[N,3], v_sh_coeffs[N,K,3], and, iff antialiased,
  *   v_opacities[N].  accumulate == 0: every output row is overwritten (zeros for culled
  *   Gaussians and for coefficients above the active degree); accumulate != 0: added to,
- *   so the cameras of a batch can be summed without a separate zero-fill pass. */
+ *   so the cameras of a batch can be summed without a separate zero-fill pass.
+ *   v_viewmat[4,4] (nullable): gradient of the world-to-camera matrix (projection and the SH
+ *   view direction, dir = mean + R^T t), ALWAYS accumulated with one float atomic per entry
+ *   per wave: zero it first.  Camera-pose optimisation only. */
 int mgs_project_color_bwd(int n, const float *means, const float *quats, const float *scales,
                           const float *opacities, int sh_degree, int coeff_stride,
                           const float *sh_coeffs, const float *viewmat, const float *K,
@@ -225,7 +228,7 @@ int mgs_project_color_bwd(int n, const float *means, const float *quats, const f
                           const float *v_conics, const float *v_depths,
                           const float *v_opac_out, float *v_means, float *v_quats,
                           float *v_scales, float *v_sh_coeffs, float *v_opacities,
-                          int accumulate, mgs_stream_t stream);
+                          float *v_viewmat, int accumulate, mgs_stream_t stream);
 
 /* -------------------------------------------------------------------------------------
  * Compositing (the step downstream of the render path): depth-tested

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void sh_bwd_kernel(
   }
 }
 
-template <int DEG, bool STAGED, bool ACCUM>
+template <int DEG, bool STAGED, bool ACCUM, bool VIEWGRAD>
 __global__ __launch_bounds__(kBlock) void project_color_bwd_kernel(
     int n, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, int stride_f,
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void project_color_bwd_kernel(
     const float* __restrict__ v_means2d, const float* __restrict__ v_conics,
     const float* __restrict__ v_depths, const float* __restrict__ v_opac_out,
     float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-    float* __restrict__ v_coeffs, float* __restrict__ v_opacities) {
+    float* __restrict__ v_coeffs, float* __restrict__ v_opacities, float* __restrict__ v_viewmat) {
   __shared__ float4 lds[STAGED ? (kBlock / kWave) * kWave * kShPitchF4 : 1];
   int g = blockIdx.x * kBlock + threadIdx.x;
   bool active = g < n && radii[g] > 0;
@@ -203,9 +203,10 @@ __global__ __launch_bounds__(kBlock) void project_color_bwd_kernel(
   float v_dir[3];
   sh_bwd_rows<DEG, STAGED, ACCUM>(n, stride_f, g, active, dir, v_rgb, coeffs, v_coeffs,
                                   lds + (threadIdx.x / kWave) * kWave * kShPitchF4, v_dir);
-  if (g >= n) return;
+  if (g >= n && !VIEWGRAD) return;
   float om[3] = {0.f, 0.f, 0.f}, os[3] = {0.f, 0.f, 0.f}, oq[4] = {0.f, 0.f, 0.f, 0.f};
   float v_opac = 0.f;
+  ProjectedGrad r;
   if (active) {
     float s[3], q[4], con[3], vcon[3], vm2[2];
     load3(scales + 3 * (size_t)g, s);
@@ -226,8 +227,7 @@ __global__ __launch_bounds__(kBlock) void project_color_bwd_kernel(
       v_comp = vo * opacities[g];
       v_opac = vo * comp;
     }
-    ProjectedGrad r = project_gaussian_vjp(m, q, s, cam, W, H, eps2d, con, comp, vm2, v_depth,
-                                           vcon, v_comp);
+    r = project_gaussian_vjp(m, q, s, cam, W, H, eps2d, con, comp, vm2, v_depth, vcon, v_comp);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       om[k] = r.v_mean[k] + v_dir[k];
@@ -235,6 +235,21 @@ __global__ __launch_bounds__(kBlock) void project_color_bwd_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) oq[k] = r.v_quat[k];
+  }
+  if constexpr (VIEWGRAD) {
+    // the view direction depends on the camera too: dir = mean - campos = mean + R^T t
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          r.v_R[j * 3 + i] += v_dir[i] * cam.t[j];
+          r.v_t[j] += cam.R[j * 3 + i] * v_dir[i];
+        }
+      }
+    }
+    reduce_viewmat(r, active, v_viewmat);
+    if (g >= n) return;
   }
   float4* vq = reinterpret_cast<float4*>(v_quats) + g;
   if (ACCUM) {
@@ -317,7 +332,7 @@ extern "C" int mgs_project_color_bwd(int n, const float* means, const float* qua
                                      const float* v_conics, const float* v_depths,
                                      const float* v_opac_out, float* v_means, float* v_quats,
                                      float* v_scales, float* v_sh_coeffs, float* v_opacities,
-                                     int accumulate, mgs_stream_t stream) {
+                                     float* v_viewmat, int accumulate, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "project_color_bwd: bad sizes");
   MGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_color_bwd: sh_degree %d not in 0..3", sh_degree);
   MGS_REQUIRE(coeff_stride >= (sh_degree + 1) * (sh_degree + 1), "project_color_bwd: coeff_stride too small");
@@ -333,14 +348,16 @@ extern "C" int mgs_project_color_bwd(int n, const float* means, const float* qua
   int sf = coeff_stride * 3;
   bool staged = coeff_stride == 16;
 #define MGS_PCB(D, S, A)                                                                        \
-  hipLaunchKernelGGL((project_color_bwd_kernel<D, S, A>), grid, block, 0, s, n, means, quats,   \
+  if (v_viewmat) MGS_PCB_V(D, S, A, true); else MGS_PCB_V(D, S, A, false)
+#define MGS_PCB_V(D, S, A, V)                                                                   \
+  hipLaunchKernelGGL((project_color_bwd_kernel<D, S, A, V>), grid, block, 0, s, n, means, quats, \
                      scales, opacities, sf, sh_coeffs, viewmat, K, (float)width, (float)height, \
                      eps2d, radii, conics, antialiased, feat_stride, feats, v_feats, v_means2d, \
                      v_conics, v_depths, v_opac_out, v_means, v_quats, v_scales, v_sh_coeffs,   \
-                     v_opacities)
+                     v_opacities, v_viewmat)
 #define MGS_PCB_D(D)                                                  \
-  if (staged) { if (accumulate) MGS_PCB(D, true, true); else MGS_PCB(D, true, false); } \
-  else { if (accumulate) MGS_PCB(D, false, true); else MGS_PCB(D, false, false); }
+  if (staged) { if (accumulate) { MGS_PCB(D, true, true); } else { MGS_PCB(D, true, false); } } \
+  else { if (accumulate) { MGS_PCB(D, false, true); } else { MGS_PCB(D, false, false); } }
   switch (sh_degree) {
     case 0: MGS_PCB_D(0) break;
     case 1: MGS_PCB_D(1) break;
@@ -349,5 +366,6 @@ extern "C" int mgs_project_color_bwd(int n, const float* means, const float* qua
   }
 #undef MGS_PCB_D
 #undef MGS_PCB
+#undef MGS_PCB_V
   return check_launch("project_color_bwd");
 }

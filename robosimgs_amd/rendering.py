@@ -62,7 +62,7 @@ class _RenderSH(torch.autograd.Function):
         render = torch.empty(C, height, width, ch, dtype=torch.float32, device=dev)
         alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
         # last_ids (and the backward's slot map) only when some input wants a gradient
-        training = any(ctx.needs_input_grad[:5]) or ctx.needs_input_grad[7]
+        training = any(ctx.needs_input_grad[:6]) or ctx.needs_input_grad[7]
         last_ids = (torch.empty(C, height, width, dtype=torch.int32, device=dev) if training
                     else None)
         per_cam = []
@@ -110,6 +110,8 @@ class _RenderSH(torch.autograd.Function):
         v_scales = torch.empty_like(scales)
         v_sh = torch.empty_like(sh_coeffs)
         v_opacities = torch.empty_like(opacities) if antialiased else None
+        # camera-pose gradients only when asked for (float atomics into a zeroed [C,4,4])
+        v_viewmats = torch.zeros_like(viewmats) if ctx.needs_input_grad[5] else None
         L = _lib.lib()
         for c in range(C):
             radii, means2d, depths, conics, opac_aa, feats, tl, splats = ctx.per_cam[c]
@@ -129,7 +131,9 @@ class _RenderSH(torch.autograd.Function):
                 eps2d, ptr(radii), ptr(conics), int(antialiased), feats.shape[1], ptr(feats),
                 ptr(v_feats), ptr(v_means2d), ptr(v_conics), None,
                 ptr(v_opac) if antialiased else None, ptr(v_means), ptr(v_quats), ptr(v_scales),
-                ptr(v_sh), ptr(v_opacities), int(c > 0), stream_handle()),
+                ptr(v_sh), ptr(v_opacities),
+                ptr(v_viewmats[c]) if v_viewmats is not None else None, int(c > 0),
+                stream_handle()),
                 "mgs_project_color_bwd")
             if not antialiased:
                 v_opacities = v_opac if v_opacities is None else v_opacities + v_opac
@@ -145,7 +149,7 @@ class _RenderSH(torch.autograd.Function):
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[7]:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return (v_means, v_quats, v_scales, v_opacities, v_sh, None, None, v_bg) + (None,) * 13
+        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 13
 
 
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,

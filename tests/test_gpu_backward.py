@@ -317,3 +317,32 @@ def test_fused_l1_loss_matches_torch(shape):
     if len(shape) == 1:
         v = torch.rand(9, device=DEV)[1:8]
         assert abs(float(l1_loss(v, b)) - float((v - b).abs().mean())) < 1e-6
+
+
+@pytest.mark.parametrize("deg,mode", [(0, "RGB"), (3, "RGB+ED")])
+def test_camera_pose_gradient_matches_autograd(deg, mode):
+    """d loss / d viewmat through the fused path (projection AND the SH view direction), against
+    autograd of the fp64 torch oracle; two cameras, each with its own 4x4 gradient."""
+    from robosimgs_amd import rasterization
+    w, h = 96, 64
+    g = synthetic_scene(3000, math.log(0.09), deg, 4)
+    cams = camera_ring(2, w, h, thetas=[0.3, 1.9])
+    t = g.to_torch(DEV, deg)
+    vm = _t(np.stack([c.viewmat() for c in cams]), True)
+    Ks = _t(np.stack([c.K for c in cams]))
+    colors, alphas, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                                      vm, Ks, w, h, sh_degree=deg, render_mode=mode)
+    rng = np.random.default_rng(6)
+    wr, wa = rng.normal(size=tuple(colors.shape)), rng.normal(size=(2, h, w))
+    ((colors * _t(wr)).sum() + (alphas[..., 0] * _t(wa)).sum()).backward()
+    assert vm.grad is not None and vm.grad.shape == (2, 4, 4)
+    assert float(vm.grad[:, 3].abs().max()) == 0.0                      # the [0 0 0 1] row has no gradient
+    for c, cam in enumerate(cams):
+        rv = _d(cam.viewmat(), True)
+        img, al, _ = OT.render(_d(g.means), _d(g.quats), _d(g.scales), _d(g.opacities),
+                               _d(g.sh_coeffs[:, :(deg + 1) ** 2]), rv, _d(cam.K), w, h, sh_degree=deg,
+                               render_mode=mode)
+        ((img * _d(wr[c])).sum() + (al[..., 0] * _d(wa[c])).sum()).backward()
+        ref = rv.grad.numpy()[:3]
+        got = vm.grad[c, :3].cpu().double().numpy()
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), (c, got, ref)
