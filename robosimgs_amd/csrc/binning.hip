@@ -40,21 +40,25 @@ __device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, fl
 // intersected with the classic rectangle `r`.  Every dropped (tile, Gaussian) pair fails the
 // raster's alpha test at all 256 pixels, so the image and the gradients do not change by a bit
 // (tests/test_gpu_forward.py, test_gpu_backward.py) while the lists shrink by ~27 % at config 2.
-// Sigma = conic^-1 is taken from the fp32 conic in double: the blend evaluates exactly that
-// rounded quadratic form, and a*c - b*b in fp32 loses everything for elongated footprints.
+// Sigma = conic^-1 is taken from the fp32 conic the blend itself evaluates; a*c - b*b cancels
+// catastrophically for elongated footprints, so the determinant is Kahan-compensated (fma
+// residuals: exact to an ulp of the true value) and the extents carry a 1e-4 relative margin.
 // `lim` carries the same fp32 slack as the raster's own quadrant cull (raster_common.h).
 __device__ __forceinline__ TileRect tighten_rect(TileRect r, float mx, float my, float a, float b,
                                                  float c, float opac, float tile_size) {
   if (!(opac >= 1.0f / 255.0f)) { r.w = 0; r.h = 0; return r; }   // alpha <= opacity < 1/255
-  const double det = (double)a * (double)c - (double)b * (double)b;
-  if (!(det > 0.0) || !(a > 0.f) || !(c > 0.f)) return r;          // degenerate: keep classic
-  const double sxx = (double)c / det, syy = (double)a / det;
+  // det = a c - b b with Kahan's compensated 2x2 determinant: exact products via fma residuals
+  const float w = b * b, e = fmaf(-b, b, w), f = fmaf(a, c, -w);
+  const float det = f + e;
+  if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return r;          // degenerate: keep classic
+  const float inv_det = 1.0f / det;
+  const float sxx = c * inv_det, syy = a * inv_det;
   const float thr = __logf(255.0f * opac);
-  const float e2 = (float)(2.0 * (double)(thr + 0.05f) * (sxx + syy));
+  const float e2 = 2.0f * (thr + 0.05f) * (sxx + syy);
   const float slack = 0.05f + 8e-6f * (fabsf(a) + fabsf(c) + 2.f * fabsf(b)) * (e2 + 512.f);
-  const double lim = 2.0 * (double)(thr + slack);
-  const float ex = (float)sqrt(lim * sxx) * 1.0001f + 0.01f;
-  const float ey = (float)sqrt(lim * syy) * 1.0001f + 0.01f;
+  const float lim = 2.0f * (thr + slack);
+  const float ex = sqrtf(lim * sxx) * 1.0001f + 0.01f;
+  const float ey = sqrtf(lim * syy) * 1.0001f + 0.01f;
   // pixel centres are i + 0.5: first / last pixel column and row inside the box
   const float plx = ceilf(mx - ex - 0.5f), phx = floorf(mx + ex - 0.5f);
   const float ply = ceilf(my - ey - 0.5f), phy = floorf(my + ey - 0.5f);
