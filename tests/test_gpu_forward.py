@@ -353,3 +353,39 @@ def test_equal_depths_keep_gaussian_index_order():
         key = depth[tile] * 1000 + tile                    # depth-major, then Gaussian index
         assert np.all(np.diff(key) > 0)
     assert len(ids) == rmeta["n_isect"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_isect_tiles_random_sweep_bit_exact(ops, seed):
+    """Binning on synthetic screen-space inputs (not derived from a projection): odd counts around
+    the sort tile sizes, many zero radii, rectangles straddling every image edge, heavy depth ties,
+    tile grids from 1x1 to 1023 wide.  Lists, keys, offsets and counts must equal the stable-sort
+    formulation bit for bit."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([1, 63, 64, 65, 255, 257, 1023, 1025, 4097, 30_011]))
+    tw = int(rng.choice([1, 2, 7, 16, 61, 200, 1023]))
+    th = int(rng.choice([1, 3, 9, 33]))
+    w, h = tw * 16 - int(rng.integers(0, 16)), th * 16 - int(rng.integers(0, 16))
+    means2d = np.column_stack([rng.uniform(-40, w + 40, n), rng.uniform(-40, h + 40, n)]).astype(np.float32)
+    means2d[:: 7] = np.round(means2d[:: 7] / 16) * 16                       # exactly on tile edges
+    radii = rng.choice([0, 0, 1, 3, 8, 17, 40, 300], size=n).astype(np.int32)
+    if n * 50 > 3_000_000:
+        radii = np.minimum(radii, 17)
+    depths = rng.uniform(0.5, 30.0, n).astype(np.float32)
+    depths[rng.integers(0, n, n // 2)] = np.float32(7.25)                   # half the scene at one depth
+    tpg, isect_ids, flatten_ids = ops.isect_tiles(_t(means2d)[None], torch.from_numpy(radii).to(DEV)[None],
+                                                  _t(depths)[None], 16, tw, th)
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, tw, th, dtype=np.float32)
+    np.testing.assert_array_equal(tpg[0].cpu().numpy(), r_tpg)
+    np.testing.assert_array_equal(isect_ids.cpu().numpy(), r_ids)
+    np.testing.assert_array_equal(flatten_ids.cpu().numpy(), r_flat)
+    offs = ops.isect_offset_encode(isect_ids, 1, tw, th)
+    np.testing.assert_array_equal(offs.cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th))
+    # the device-resident variant (count never read back) agrees, with exactly enough capacity
+    total = int(r_tpg.sum())
+    tl = ops.isect_tiles_raw(_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), tw, th, max(total, 1),
+                             want_pair_info=True)
+    assert int(tl.n_isect.item()) == total and int(tl.status.item()) == 0
+    np.testing.assert_array_equal(tl.flatten_ids[:total].cpu().numpy(), r_flat)
+    np.testing.assert_array_equal(tl.tile_offsets[:-1].cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th).reshape(-1))
+    assert int(tl.tile_offsets[-1]) == total
