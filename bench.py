@@ -58,12 +58,14 @@ def parse():
     # debugging aid for the N > 1 control flow on a single-GPU box: all ranks share cuda:0 and the
     # collectives run over gloo with host staging.  Never used for a reported number.
     ap.add_argument("--debug-single-device-gloo", action="store_true")
+    # debugging aid: run the gather code path in a world of one (checks the RCCL plumbing on a 1-GPU box)
+    ap.add_argument("--force-gather", action="store_true")
     return ap.parse_args()
 
 
-def barrier_sync(world):
+def barrier_sync(use_dist):
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -80,8 +82,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if debug_gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -125,28 +129,36 @@ def main():
     vm_np, K_np = vm[0].cpu().numpy(), K[0].cpu().numpy()
     vm_dev, K_dev = vm[0].contiguous(), K[0].contiguous()
 
-    do_gather = world > 1 and not a.no_gather
+    do_gather = use_dist and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
     frame_shape = (H, W, 3)
     gather_bufs = None
     if do_gather and rank == 0:
         gather_bufs = [[torch.empty(frame_shape, device=comm_dev) for _ in range(world)]
                        for _ in range(n_fl)]
+    # host-staged copies only for the gloo debugging mode; RCCL sends straight from the slot
     send_bufs = ([torch.empty(frame_shape, device=comm_dev) for _ in range(n_fl)]
-                 if do_gather else None)
+                 if do_gather and debug_gloo else None)
     pending = [None] * n_fl
     tickets = []
 
     def retire():
-        """Fetch the oldest frame; with N > 1 hand it to the (asynchronous) RCCL gather."""
+        """Fetch the oldest frame; with N > 1 hand it to the (asynchronous) RCCL gather.  The
+        gather reads the slot's own frame buffer (no staging copy); the slot is released -- on the
+        stream level, the host does not block -- once that collective has drained, which with
+        `inflight` slots gives each gather inflight - 1 frame times to complete."""
         tk = tickets.pop(0)
         f = fr.fetch(tk, check=False)
-        if do_gather:
+        if do_gather and debug_gloo:
             if pending[tk] is not None:            # this slot's previous collective has drained
                 pending[tk].wait()
             send_bufs[tk].copy_(f["colors"], non_blocking=True)
             pending[tk] = dist.gather(send_bufs[tk], gather_bufs[tk] if rank == 0 else None,
                                       dst=0, async_op=True)
+        elif do_gather:
+            work = dist.gather(f["colors"], gather_bufs[tk] if rank == 0 else None, dst=0,
+                               async_op=True)
+            work.wait()                            # current STREAM waits for the collective
         fr.release(tk)
 
     def step(i):
@@ -165,14 +177,14 @@ def main():
     for i in range(a.warmup):
         step(i)
     drain()
-    barrier_sync(world)
+    barrier_sync(use_dist)
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
     drain()
-    barrier_sync(world)
+    barrier_sync(use_dist)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -264,7 +276,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, cam, W, H, deg, a.cpu_seconds)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
