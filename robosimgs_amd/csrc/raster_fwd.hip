@@ -59,18 +59,17 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
   float power = fmaf(dx, fmaf(B, dy, A * dx), (C * dy) * dy);   // spelled out: the backward repeats it bit for bit
   float alpha = fminf(kAlphaMax, opac * __builtin_amdgcn_exp2f(power));
   bool valid = power <= 0.f && alpha >= kAlphaMin;
-  float next_T = fmaf(-alpha, px.T, px.T);
-  bool acc = valid && next_T > kTStop;            // false for finished pixels (T < 0)
-#ifdef MGS_RASTER_STATS
-  px.n_valid += valid && px.T > 0.f;
-  px.n_acc += acc;
-#endif
-  float w = acc ? alpha * px.T : 0.f;
+  // alpha forced to 0 where the Gaussian does not count: an open pixel (T > 1e-4 by invariant)
+  // then keeps T and adds nothing, with no second mask to combine
+  float a_eff = valid ? alpha : 0.f;
+  float next_T = fmaf(-a_eff, px.T, px.T);
+  bool acc = next_T > kTStop;                     // false for finished pixels (T < 0) and for the closing Gaussian
+  float w = a_eff * px.T;
+  w = acc ? w : 0.f;
 #pragma unroll
   for (int c = 0; c < CHT; ++c) px.C[c] = fmaf(w, feat[c], px.C[c]);
-  float closed = valid ? -fabsf(px.T) : px.T;     // valid but not accumulated: the pixel finishes
-  px.T = acc ? next_T : closed;
-  if (TRACK_LAST) px.last = acc ? idx : px.last;
+  px.T = acc ? next_T : -fabsf(px.T);             // not accumulated: the pixel is (or stays) finished
+  if (TRACK_LAST) px.last = (acc && valid) ? idx : px.last;
 }
 
 template <int CHT, bool TRACK_LAST>
