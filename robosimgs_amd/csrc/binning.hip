@@ -17,7 +17,9 @@
 namespace mgs {
 namespace {
 
-constexpr int kBlock = 256;
+// 128-thread workgroups interleave better with other frames' raster waves than 256 (3035 -> 3090
+// frames/s at three frames in flight); 64 makes the kernels themselves slower (binning 224 -> 235 us).
+constexpr int kBlock = 128;
 
 struct TileRect { int x0, y0, w, h; };
 
@@ -125,7 +127,12 @@ __global__ __launch_bounds__(kBlock) void rank_blocksum_kernel(
   c = wave_sum(c);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
   __syncthreads();
-  if (threadIdx.x == 0) blocksums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+  if (threadIdx.x == 0) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) sum += ws[w];
+    blocksums[blockIdx.x] = sum;
+  }
 }
 
 // single workgroup: exclusive scan of the block sums in place; publishes n_isect / overflow

@@ -16,7 +16,10 @@
 namespace mgs {
 namespace {
 
-constexpr int kBlock = 256;
+// One wave per workgroup: with several frames in flight the raster's one-wave workgroups take every
+// wave slot as it frees up, and a 4-wave workgroup (which needs four slots on one CU at once) waits;
+// 256 -> 64 threads: 2936 -> 3060 frames/s at three frames in flight, same 55 us alone.
+constexpr int kBlock = 64;
 constexpr int kWave = kShWave;
 
 __device__ __forceinline__ void load3(const float* p, float v[3]) {
