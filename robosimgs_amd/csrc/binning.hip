@@ -269,22 +269,41 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
   }
 }
 
-// first sorted index of every tile; offsets[n_tiles] = n_isect
+// first sorted index of every tile; offsets[n_tiles] = n_isect.  Eight consecutive list entries per
+// thread (two 16-byte loads in flight): an eighth of the waves, each as short-lived as before --
+// with other frames' raster kernels running beside it, wave-slot time is what this kernel costs.
+constexpr int kOffsetsPerThread = 8;
 __global__ __launch_bounds__(kBlock) void tile_offsets_kernel(
     const uint32_t* __restrict__ n_ptr, uint32_t capacity, const uint32_t* __restrict__ tiles,
     int n_tiles, int32_t* __restrict__ offsets) {
   uint32_t n = min(*n_ptr, capacity);
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (n == 0) {
-    for (uint32_t k = i; k <= (uint32_t)n_tiles; k += gridDim.x * kBlock) offsets[k] = 0;
+    for (uint32_t k = t; k <= (uint32_t)n_tiles; k += gridDim.x * kBlock) offsets[k] = 0;
     return;
   }
-  if (i >= n) return;
-  int cur = (int)tiles[i];
-  int prev = i ? (int)tiles[i - 1] : -1;
-  for (int k = prev + 1; k <= cur; ++k) offsets[k] = (int32_t)i;
-  if (i == n - 1)
-    for (int k = cur + 1; k <= n_tiles; ++k) offsets[k] = (int32_t)n;
+  uint32_t i0 = t * kOffsetsPerThread;
+  if (i0 >= n) return;
+  uint32_t v[kOffsetsPerThread];
+  if (i0 + kOffsetsPerThread <= n) {
+    const uint4 a = *reinterpret_cast<const uint4*>(tiles + i0), b = *reinterpret_cast<const uint4*>(tiles + i0 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < kOffsetsPerThread; ++j) v[j] = i0 + j < n ? tiles[i0 + j] : 0u;
+  }
+  int prev = i0 ? (int)tiles[i0 - 1] : -1;
+#pragma unroll
+  for (int j = 0; j < kOffsetsPerThread; ++j) {
+    const uint32_t i = i0 + j;
+    if (i < n) {
+      const int cur = (int)v[j];
+      for (int k = prev + 1; k <= cur; ++k) offsets[k] = (int32_t)i;
+      prev = cur;
+      if (i == n - 1)
+        for (int k = cur + 1; k <= n_tiles; ++k) offsets[k] = (int32_t)n;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void isect_ids_kernel(
@@ -424,8 +443,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     if (rc) return rc;
   }
   const unsigned gblk = div_up(cap, kBlock);
-  hipLaunchKernelGGL(tile_offsets_kernel, dim3(gblk), dim3(kBlock), 0, s, n_isect, cap, tile_ids,
-                     n_tiles, tile_offsets);
+  hipLaunchKernelGGL(tile_offsets_kernel, dim3(div_up(cap, kBlock * kOffsetsPerThread)), dim3(kBlock), 0,
+                     s, n_isect, cap, tile_ids, n_tiles, tile_offsets);
   if (isect_ids) {
     const int tile_bits_key = bits_for((uint32_t)n_tiles + 1);   // floor(log2(n_tiles)) + 1
     hipLaunchKernelGGL(isect_ids_kernel, dim3(gblk), dim3(kBlock), 0, s, n_isect, cap, tile_ids,
