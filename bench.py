@@ -36,7 +36,7 @@ from robosimgs_amd import ops  # noqa: E402
 from robosimgs_amd.rendering import rasterization  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
-RASTER_PMC_TRAFFIC_BYTES = 265_629_901   # 2 x FETCH_SIZE + WRITE_SIZE of raster_fwd_kernel<3,false>, config 2 (profiles/r1/11)
+RASTER_PMC_TRAFFIC_BYTES = 315_551_744   # 2 x FETCH_SIZE + WRITE_SIZE of raster_fwd_kernel<3,false>, config 2 (profiles/r1/11)
 
 
 def parse():
@@ -257,12 +257,12 @@ def main():
                               # scripts/pmc.sh on this kernel and workload (profiles/r1/11)
                               "traffic": RASTER_PMC_TRAFFIC_BYTES if (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3) else None,
                               "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes: "
-                                                "2 x 116.2 MB (gfx950 counts 128-byte requests at 64 B; calibrated "
-                                                "on this gather pattern) + 33.2 MB per launch (profiles/r1/11_pmc_final.md)",
+                                                "2 x 140.3 MB (gfx950 counts 128-byte requests at 64 B; calibrated "
+                                                "on this gather pattern) + 34.9 MB per launch (profiles/r1/11_pmc_final.md)",
                               "algorithmic_bytes": algo_bytes,
                               "kernel_ms": round(raster_ms, 4),
-                              "valu_busy_frac": 0.90,
-                              "note": "VALU-bound kernel: SQ_ACTIVE_INST_VALU = 90 % of SIMD cycles "
+                              "valu_busy_frac": 0.92,
+                              "note": "VALU-bound kernel: SQ_ACTIVE_INST_VALU = 92 % of SIMD cycles "
                                       "(profiles/r1/11); the HBM fraction is reported as the "
                                       "contract asks; see DESIGN.md 4.3"}
 
