@@ -128,6 +128,7 @@ def main():
     fr = FrameRenderer(t, W, H, render_mode="RGB", frames_in_flight=n_fl, isect_capacity=cap)
     vm_np, K_np = vm[0].cpu().numpy(), K[0].cpu().numpy()
     vm_dev, K_dev = vm[0].contiguous(), K[0].contiguous()
+    cam_dev = FrameRenderer.pack_camera(vm_dev, K_dev)      # one device tensor: one copy per submit
 
     do_gather = use_dist and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
@@ -164,7 +165,7 @@ def main():
     def step(i):
         if len(tickets) == n_fl:
             retire()
-        tickets.append(fr.submit(vm_dev, K_dev))
+        tickets.append(fr.submit(cam_dev))
 
     def drain():
         while tickets:

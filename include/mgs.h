@@ -141,8 +141,9 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * tiles_per_gauss / n_isect then count the tightened lists.  NULL: gsplat's classic lists.
  *
  * Workspace: call with workspace == NULL to get the byte count in *workspace_bytes.
- * tiles_per_gauss[N] nullable.  n_isect, status: device uint32 scalars (status is OR-ed,
- * never cleared, by the library).
+ * tiles_per_gauss[N] nullable.  n_isect, status: device uint32 scalars, both OVERWRITTEN by
+ * every call (status = MGS_STATUS_ISECT_OVERFLOW if n_isect > isect_capacity, else 0): the caller
+ * never has to clear them.
  * pair_info[N,4] (nullable): per Gaussian {slot_base, x0, y0, w | h << 16} of its tile
  * rectangle; the pair (g, tile (tx,ty)) owns slot slot_base + (ty - y0) * w + (tx - x0) in
  * [0, n_isect); slot bases ascend with the Gaussian index.  Consumed by

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
   }
   if (threadIdx.x == 0 && n_isect) {
     *n_isect = running;
-    if (running > capacity) atomicOr(status, MGS_STATUS_ISECT_OVERFLOW);
+    *status = running > capacity ? MGS_STATUS_ISECT_OVERFLOW : 0u;   // this call's result: no zero-fill needed
   }
 }
 
@@ -404,6 +404,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
 
   if (n == 0) {
     (void)hipMemsetAsync(n_isect, 0, 4, s);
+    (void)hipMemsetAsync(status, 0, 4, s);
   } else {
     const unsigned nblk = div_up(n, kBlock);
     hipLaunchKernelGGL(depth_key_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,

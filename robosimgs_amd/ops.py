@@ -109,7 +109,7 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     out = TileLists()
     out.capacity = int(capacity)
     out.n_isect = torch.empty(1, dtype=torch.int32, device=dev)
-    out.status = torch.zeros(1, dtype=torch.int32, device=dev)
+    out.status = torch.empty(1, dtype=torch.int32, device=dev)       # written by every call
     out.tile_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
     out.flatten_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
     out.tile_offsets = torch.empty(tile_w * tile_h + 1, dtype=torch.int32, device=dev)

@@ -70,9 +70,12 @@ class FrameRenderer:
 
     def _capture_slot(self) -> Dict:
         stream = torch.cuda.Stream(self.dev)
-        vm = torch.eye(4, device=self.dev).reshape(1, 4, 4).contiguous()
+        # the slot's camera: one 25-float device buffer (viewmat | K), so a submit is ONE small copy
+        cam = torch.zeros(32, device=self.dev)
+        vm, K = cam[:16].view(1, 4, 4), cam[16:25].view(1, 3, 3)
+        vm.copy_(torch.eye(4, device=self.dev).reshape(1, 4, 4))
         vm[0, 2, 3] = -1e3                                 # warm-up camera: everything is behind it, nothing to bin
-        K = torch.tensor([[[1.0, 0, 0.5], [0, 1.0, 0.5], [0, 0, 1]]], device=self.dev)
+        K.copy_(torch.tensor([[[1.0, 0, 0.5], [0, 1.0, 0.5], [0, 0, 1]]], device=self.dev))
         with torch.cuda.stream(stream):
             for _ in range(2):
                 self._raster(vm, K, self.capacity)
@@ -81,13 +84,22 @@ class FrameRenderer:
             with torch.cuda.graph(graph, stream=stream):
                 colors, alphas, meta = self._raster(vm, K, self.capacity)
         torch.cuda.synchronize(self.dev)
-        return {"stream": stream, "vm": vm, "K": K, "graph": graph, "colors": colors,
+        return {"stream": stream, "vm": vm, "K": K, "cam": cam, "graph": graph, "colors": colors,
                 "alphas": alphas, "meta": meta, "done": torch.cuda.Event(),
                 "released": torch.cuda.Event(), "state": "free"}
 
     # -- API ---------------------------------------------------------------------------
-    def submit(self, viewmat, K) -> int:
-        """Enqueue one frame (viewmat: OpenCV world-to-camera 4x4, K: 3x3; numpy or tensors).
+    @staticmethod
+    def pack_camera(viewmat, K, device=None) -> torch.Tensor:
+        """(viewmat | K) as one 25-float tensor; submit(packed, None) then uploads it with a single copy."""
+        v = torch.as_tensor(np.asarray(viewmat, dtype=np.float32) if not torch.is_tensor(viewmat) else viewmat)
+        k = torch.as_tensor(np.asarray(K, dtype=np.float32) if not torch.is_tensor(K) else K)
+        out = torch.cat([v.reshape(16).float(), k.reshape(9).float()])
+        return out.to(device) if device is not None else out
+
+    def submit(self, viewmat, K=None) -> int:
+        """Enqueue one frame (viewmat: OpenCV world-to-camera 4x4, K: 3x3; numpy or tensors; or
+        viewmat = pack_camera(viewmat, K) and K = None).
         Returns a ticket for fetch().  Slots are used round-robin: the slot's previous frame
         must have been fetched and released."""
         slot = self._next
@@ -96,13 +108,19 @@ class FrameRenderer:
             raise RuntimeError(f"slot {slot} still holds a frame that was not released "
                                f"({self.n_slots} frames in flight at most)")
         self._next = (slot + 1) % self.n_slots
-        vm_src = viewmat if torch.is_tensor(viewmat) else torch.as_tensor(
-            np.ascontiguousarray(viewmat, dtype=np.float32))
-        K_src = K if torch.is_tensor(K) else torch.as_tensor(np.ascontiguousarray(K, dtype=np.float32))
+        packed = None
+        if torch.is_tensor(viewmat) and K is None:
+            packed = viewmat.reshape(-1)               # pack_camera(): (viewmat | K) already on one tensor
+        elif not torch.is_tensor(viewmat) and not torch.is_tensor(K):
+            packed = torch.from_numpy(np.concatenate([np.asarray(viewmat, dtype=np.float32).reshape(16),
+                                                      np.asarray(K, dtype=np.float32).reshape(9)]))
         with torch.cuda.stream(s["stream"]):
             s["stream"].wait_event(s["released"])      # the previous consumer's reads are done
-            s["vm"].copy_(vm_src.reshape(1, 4, 4), non_blocking=True)
-            s["K"].copy_(K_src.reshape(1, 3, 3), non_blocking=True)
+            if packed is not None:
+                s["cam"][:25].copy_(packed, non_blocking=True)
+            else:
+                s["vm"].copy_(torch.as_tensor(viewmat).reshape(1, 4, 4), non_blocking=True)
+                s["K"].copy_(torch.as_tensor(K).reshape(1, 3, 3), non_blocking=True)
             s["graph"].replay()
             s["done"].record(s["stream"])
         s["state"] = "submitted"
