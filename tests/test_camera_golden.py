@@ -100,3 +100,17 @@ def test_look_at_matches_reference_recipe():
     R = cam.c2w[:3, :3]
     np.testing.assert_allclose(R.T @ R, np.eye(3), atol=1e-12)
     assert np.linalg.det(R) > 0
+
+
+def test_frame_renderer_pack_camera_layout():
+    """(viewmat | K) as one 25-float tensor: the layout FrameRenderer.submit uploads in one copy."""
+    import torch
+    from robosimgs_amd import camera_ring
+    from robosimgs_amd.pipeline import FrameRenderer
+    cam = camera_ring(1, 320, 200, thetas=[0.7])[0]
+    p = FrameRenderer.pack_camera(cam.viewmat(), cam.K)
+    assert p.dtype == torch.float32 and p.shape == (25,)
+    np.testing.assert_allclose(p[:16].reshape(4, 4).numpy(), cam.viewmat().astype(np.float32))
+    np.testing.assert_allclose(p[16:].reshape(3, 3).numpy(), cam.K.astype(np.float32))
+    q = FrameRenderer.pack_camera(torch.from_numpy(cam.viewmat()), torch.from_numpy(cam.K))
+    assert torch.equal(p, q)
