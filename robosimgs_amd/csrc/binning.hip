@@ -77,16 +77,23 @@ __device__ __forceinline__ TileRect tighten_rect(TileRect r, float mx, float my,
   return r;
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
 __global__ __launch_bounds__(kBlock) void depth_key_kernel(
     int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float* __restrict__ depths, const float* __restrict__ conics,
     const float* __restrict__ opacities, float tile_size, int tile_w, int tile_h,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ ginfo,
-    int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ n_gauss_dev) {
+    int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ n_gauss_dev,
+    uint32_t* __restrict__ index_blocksums) {
+  __shared__ uint32_t ws[kBlock / 64];
   int g = blockIdx.x * kBlock + threadIdx.x;
   if (g == 0) *n_gauss_dev = (uint32_t)n;
-  if (g >= n) return;
-  int radius = radii[g];
+  int radius = g < n ? radii[g] : 0;
   uint32_t key = 0xffffffffu, cnt = 0, pack = 1u << 20;
   if (radius > 0) {
     float2 m = reinterpret_cast<const float2*>(means2d)[g];
@@ -98,16 +105,23 @@ __global__ __launch_bounds__(kBlock) void depth_key_kernel(
     pack = (uint32_t)r.x0 | ((uint32_t)r.y0 << 10) | ((uint32_t)max(r.w, 1) << 20);
     key = __float_as_uint(depths[g]);
   }
-  keys[g] = key;
-  vals[g] = (uint32_t)g;
-  ginfo[g] = make_uint2(pack, cnt);       // tile rectangle (x0 | y0 << 10 | w << 20) and tile count
-  if (tiles_per_gauss) tiles_per_gauss[g] = (int32_t)cnt;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  if (g < n) {
+    keys[g] = key;
+    vals[g] = (uint32_t)g;
+    ginfo[g] = make_uint2(pack, cnt);     // tile rectangle (x0 | y0 << 10 | w << 20) and tile count
+    if (tiles_per_gauss) tiles_per_gauss[g] = (int32_t)cnt;
+  }
+  if (index_blocksums) {   // training: tile counts per block in INDEX order (slot bases of pair_info)
+    const uint32_t c = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t sum = 0;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-  return v;
+      for (int w = 0; w < kBlock / 64; ++w) sum += ws[w];
+      index_blocksums[blockIdx.x] = sum;
+    }
+  }
 }
 
 // sum of tile counts of the 256 depth-ranks owned by each workgroup.  With sorted_ids the
@@ -410,7 +424,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     hipLaunchKernelGGL(depth_key_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,
                        depths, conics, opacities, (float)tile_size, tile_w, tile_h, u32(ws.keys_a),
                        u32(ws.vals_a),
-                       reinterpret_cast<uint2*>(w + ws.ginfo), tiles_per_gauss, n_gauss_dev);
+                       reinterpret_cast<uint2*>(w + ws.ginfo), tiles_per_gauss, n_gauss_dev,
+                       pair_info ? u32(ws.blocksums2) : (uint32_t*)nullptr);
     // 4 passes (even): the depth order ends in (keys_a, vals_a)
     rc = radix_sort_pairs(n_gauss_dev, (uint32_t)n, 32, u32(ws.keys_a), u32(ws.vals_a),
                           u32(ws.keys_b), u32(ws.vals_b), w + ws.radix, s);
@@ -430,10 +445,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a),
                        reinterpret_cast<const uint2*>(w + ws.rank_info), tile_w, u32(ws.blocksums), cap,
                        a_t, a_i);
-    if (pair_info) {   // training only: index-major slot bases (three small kernels)
-      hipLaunchKernelGGL(rank_blocksum_kernel, dim3(nblk), dim3(kBlock), 0, s, n,
-                         (const uint32_t*)nullptr, reinterpret_cast<const uint2*>(w + ws.ginfo),
-                         (uint2*)nullptr, u32(ws.blocksums2));
+    if (pair_info) {   // training only: index-major slot bases (block sums come from depth_key_kernel)
       hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
                          u32(ws.blocksums2), cap, (uint32_t*)nullptr, (uint32_t*)nullptr);
       hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n,
