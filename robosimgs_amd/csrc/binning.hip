@@ -151,16 +151,22 @@ __global__ __launch_bounds__(kBlock) void rank_blocksum_kernel(
 
 // single workgroup: exclusive scan of the block sums in place; publishes n_isect / overflow
 constexpr int kScanThreads = 1024;
+constexpr int kScanPerThread = 8;     // consecutive block sums per thread: 8192 per trip, one trip at 1 M Gaussians
 __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
     uint32_t nblk, uint32_t* __restrict__ blocksums, uint32_t capacity,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
   __shared__ uint32_t ws[kScanThreads / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t running = 0;
-  for (uint32_t b0 = 0; b0 < nblk; b0 += kScanThreads) {
-    uint32_t b = b0 + threadIdx.x;
-    uint32_t v = b < nblk ? blocksums[b] : 0u;
-    uint32_t incl = v;
+  for (uint32_t b0 = 0; b0 < nblk; b0 += kScanThreads * kScanPerThread) {
+    const uint32_t b = b0 + threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) {
+      v[j] = b + j < nblk ? blocksums[b + j] : 0u;
+      sum += v[j];
+    }
+    uint32_t incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       uint32_t t = __shfl_up(incl, d);
@@ -174,7 +180,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
       tot += ws[w];
     }
     __syncthreads();
-    if (b < nblk) blocksums[b] = running + off + incl - v;
+    uint32_t ex = running + off + incl - sum;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) {
+      if (b + j < nblk) blocksums[b + j] = ex;
+      ex += v[j];
+    }
     running += tot;
   }
   if (threadIdx.x == 0 && n_isect) {
