@@ -346,3 +346,31 @@ def test_camera_pose_gradient_matches_autograd(deg, mode):
         ref = rv.grad.numpy()[:3]
         got = vm.grad[c, :3].cpu().double().numpy()
         assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), (c, got, ref)
+
+
+@pytest.mark.parametrize("ch", [5, 12, 20, 32])
+def test_deterministic_backward_many_channels(ch):
+    """Record-based backward with more than 4 feature channels (several 8-value LDS reduction
+    rounds plus a DPP remainder per record) against the atomic backward."""
+    from robosimgs_amd import ops
+    g, cam = _scene(4000, 0.1, 0, 112, 80)
+    t = g.to_torch(DEV, 0)
+    vm, K = _t(cam.viewmat()), _t(cam.K)
+    radii, m2d, dep, con, _ = ops.projection_fwd_raw(t["means"], t["quats"], t["scales"], vm, K, 112, 80,
+                                                     0.3, 0.01, 1e10, 0.0, False)
+    tw, th = 7, 5
+    tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 300_000, want_pair_info=True)
+    gen = torch.Generator(DEV).manual_seed(ch)
+    feats = torch.rand(len(g), ch, device=DEV, generator=gen)
+    bg = torch.rand(ch, device=DEV, generator=gen)
+    out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], bg, 112, 80, tw, th, tl.tile_offsets,
+                                tl.flatten_ids)
+    vr = torch.randn(80, 112, ch, device=DEV, generator=gen)
+    va = torch.randn(80, 112, device=DEV, generator=gen)
+    a = ops.rasterize_bwd_raw(m2d, con, feats, t["opacities"], bg, 112, 80, tw, th, tl.tile_offsets,
+                              tl.flatten_ids, out[1], out[2], vr, va, absgrad=True)
+    d = ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], bg, 112, 80, tw, th, tl, out[1], out[2],
+                                  vr, va, absgrad=True)
+    for x, y in zip(a, d):
+        scale = float(x.abs().max()) + 1e-20
+        assert float((x - y).abs().max()) / scale < 1e-4
