@@ -365,6 +365,10 @@ def test_deterministic_backward_many_channels(ch):
     bg = torch.rand(ch, device=DEV, generator=gen)
     out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], bg, 112, 80, tw, th, tl.tile_offsets,
                                 tl.flatten_ids)
+    # the inference variant (no last_ids, four tiles per workgroup) renders the same bits
+    inf = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], bg, 112, 80, tw, th, tl.tile_offsets,
+                                tl.flatten_ids, track_last=False)
+    assert inf[2] is None and torch.equal(inf[0], out[0]) and torch.equal(inf[1], out[1])
     vr = torch.randn(80, 112, ch, device=DEV, generator=gen)
     va = torch.randn(80, 112, device=DEV, generator=gen)
     a = ops.rasterize_bwd_raw(m2d, con, feats, t["opacities"], bg, 112, 80, tw, th, tl.tile_offsets,
