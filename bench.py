@@ -267,6 +267,26 @@ def main():
                                       "(profiles/r1/11); the HBM fraction is reported as the "
                                       "contract asks; see DESIGN.md 4.3"}
 
+        # the second-largest forward kernel is HBM-bound: projection + SH colour (SURVEY.md 8(d):
+        # N*236 + n_vis*48 algorithmic bytes), timed the same way
+        for _ in range(5):
+            ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"],
+                                      vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
+        e0.record()
+        for _ in range(reps):
+            ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"],
+                                      vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
+        e1.record()
+        torch.cuda.synchronize()
+        proj_ms = e0.elapsed_time(e1) / reps
+        proj_bytes = a.n * (44 + 12 * (deg + 1) ** 2) + n_vis * 48
+        result["roofline_projection"] = {
+            "kernel": f"project_color_fwd_kernel<{deg}, {'true' if deg >= 2 else 'false'}>", "bound": "hbm",
+            "achieved": round(proj_bytes / (proj_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes": proj_bytes, "kernel_ms": round(proj_ms, 4),
+            "note": "also writes the 48-byte splat records (n_vis * 48 more bytes, not counted)"}
+
         # ---- training-step variant (configs[2]): forward + L1 + backward ------------------
         try:
             result["fwd_bwd"] = bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev)
