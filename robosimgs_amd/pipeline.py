@@ -139,6 +139,8 @@ class FrameRenderer:
         s["state"] = "fetched"
         if check and bool((s["meta"]["isect_status"] != 0).any().item()):
             need = int(s["meta"]["n_isects"].max().item())
+            s["released"].record(torch.cuda.current_stream(self.dev))   # the slot is usable again
+            s["state"] = "free"
             raise _lib.MgsError(f"frame needs {need} tile intersections, capacity is "
                                 f"{self.capacity}: build the FrameRenderer with a larger "
                                 "isect_capacity / capacity_margin")

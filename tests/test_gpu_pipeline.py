@@ -59,3 +59,25 @@ def test_render_sharded_single_rank_with_and_without_renderer():
     r = FrameRenderer(t, 192, 128, frames_in_flight=2, sizing_camera=(cams[0].viewmat(), cams[0].K))
     b, ba, _ = render_sharded(t, vm, Ks, 192, 128, renderer=r)
     assert torch.equal(a, b) and torch.equal(aa, ba)
+
+
+def test_overflow_is_per_frame_and_packed_camera_submit():
+    """The binning overwrites its status word every frame: a frame that overflows the slot's
+    capacity raises, the next frame that fits renders normally.  A packed (viewmat | K) device
+    tensor submits with a single copy and renders the same bits."""
+    from robosimgs_amd import FrameRenderer, _lib
+    g = synthetic_scene(30_000, math.log(0.05), 1, 4)
+    t = g.to_torch(DEV, 1)
+    near, far = camera_ring(2, 256, 160, radius=6.0)[0], camera_ring(2, 256, 160, radius=60.0)[0]
+    r_far = FrameRenderer(t, 256, 160, frames_in_flight=1, sizing_camera=(far.viewmat(), far.K),
+                          capacity_margin=1.05)
+    ok = r_far.render(far.viewmat(), far.K)
+    with pytest.raises(_lib.MgsError, match="capacity"):
+        r_far.render(near.viewmat(), near.K)               # the close-up needs far more tile pairs
+    again = r_far.render(far.viewmat(), far.K)
+    assert torch.equal(again["colors"], ok["colors"]) and torch.equal(again["alphas"], ok["alphas"])
+    packed = FrameRenderer.pack_camera(far.viewmat(), far.K, device=DEV)
+    tk = r_far.submit(packed)
+    f = r_far.fetch(tk)
+    assert torch.equal(f["colors"], ok["colors"])
+    r_far.release(tk)
