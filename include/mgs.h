@@ -289,6 +289,22 @@ int mgs_l1_loss_fwd(size_t n, const float *a, const float *b, float *loss, void 
 int mgs_l1_loss_bwd(size_t n, const float *a, const float *b, const float *v_loss, float *v_a,
                     mgs_stream_t stream);
 
+/* -------------------------------------------------------------------------------------
+ * Similarity transforms of Gaussian groups (world-frame alignment,
+ * /root/reference/README.md:54-55; per frame: Gaussians riding on articulated parts).
+ * group_ids[N] (nullable = all in group 0; -1 = leave unchanged) selects one of n_groups rows of
+ *   xforms[n_groups,20] = { M[9] = s R row-major, t[3], q_R[4] (wxyz), s, pad[3] }:
+ *   means' = M p + t, quats' = q_R (x) q, scales' = s scales.
+ * sh_coeffs / out_sh [N,coeff_stride,3] (nullable pair): degree-l coefficients are multiplied by the
+ *   (2l+1)x(2l+1) real-SH rotation matrix of R, sh_rot[n_groups,84] = {3x3, 5x5, 7x7, pad}
+ *   row-major (needed for sh_degree >= 1).  out_* may alias the inputs (in place).
+ * ----------------------------------------------------------------------------------- */
+int mgs_transform_gaussians(int n, const float *means, const float *quats, const float *scales,
+                            int sh_degree, int coeff_stride, const float *sh_coeffs,
+                            const int32_t *group_ids, int n_groups, const float *xforms,
+                            const float *sh_rot, float *out_means, float *out_quats,
+                            float *out_scales, float *out_sh, mgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

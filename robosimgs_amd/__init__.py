@@ -29,6 +29,9 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
     if name == "composite_over":
         from . import compositing
         return compositing.composite_over
+    if name == "transform_gaussians":
+        from . import transform
+        return transform.transform_gaussians
     if name == "l1_loss":
         from . import losses
         return losses.l1_loss

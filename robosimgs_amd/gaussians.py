@@ -269,23 +269,32 @@ def _sh_basis_np(degree: int, dirs: np.ndarray) -> np.ndarray:
     return np.stack(Y, axis=-1)
 
 
+_SH_FIT_CACHE: dict = {}
+
+
+def _sh_fit_basis(degree: int):
+    """Fixed sample directions and, per band, the pseudo-inverse of the basis evaluated there
+    (they do not depend on the rotation, so a fit is two small matrix products)."""
+    hit = _SH_FIT_CACHE.get(degree)
+    if hit is None:
+        rng = np.random.default_rng(12345)
+        d = rng.normal(size=(64, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        Y_new = _sh_basis_np(degree, d)               # basis at the new-frame directions
+        pinv = [np.linalg.pinv(Y_new[:, l * l:(l + 1) * (l + 1)]) for l in range(degree + 1)]
+        hit = _SH_FIT_CACHE[degree] = (d, pinv)
+    return hit
+
+
 def sh_rotation_matrices(R: np.ndarray, degree: int):
     """Per-degree matrices M_l with  c'_l = M_l c_l  such that
     sum_k Y_k(d) c'_k == sum_k Y_k(R^T d) c_k  for every direction d (the colour field rotated
     by R).  Each degree-l band is invariant under rotation, so M_l is found exactly by a
     least-squares fit on a fixed set of sample directions."""
-    rng = np.random.default_rng(12345)
-    d = rng.normal(size=(64, 3))
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    Y_new = _sh_basis_np(degree, d)               # basis at the new-frame directions
-    Y_old = _sh_basis_np(degree, d @ R)           # rows are (R^T d)^T
-    out = []
-    for l in range(degree + 1):
-        lo, hi = l * l, (l + 1) * (l + 1)
-        # Y_new[:, band] @ M = Y_old[:, band]  ->  c' = M c
-        M, *_ = np.linalg.lstsq(Y_new[:, lo:hi], Y_old[:, lo:hi], rcond=None)
-        out.append(M)
-    return out
+    d, pinv = _sh_fit_basis(degree)
+    Y_old = _sh_basis_np(degree, d @ np.asarray(R, dtype=np.float64))   # rows are (R^T d)^T
+    # Y_new[:, band] @ M = Y_old[:, band]  ->  c' = M c
+    return [pinv[l] @ Y_old[:, l * l:(l + 1) * (l + 1)] for l in range(degree + 1)]
 
 
 def _rotmat_to_quat(R: np.ndarray) -> np.ndarray:

@@ -118,3 +118,25 @@ def test_rotating_the_scene_rotates_the_sh_colour_field():
     assert np.abs(a).max() > 0.5
     np.testing.assert_allclose(b, a, atol=5e-4)
     np.testing.assert_allclose(ba, aa, atol=5e-4)
+
+
+def test_pack_transforms_layout_and_validation():
+    """Host packing for mgs_transform_gaussians: {sR | t | q_R | s} and the per-degree SH matrices."""
+    import pytest
+    from robosimgs_amd.transform import pack_transforms
+    from robosimgs_amd.gaussians import sh_rotation_matrices
+    c, s = np.cos(0.4), np.sin(0.4)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    x, rot = pack_transforms([np.eye(3), R], [[0, 0, 0], [1, 2, 3]], [1.0, 2.0], sh_degree=3)
+    assert x.shape == (2, 20) and rot.shape == (2, 84) and x.dtype == np.float32
+    np.testing.assert_allclose(x[1, :9].reshape(3, 3), 2.0 * R, atol=1e-6)
+    np.testing.assert_allclose(x[1, 9:12], [1, 2, 3])
+    np.testing.assert_allclose(x[1, 12:16], [np.cos(0.2), 0, 0, np.sin(0.2)], atol=1e-6)   # wxyz about z
+    assert x[1, 16] == 2.0
+    Ms = sh_rotation_matrices(R, 3)
+    np.testing.assert_allclose(rot[1, :9].reshape(3, 3), Ms[1], atol=1e-6)
+    np.testing.assert_allclose(rot[1, 9:34].reshape(5, 5), Ms[2], atol=1e-6)
+    np.testing.assert_allclose(rot[1, 34:83].reshape(7, 7), Ms[3], atol=1e-6)
+    np.testing.assert_allclose(rot[0, :9].reshape(3, 3), np.eye(3), atol=1e-6)
+    with pytest.raises(ValueError):
+        pack_transforms([2.0 * np.eye(3)], [[0, 0, 0]])          # scale belongs in `scales`
