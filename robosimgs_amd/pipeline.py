@@ -32,12 +32,24 @@ class FrameRenderer:
     def __init__(self, tensors: Dict, width: int, height: int, render_mode: str = "RGB",
                  frames_in_flight: int = 3, isect_capacity: Optional[int] = None,
                  capacity_margin: float = 1.5, background: Optional[torch.Tensor] = None,
-                 sizing_camera=None, **raster_kw):
+                 sizing_camera=None, group_ids: Optional[torch.Tensor] = None, n_groups: int = 0,
+                 rotate_sh: bool = True, **raster_kw):
         """tensors: dict(means, quats, scales, opacities, colors, sh_degree) on the GPU
         (Gaussians.to_torch()).  isect_capacity: slots reserved for tile intersections per
         frame; if None it is measured once with `sizing_camera` = (viewmat, K) (required then)
-        and multiplied by `capacity_margin`.  A frame that needs more raises on fetch()."""
+        and multiplied by `capacity_margin`.  A frame that needs more raises on fetch().
+
+        Dynamic scenes (articulated parts, a moving robot): give group_ids (int32 [N] on the GPU,
+        -1 = static) and n_groups; submit(..., rotations=, translations=[, scales=]) then poses
+        the groups for that frame.  Every slot owns a posed copy of the Gaussians and its graph
+        starts with mgs_transform_gaussians(rest pose -> copy) reading the slot's transform buffer,
+        so a posed frame costs one small upload and 14-97 us of GPU time more than a static one."""
         self.t = tensors
+        self.group_ids = group_ids.to(torch.int32).contiguous() if group_ids is not None else None
+        self.n_groups = int(n_groups)
+        self.rotate_sh = bool(rotate_sh) and int(tensors.get("sh_degree") or 0) >= 1
+        if self.group_ids is not None and self.n_groups < 1:
+            raise ValueError("group_ids needs n_groups >= 1")
         self.dev = tensors["means"].device
         self.width, self.height, self.mode = int(width), int(height), render_mode
         self.kw = dict(raster_kw)
@@ -61,8 +73,8 @@ class FrameRenderer:
         Kt = torch.as_tensor(np.asarray(K, dtype=np.float32)).reshape(1, 3, 3).to(self.dev)
         return vm, Kt
 
-    def _raster(self, vm, K, cap):
-        t = self.t
+    def _raster(self, vm, K, cap, t=None):
+        t = self.t if t is None else t
         return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm,
                              K, self.width, self.height, sh_degree=t.get("sh_degree"),
                              render_mode=self.mode, backgrounds=self.bg, isect_capacity=cap,
@@ -76,15 +88,33 @@ class FrameRenderer:
         vm.copy_(torch.eye(4, device=self.dev).reshape(1, 4, 4))
         vm[0, 2, 3] = -1e3                                 # warm-up camera: everything is behind it, nothing to bin
         K.copy_(torch.tensor([[[1.0, 0, 0.5], [0, 1.0, 0.5], [0, 0, 1]]], device=self.dev))
+        pose = None
+        if self.group_ids is not None:       # dynamic scene: this slot's transforms and posed copy
+            from .transform import pack_transforms
+            eye = np.tile(np.eye(3), (self.n_groups, 1, 1))
+            x0, r0 = pack_transforms(eye, np.zeros((self.n_groups, 3)), None, 3 if self.rotate_sh else 0)
+            pose = {"x": torch.from_numpy(x0).to(self.dev),
+                    "r": torch.from_numpy(r0).to(self.dev) if r0 is not None else None,
+                    "t": {k: (v.clone() if torch.is_tensor(v) and k in ("means", "quats", "scales", "colors") else v)
+                          for k, v in self.t.items()}}
+
+        def body():
+            if pose is None:
+                return self._raster(vm, K, self.capacity)
+            from .transform import transform_gaussians
+            posed = transform_gaussians(self.t, group_ids=self.group_ids, rotate_sh=self.rotate_sh,
+                                        out=pose["t"], packed=(pose["x"], pose["r"]))
+            return self._raster(vm, K, self.capacity, posed)
+
         with torch.cuda.stream(stream):
             for _ in range(2):
-                self._raster(vm, K, self.capacity)
+                body()
             torch.cuda.synchronize(self.dev)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                colors, alphas, meta = self._raster(vm, K, self.capacity)
+                colors, alphas, meta = body()
         torch.cuda.synchronize(self.dev)
-        return {"stream": stream, "vm": vm, "K": K, "cam": cam, "graph": graph, "colors": colors,
+        return {"stream": stream, "vm": vm, "K": K, "cam": cam, "pose": pose, "graph": graph, "colors": colors,
                 "alphas": alphas, "meta": meta, "done": torch.cuda.Event(),
                 "released": torch.cuda.Event(), "state": "free"}
 
@@ -97,9 +127,11 @@ class FrameRenderer:
         out = torch.cat([v.reshape(16).float(), k.reshape(9).float()])
         return out.to(device) if device is not None else out
 
-    def submit(self, viewmat, K=None) -> int:
+    def submit(self, viewmat, K=None, rotations=None, translations=None, scales=None) -> int:
         """Enqueue one frame (viewmat: OpenCV world-to-camera 4x4, K: 3x3; numpy or tensors; or
-        viewmat = pack_camera(viewmat, K) and K = None).
+        viewmat = pack_camera(viewmat, K) and K = None).  Dynamic scenes: rotations [G,3,3],
+        translations [G,3] (and uniform scales [G]) pose the groups for this frame; omitted, the
+        slot keeps the pose of its previous frame (the rest pose at first).
         Returns a ticket for fetch().  Slots are used round-robin: the slot's previous frame
         must have been fetched and released."""
         slot = self._next
@@ -121,6 +153,16 @@ class FrameRenderer:
             else:
                 s["vm"].copy_(torch.as_tensor(viewmat).reshape(1, 4, 4), non_blocking=True)
                 s["K"].copy_(torch.as_tensor(K).reshape(1, 3, 3), non_blocking=True)
+            if rotations is not None:
+                if s["pose"] is None:
+                    raise ValueError("this FrameRenderer was built without group_ids: the scene is static")
+                from .transform import pack_transforms
+                x, r = pack_transforms(rotations, translations, scales, 3 if self.rotate_sh else 0)
+                if x.shape[0] != self.n_groups:
+                    raise ValueError(f"{x.shape[0]} transforms for {self.n_groups} groups")
+                s["pose"]["x"].copy_(torch.from_numpy(x), non_blocking=True)
+                if r is not None:
+                    s["pose"]["r"].copy_(torch.from_numpy(r), non_blocking=True)
             s["graph"].replay()
             s["done"].record(s["stream"])
         s["state"] = "submitted"
