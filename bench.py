@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--bwd-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-dtype", choices=("fp32", "u8"), default="fp32",
+                    help="N > 1: gather fp32 renders (default) or 8-bit images (frame_to_u8, 4x fewer bytes)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent frames in flight, one HIP stream + one HIP graph each")
@@ -123,7 +125,7 @@ def main():
     # on their own streams: the latency-bound binning kernels of one frame run under the
     # VALU-bound raster of another.  Every step submits one whole frame (projection + binning +
     # raster) and the timed region ends with a full sync.
-    from robosimgs_amd import FrameRenderer
+    from robosimgs_amd import FrameRenderer, frame_to_u8
     n_fl = max(1, a.inflight)
     fr = FrameRenderer(t, W, H, render_mode="RGB", frames_in_flight=n_fl, isect_capacity=cap)
     vm_np, K_np = vm[0].cpu().numpy(), K[0].cpu().numpy()
@@ -133,12 +135,15 @@ def main():
     do_gather = use_dist and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
     frame_shape = (H, W, 3)
+    g_u8 = a.gather_dtype == "u8"
+    g_dtype = torch.uint8 if g_u8 else torch.float32
     gather_bufs = None
     if do_gather and rank == 0:
-        gather_bufs = [[torch.empty(frame_shape, device=comm_dev) for _ in range(world)]
+        gather_bufs = [[torch.empty(frame_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
                        for _ in range(n_fl)]
+    u8_bufs = [torch.empty(frame_shape, device=dev, dtype=torch.uint8) for _ in range(n_fl)] if (do_gather and g_u8) else None
     # host-staged copies only for the gloo debugging mode; RCCL sends straight from the slot
-    send_bufs = ([torch.empty(frame_shape, device=comm_dev) for _ in range(n_fl)]
+    send_bufs = ([torch.empty(frame_shape, device=comm_dev, dtype=g_dtype) for _ in range(n_fl)]
                  if do_gather and debug_gloo else None)
     pending = [None] * n_fl
     tickets = []
@@ -150,14 +155,17 @@ def main():
         `inflight` slots gives each gather inflight - 1 frame times to complete."""
         tk = tickets.pop(0)
         f = fr.fetch(tk, check=False)
+        payload = f["colors"]
+        if do_gather and g_u8:                     # quantise on the device, inside the timed region
+            payload = frame_to_u8(f["colors"], f["alphas"], out=u8_bufs[tk].view(-1, 3))
         if do_gather and debug_gloo:
             if pending[tk] is not None:            # this slot's previous collective has drained
                 pending[tk].wait()
-            send_bufs[tk].copy_(f["colors"], non_blocking=True)
+            send_bufs[tk].copy_(payload, non_blocking=True)
             pending[tk] = dist.gather(send_bufs[tk], gather_bufs[tk] if rank == 0 else None,
                                       dst=0, async_op=True)
         elif do_gather:
-            work = dist.gather(f["colors"], gather_bufs[tk] if rank == 0 else None, dst=0,
+            work = dist.gather(payload, gather_bufs[tk] if rank == 0 else None, dst=0,
                                async_op=True)
             work.wait()                            # current STREAM waits for the collective
         fr.release(tk)
@@ -202,7 +210,7 @@ def main():
     if do_gather and rank == 0:
         # the collective really delivered every rank's frame (all cameras see the scene)
         for r_ in range(world):
-            assert float(gather_bufs[0][r_].abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
+            assert float(gather_bufs[0][r_].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
     status = max(int(o[2]["isect_status"].max().item()) for o in outs)
     assert status == 0, "tile-intersection capacity overflow inside the timed region"
     frames_per_s = world * a.steps / elapsed
@@ -218,7 +226,7 @@ def main():
                    "n_gaussians": a.n, "n_visible": n_vis, "n_isect": n_isect,
                    "n_isect_binned": n_isect_binned,
                    "tiles": tile_w * tile_h, "cameras_per_step": world,
-                   "gather": "fp32 RGB frames to rank 0 (RCCL)" if do_gather else "none",
+                   "gather": (("8-bit RGB images" if g_u8 else "fp32 RGB frames") + " to rank 0 (RCCL)") if do_gather else "none",
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
                              "frames in flight on separate HIP streams",
                    "frames_in_flight": n_fl, "single_frame_latency_ms": round(latency_ms, 4)},

@@ -247,6 +247,13 @@ int mgs_composite_over(int n_px, const float *bg_rgb, const float *bg_alpha,
                        const uint8_t *fg_mask, const float *backdrop, float *out_rgb,
                        float *out_depth, mgs_stream_t stream);
 
+/* 8-bit frame for the dataset writer / the multi-GPU gather: out[P,3] = round(255 *
+ * clamp(rgb + (1 - alpha) * background, 0, 1)) -- splatfacto's post-processing
+ * and the quantisation of an image file.  rgb[P,rgb_stride] (first three channels are used, so
+ * an RGB+ED render can be passed as is), alpha[P], background[3] nullable (black). */
+int mgs_frame_to_u8(int n_px, const float *rgb, int rgb_stride, const float *alpha,
+                    const float *background, uint8_t *out, mgs_stream_t stream);
+
 /* -------------------------------------------------------------------------------------
  * Point-cloud z-buffer helpers: the reference's
  * Articulation/utils/point_utils.py, one entry point per function.

@@ -26,9 +26,9 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
                 "isect_offset_encode", "rasterize_to_pixels"):
         from . import ops
         return getattr(ops, name)
-    if name == "composite_over":
+    if name in ("composite_over", "frame_to_u8"):
         from . import compositing
-        return compositing.composite_over
+        return getattr(compositing, name)
     if name == "transform_gaussians":
         from . import transform
         return transform.transform_gaussians

@@ -36,3 +36,23 @@ def composite_over(bg_rgb: torch.Tensor, bg_alpha: torch.Tensor, bg_depth: torch
                                         ptr(mask), ptr(bd), ptr(out_rgb), ptr(out_depth),
                                         stream_handle()), "mgs_composite_over")
     return out_rgb.reshape(*lead, 3), out_depth.reshape(*lead)
+
+
+def frame_to_u8(colors: torch.Tensor, alphas: torch.Tensor,
+                background: Optional[Sequence[float]] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """colors [...,D>=3] (the first three channels are RGB, so an "RGB+ED" render works as is),
+    alphas [...,1] or [...] -> uint8 [...,3] = round(255 * clamp(rgb + (1 - alpha) * bg, 0, 1)):
+    the image a dataset writer stores, a quarter of the bytes to gather or download."""
+    require_device(colors, alphas)
+    lead = colors.shape[:-1]
+    n_px = int(torch.Size(lead).numel())
+    c = _f32c(colors).reshape(n_px, colors.shape[-1])
+    a = _f32c(alphas).reshape(n_px)
+    bg = (torch.tensor(list(background), dtype=torch.float32, device=colors.device)
+          if background is not None else None)
+    if out is None:
+        out = torch.empty(n_px, 3, dtype=torch.uint8, device=colors.device)
+    check(_lib.lib().mgs_frame_to_u8(n_px, ptr(c), c.shape[1], ptr(a), ptr(bg), ptr(out), stream_handle()),
+          "mgs_frame_to_u8")
+    return out.reshape(*lead, 3)

@@ -62,3 +62,39 @@ extern "C" int mgs_composite_over(int n_px, const float* bg_rgb, const float* bg
                      bg_alpha, bg_depth, fg_rgb, fg_depth, fg_mask, backdrop, out_rgb, out_depth);
   return check_launch("composite_over");
 }
+
+// ---- 8-bit frames for the dataset writer / the multi-GPU gather -----------------------------
+// out = round(255 * clamp(rgb + (1 - alpha) * background, 0, 1)): splatfacto's post-processing
+//  followed by the quantisation every image file format applies anyway; a quarter
+// of the bytes to gather over xGMI or to copy to the host.  HBM-bound: 16 B read, 3 B written.
+namespace mgs {
+namespace {
+__global__ __launch_bounds__(256) void frame_to_u8_kernel(int n_px, const float* __restrict__ rgb,
+                                                          int rgb_stride, const float* __restrict__ alpha,
+                                                          const float* __restrict__ background,
+                                                          uint8_t* __restrict__ out) {
+  const float b0 = background ? background[0] : 0.f, b1 = background ? background[1] : 0.f,
+              b2 = background ? background[2] : 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < n_px; p += gridDim.x * 256) {
+    const float w = 1.f - alpha[p];
+    const float* c = rgb + (size_t)p * rgb_stride;
+    const float v[3] = {c[0] + w * b0, c[1] + w * b1, c[2] + w * b2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      out[3 * (size_t)p + k] = (uint8_t)__float2int_rn(255.f * fminf(fmaxf(v[k], 0.f), 1.f));
+  }
+}
+}  // namespace
+}  // namespace mgs
+
+extern "C" int mgs_frame_to_u8(int n_px, const float* rgb, int rgb_stride, const float* alpha,
+                               const float* background, uint8_t* out, mgs_stream_t stream) {
+  MGS_REQUIRE(n_px >= 0 && rgb_stride >= 3, "frame_to_u8: bad sizes");
+  if (n_px == 0) return MGS_OK;
+  MGS_REQUIRE(rgb && alpha && out, "frame_to_u8: null pointer");
+  unsigned grid = div_up((unsigned)n_px, 256u);
+  if (grid > 4096u) grid = 4096u;
+  hipLaunchKernelGGL(frame_to_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_px, rgb,
+                     rgb_stride, alpha, background, out);
+  return check_launch("frame_to_u8");
+}

@@ -72,6 +72,7 @@ def all_reduce_gradients(params: Sequence[torch.Tensor], group=None, average: bo
 
 def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, width: int,
                    height: int, dst: int = 0, group=None, gather: bool = True, renderer=None,
+                   as_u8: bool = False, u8_background=None,
                    **kw) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], range]:
     """Render this rank's block of the C cameras and (optionally) gather all frames on `dst`.
     `renderer`: a persistent `FrameRenderer` built for this scene / resolution / render mode;
@@ -81,7 +82,9 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
     tensors: dict(means, quats, scales, opacities, colors, sh_degree) as from
     Gaussians.to_torch().  viewmats [C,4,4] / Ks [C,3,3] hold ALL cameras on every rank.
     Returns (colors, alphas, my_range): full [C,...] tensors on `dst` when gathered, this
-    rank's block otherwise."""
+    rank's block otherwise.  as_u8=True gathers 8-bit RGB images instead of fp32 renders
+    (compositing.frame_to_u8 with `u8_background`; alphas are then not gathered): a quarter of the
+    bytes over xGMI, which is what a dataset writer stores anyway."""
     from .rendering import rasterization
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -109,6 +112,11 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
         d = 3 if kw.get("render_mode", "RGB") == "RGB" else 4
         colors = torch.zeros(0, height, width, d, device=viewmats.device)
         alphas = torch.zeros(0, height, width, 1, device=viewmats.device)
+    if as_u8:
+        from .compositing import frame_to_u8
+        colors = (frame_to_u8(colors, alphas, u8_background) if len(mine)
+                  else torch.zeros(0, height, width, 3, dtype=torch.uint8, device=viewmats.device))
     if not gather or world == 1:
         return colors, alphas, mine
-    return (gather_frames(colors, C, dst, group), gather_frames(alphas, C, dst, group), mine)
+    return (gather_frames(colors, C, dst, group),
+            None if as_u8 else gather_frames(alphas, C, dst, group), mine)

@@ -47,3 +47,21 @@ def test_composite_matches_rule_on_a_real_render(use_mask):
     # both occlusion orders actually occur in this scene
     av, zb = a[0, ..., 0].cpu().numpy(), c[0, ..., 3].cpu().numpy()
     assert (present & (av > 0) & (zf <= zb)).any() and (present & (av > 0) & (zf > zb)).any()
+
+
+@pytest.mark.parametrize("mode,bg", [("RGB", None), ("RGB+ED", (0.2, 0.4, 0.9))])
+def test_frame_to_u8_is_splatfacto_postprocessing_quantised(mode, bg):
+    from robosimgs_amd import frame_to_u8, rasterization
+    g = synthetic_scene(8000, math.log(0.08), 1, 2)
+    cam = camera_ring(1, 203, 117, thetas=[0.5])[0]
+    t = g.to_torch(DEV, 1)
+    f = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(DEV)
+    c, a, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
+                            f(cam.viewmat())[None], f(cam.K)[None], 203, 117, sh_degree=1, render_mode=mode)
+    u8 = frame_to_u8(c[0], a[0], bg)
+    assert u8.dtype == torch.uint8 and u8.shape == (117, 203, 3)
+    back = torch.tensor(bg if bg is not None else (0.0, 0.0, 0.0), device=DEV)
+    ref = (c[0, ..., :3] + (1 - a[0]) * back).clamp(0, 1)
+    diff = (u8.float() - ref * 255).abs()
+    assert float(diff.max()) <= 0.5 + 1e-3                     # round to nearest
+    assert int(u8.max()) > 100 and int((u8 == 0).sum()) >= 0
