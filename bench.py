@@ -52,8 +52,11 @@ def parse():
     ap.add_argument("--bwd-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--gather-dtype", choices=("fp32", "u8"), default="fp32",
-                    help="N > 1: gather fp32 renders (default) or 8-bit images (frame_to_u8, 4x fewer bytes)")
+    # N > 1: what rank 0 collects.  "u8" (default) = the 8-bit images a dataset writer stores,
+    # quantised on the device inside the timed region ("or gather uint8 RGB"); "fp32" =
+    # the raw renders, 4x the bytes (7 x 24.9 MB per step into rank 0 at 8 ranks: about one frame time
+    # of xGMI bandwidth).  The render itself is fp32 either way.
+    ap.add_argument("--gather-dtype", choices=("fp32", "u8"), default="u8")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent frames in flight, one HIP stream + one HIP graph each")
@@ -226,7 +229,8 @@ def main():
                    "n_gaussians": a.n, "n_visible": n_vis, "n_isect": n_isect,
                    "n_isect_binned": n_isect_binned,
                    "tiles": tile_w * tile_h, "cameras_per_step": world,
-                   "gather": (("8-bit RGB images" if g_u8 else "fp32 RGB frames") + " to rank 0 (RCCL)") if do_gather else "none",
+                   "gather": (("8-bit RGB images (frame_to_u8 on the device, inside the timed region)" if g_u8
+                               else "fp32 RGB frames") + " to rank 0 (RCCL)") if do_gather else "none",
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
                              "frames in flight on separate HIP streams",
                    "frames_in_flight": n_fl, "single_frame_latency_ms": round(latency_ms, 4)},
