@@ -57,6 +57,7 @@ def parse():
     # the raw renders, 4x the bytes (7 x 24.9 MB per step into rank 0 at 8 ranks: about one frame time
     # of xGMI bandwidth).  The render itself is fp32 either way.
     ap.add_argument("--gather-dtype", choices=("fp32", "u8"), default="u8")
+    ap.add_argument("--gather-batch", type=int, default=4, help="frames per collective (N > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent frames in flight, one HIP stream + one HIP graph each")
@@ -137,40 +138,51 @@ def main():
 
     do_gather = use_dist and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
-    frame_shape = (H, W, 3)
     g_u8 = a.gather_dtype == "u8"
     g_dtype = torch.uint8 if g_u8 else torch.float32
+    # Frames leave in batches of `gather_batch` through a double-buffered staging area: the frame
+    # is converted (u8) or copied (fp32) into its place in the batch, the slot is released at once,
+    # and every gather_batch-th frame one collective ships the whole batch -- a per-frame
+    # collective costs ~80 us of launch / stream hand-over each, a quarter of a frame time.
+    GB = max(1, a.gather_batch)
+    batch_shape = (GB, H, W, 3)
+    staging = [torch.empty(batch_shape, device=dev, dtype=g_dtype) for _ in range(2)] if do_gather else None
+    host_staging = ([torch.empty(batch_shape, device="cpu", dtype=g_dtype) for _ in range(2)]
+                    if do_gather and debug_gloo else None)          # gloo debugging mode only
     gather_bufs = None
     if do_gather and rank == 0:
-        gather_bufs = [[torch.empty(frame_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
-                       for _ in range(n_fl)]
-    u8_bufs = [torch.empty(frame_shape, device=dev, dtype=torch.uint8) for _ in range(n_fl)] if (do_gather and g_u8) else None
-    # host-staged copies only for the gloo debugging mode; RCCL sends straight from the slot
-    send_bufs = ([torch.empty(frame_shape, device=comm_dev, dtype=g_dtype) for _ in range(n_fl)]
-                 if do_gather and debug_gloo else None)
-    pending = [None] * n_fl
+        gather_bufs = [[torch.empty(batch_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
+                       for _ in range(2)]
+    pending = [None, None]
+    state = {"cur": 0, "fill": 0}
     tickets = []
 
+    def ship():
+        """One collective for the frames staged so far (stream-ordered after their conversion)."""
+        cur = state["cur"]
+        src = staging[cur]
+        if debug_gloo:
+            host_staging[cur].copy_(src)                           # synchronous host copy
+            src = host_staging[cur]
+        pending[cur] = dist.gather(src, gather_bufs[cur] if rank == 0 else None, dst=0, async_op=True)
+        state["cur"], state["fill"] = cur ^ 1, 0
+
     def retire():
-        """Fetch the oldest frame; with N > 1 hand it to the (asynchronous) RCCL gather.  The
-        gather reads the slot's own frame buffer (no staging copy); the slot is released -- on the
-        stream level, the host does not block -- once that collective has drained, which with
-        `inflight` slots gives each gather inflight - 1 frame times to complete."""
+        """Fetch the oldest frame; with N > 1 stage it for the (asynchronous) RCCL gather."""
         tk = tickets.pop(0)
         f = fr.fetch(tk, check=False)
-        payload = f["colors"]
-        if do_gather and g_u8:                     # quantise on the device, inside the timed region
-            payload = frame_to_u8(f["colors"], f["alphas"], out=u8_bufs[tk].view(-1, 3))
-        if do_gather and debug_gloo:
-            if pending[tk] is not None:            # this slot's previous collective has drained
-                pending[tk].wait()
-            send_bufs[tk].copy_(payload, non_blocking=True)
-            pending[tk] = dist.gather(send_bufs[tk], gather_bufs[tk] if rank == 0 else None,
-                                      dst=0, async_op=True)
-        elif do_gather:
-            work = dist.gather(payload, gather_bufs[tk] if rank == 0 else None, dst=0,
-                               async_op=True)
-            work.wait()                            # current STREAM waits for the collective
+        if do_gather:
+            cur, j = state["cur"], state["fill"]
+            if j == 0 and pending[cur] is not None:    # the collective that last read this staging buffer
+                pending[cur].wait()                    # (NCCL: the current STREAM waits, not the host)
+                pending[cur] = None
+            if g_u8:                                   # quantise on the device, inside the timed region
+                frame_to_u8(f["colors"], f["alphas"], out=staging[cur][j].view(-1, 3))
+            else:
+                staging[cur][j].copy_(f["colors"], non_blocking=True)
+            state["fill"] = j + 1
+            if state["fill"] == GB:
+                ship()
         fr.release(tk)
 
     def step(i):
@@ -181,7 +193,9 @@ def main():
     def drain():
         while tickets:
             retire()
-        for k in range(n_fl):
+        if do_gather and state["fill"] > 0:            # a partial last batch still travels (whole buffer)
+            ship()
+        for k in range(2):
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
@@ -213,7 +227,7 @@ def main():
     if do_gather and rank == 0:
         # the collective really delivered every rank's frame (all cameras see the scene)
         for r_ in range(world):
-            assert float(gather_bufs[0][r_].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
+            assert float(gather_bufs[0][r_][0].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
     status = max(int(o[2]["isect_status"].max().item()) for o in outs)
     assert status == 0, "tile-intersection capacity overflow inside the timed region"
     frames_per_s = world * a.steps / elapsed
@@ -230,7 +244,7 @@ def main():
                    "n_isect_binned": n_isect_binned,
                    "tiles": tile_w * tile_h, "cameras_per_step": world,
                    "gather": (("8-bit RGB images (frame_to_u8 on the device, inside the timed region)" if g_u8
-                               else "fp32 RGB frames") + " to rank 0 (RCCL)") if do_gather else "none",
+                               else "fp32 RGB frames") + f" to rank 0 (RCCL), {GB} frames per collective") if do_gather else "none",
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
                              "frames in flight on separate HIP streams",
                    "frames_in_flight": n_fl, "single_frame_latency_ms": round(latency_ms, 4)},
