@@ -2,7 +2,9 @@
 product never reaches into oracle/ (no compute calls here: CPU-only)."""
 import os
 import re
+import shutil
 import subprocess
+import tempfile
 
 import pytest
 
@@ -39,7 +41,11 @@ def test_library_is_gfx950_only_and_links_no_torch():
     assert not any("torch" in n or "c10" in n for n in needed), needed
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if os.path.exists(objdump):
-        o = subprocess.run([objdump, "--offloading", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        # --offloading dumps every bundle entry next to its input: inspect a scratch copy
+        with tempfile.TemporaryDirectory() as scratch:
+            copy = shutil.copy(_lib.LIB_PATH, scratch)
+            o = subprocess.run([objdump, "--offloading", copy], capture_output=True, text=True,
+                               cwd=scratch).stdout
         archs = set(re.findall(r"gfx\w+", o))
         assert archs == {"gfx950"}, archs
 
