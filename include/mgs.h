@@ -45,6 +45,9 @@ extern "C" {
 
 #define MGS_STATUS_ISECT_OVERFLOW 1u
 
+/* mgs_rasterize_fwd flags */
+#define MGS_RASTER_EXPECTED_LAST 1 /* last channel leaves as channel / max(alpha, 1e-10): "ED" */
+
 #define MGS_TILE_SIZE 16
 #define MGS_MAX_CHANNELS 32
 
@@ -173,12 +176,15 @@ int mgs_isect_offset_encode(uint32_t n_isect, const int64_t *isect_ids, int n_ca
  *   channels in 1..MGS_MAX_CHANNELS.
  *   splats[N,12] (nullable, channels <= 4): packed records from mgs_project_color_fwd; when
  *   given, means2d / conics / feats / opacities are not read (and may be NULL).
+ *   flags: MGS_RASTER_EXPECTED_LAST divides the last channel (after the background term) by
+ *   max(alpha, 1e-10) in the epilogue -- the "ED" / "RGB+ED" render modes
+ *   without a second pass over the frame.
  * ----------------------------------------------------------------------------------- */
 int mgs_rasterize_fwd(int n, const float *means2d, const float *conics, const float *feats,
                       const float *opacities, const float *splats, const float *background,
                       int channels, int width, int height, int tile_w, int tile_h,
-                      const int32_t *tile_offsets, const int32_t *flatten_ids, float *render,
-                      float *alphas, int32_t *last_ids, mgs_stream_t stream);
+                      const int32_t *tile_offsets, const int32_t *flatten_ids, int flags,
+                      float *render, float *alphas, int32_t *last_ids, mgs_stream_t stream);
 
 /*   v_render[H,W,channels], v_alphas[H,W] incoming; v_means2d[N,2] v_conics[N,3]
  *   v_feats[N,channels] v_opacities[N] are ACCUMULATED into with float atomics

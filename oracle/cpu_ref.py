@@ -30,6 +30,7 @@ def lib():
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.gs_cpu_render.restype = ctypes.c_longlong
+        _lib.gs_cpu_render_f64.restype = ctypes.c_longlong
         _lib.gs_cpu_max_threads.restype = ctypes.c_int
     return _lib
 
@@ -58,3 +59,49 @@ def render(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height
                                   p(bg), int(n_threads), p(out), p(alpha), p(counters))
     return out, alpha, {"n_isect": int(n_isect), "n_vis": int(counters[0]),
                         "pair_evals": int(counters[1])}
+
+
+def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height, sh_degree,
+               with_depth=False, background=None, eps2d=0.3, near_plane=0.01, far_plane=1e10,
+               radius_clip=0.0, n_threads=0, margins=True, v_render=None, v_alpha=None,
+               want_projected=False):
+    """The frame in fp64 arithmetic on the fp32 inputs the GPU gets (the full-size reference
+    answer).  Returns (render[H,W,ch] f32, alpha[H,W] f32, info).  info carries
+      margins [3,H,W], edge_mask [H,W] bool, n_edge_gaussians        (margins=True; feed
+          oracle.gs_oracle_np.explained_pixels)
+      g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opacities [N]  f64: the blend's backward
+          (A.2 step 10) for upstream v_render [H,W,ch] / v_alpha [H,W]
+      means2d, conics, feats, radii as projected by the oracle          (want_projected=True)."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    means, quats, scales, opacities, sh = f(means), f(quats), f(scales), f(opacities), f(sh_coeffs)
+    vm, Km = f(viewmat), f(K)
+    n, ch = means.shape[0], 4 if with_depth else 3
+    out = np.empty((height, width, ch), np.float32)
+    alpha = np.empty((height, width), np.float32)
+    counters = np.zeros(2, np.int64)
+    bg = f(background) if background is not None else None
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    cf = ctypes.c_float
+    marg = np.empty((3, height, width), np.float32) if margins else None
+    edge = np.empty((height, width), np.uint8) if margins else None
+    n_edge = np.zeros(1, np.int64)
+    bwd = v_render is not None
+    vr = f(v_render).reshape(height, width, ch) if bwd else None
+    va = f(v_alpha if v_alpha is not None else np.zeros((height, width))).reshape(height, width) if bwd else None
+    gm, gc, gf, go = ((np.empty((n, 2)), np.empty((n, 3)), np.empty((n, ch)), np.empty(n)) if bwd
+                      else (None, None, None, None))
+    om, oc, of_, orad = ((np.empty((n, 2)), np.empty((n, 3)), np.empty((n, ch)), np.empty(n, np.int32))
+                         if want_projected else (None, None, None, None))
+    n_isect = lib().gs_cpu_render_f64(
+        n, p(means), p(quats), p(scales), p(opacities), int(sh_degree), sh.shape[1], p(sh), p(vm),
+        p(Km), int(width), int(height), cf(eps2d), cf(near_plane), cf(far_plane), cf(radius_clip),
+        ch, p(bg), int(n_threads), p(out), p(alpha), p(counters), p(marg), p(edge), p(n_edge),
+        p(vr), p(va), p(gm), p(gc), p(gf), p(go), p(om), p(oc), p(of_), p(orad))
+    info = {"n_isect": int(n_isect), "n_vis": int(counters[0]), "pair_evals": int(counters[1])}
+    if margins:
+        info.update(margins=marg, edge_mask=edge.astype(bool), n_edge_gaussians=int(n_edge[0]))
+    if bwd:
+        info.update(g_means2d=gm, g_conics=gc, g_feats=gf, g_opacities=go)
+    if want_projected:
+        info.update(means2d=om, conics=oc, feats=of_, radii=orad)
+    return out, alpha, info

@@ -1,19 +1,29 @@
-// gs_cpu.cpp -- fp32 C++/OpenMP restatement of the forward render path (TEST INFRASTRUCTURE
-// ONLY: the checker for large scenes and the timed `cpu_baseline` of bench.py).
+// gs_cpu.cpp -- C++/OpenMP restatement of the render path (TEST INFRASTRUCTURE ONLY: the checker
+// for large scenes and the timed `cpu_baseline` of bench.py).
 //
 // PARITY UNPINNED: the reference (Maxwell-Zhao/RoboSimGS) contains no renderer and no CPU
 // fallback (README.md:75 delegates 3DGS to Nerfstudio; README.md:29 lists the render stage as
 // unreleased), so this is a "port" of the published gsplat 1.x algorithm as written down in
-// SURVEY.md Appendix A.2 steps 1-9, in the textbook formulation: one 64-bit key
+// SURVEY.md Appendix A.2 steps 1-10, in the textbook formulation: one 64-bit key
 // (tile << 32 | depth bits) per (Gaussian, tile) pair, one global stable sort, one sequential
 // blend loop per pixel.  It shares no code with robosimgs_amd/csrc.  Validated against the
 // fp64 NumPy oracle in tests/test_oracle_cpu.py.
 //
-// Build: g++ -O3 -march=native -fopenmp -shared -fPIC gs_cpu.cpp -o _build/libgs_cpu.so
+// One template, two instantiations:
+//   float   gs_cpu_render      the timed CPU baseline (device-like rounding)
+//   double  gs_cpu_render_f64  the full-size reference answer.  It can also report, per pixel,
+//           how close every branch of the blend came to flipping (the margins of
+//           oracle/gs_oracle_np.py:rasterize) and which pixels a per-Gaussian knife edge of the
+//           projection reaches (gaussian_edge_mask), so that tests demand ZERO unexplained pixels
+//           over the 1e-4 tolerance at 1080p and 4K too; and it can run A.2 step 10 (the blend's
+//           backward) with fp64 accumulation: gradients w.r.t. the projected quantities.
+//
+// Build: g++ -O3 -std=c++17 -fopenmp -shared -fPIC gs_cpu.cpp -o _build/libgs_cpu.so
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <vector>
 #ifdef _OPENMP
@@ -22,146 +32,220 @@
 
 namespace {
 
+template <typename F>
 struct Splat {
-  float mx, my, depth, ca, cb, cc, opac;
+  F mx, my, depth, ca, cb, cc, opac;
+  float depth32;            // sort key: fp32 depth bits (A.2 step 7), also in the double build
   int radius;
   int x0, y0, x1, y1;
+  // knife-edge bookkeeping (margins only): outer / inner tile rectangles under perturbation
+  int ox0, oy0, ox1, oy1, ix0, iy0, ix1, iy1;
+  bool inner_on, unsure;
 };
 
-inline void mat3mul(const float* A, const float* B, float* C, bool bt) {
+template <typename F>
+inline void mat3mul(const F* A, const F* B, F* C, bool bt) {
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
-      float s = 0.f;
+      F s = 0;
       for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * (bt ? B[j * 3 + k] : B[k * 3 + j]);
       C[i * 3 + j] = s;
     }
 }
 
-// A.2 steps 1-5
-bool project_one(const float* mean, const float* quat, const float* scale, const float* V,
-                 const float* K, float W, float H, float eps2d, float near_p, float far_p,
-                 float radius_clip, Splat& s, float& comp) {
-  const float R[9] = {V[0], V[1], V[2], V[4], V[5], V[6], V[8], V[9], V[10]};
-  const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-  float x = R[0] * mean[0] + R[1] * mean[1] + R[2] * mean[2] + V[3];
-  float y = R[3] * mean[0] + R[4] * mean[1] + R[5] * mean[2] + V[7];
-  float z = R[6] * mean[0] + R[7] * mean[1] + R[8] * mean[2] + V[11];
-  if (z < near_p || z > far_p) return false;
-  float qn = std::sqrt(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
-  float w = quat[0] / qn, qx = quat[1] / qn, qy = quat[2] / qn, qz = quat[3] / qn;
-  float Rq[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - w * qz), 2 * (qx * qz + w * qy),
-                 2 * (qx * qy + w * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - w * qx),
-                 2 * (qx * qz - w * qy), 2 * (qy * qz + w * qx), 1 - 2 * (qx * qx + qy * qy)};
-  float M[9], cov[9], t[9], cc3[9];
+// A.2 steps 1-5.  Returns false when culled; `edge` (optional) receives the un-culled
+// intermediates the knife-edge classification needs: {3 sqrt(lambda), mx, my, z, det > 0}.
+template <typename F>
+bool project_one(const float* mean, const float* quat, const float* scale, const float* Vf,
+                 const float* Kf, F W, F H, F eps2d, F near_p, F far_p, F radius_clip,
+                 Splat<F>& s, F& comp, F* edge) {
+  F V[12], K[9];
+  for (int i = 0; i < 12; ++i) V[i] = Vf[i];
+  for (int i = 0; i < 9; ++i) K[i] = Kf[i];
+  const F R[9] = {V[0], V[1], V[2], V[4], V[5], V[6], V[8], V[9], V[10]};
+  const F fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  const F m0 = mean[0], m1 = mean[1], m2 = mean[2];
+  F x = R[0] * m0 + R[1] * m1 + R[2] * m2 + V[3];
+  F y = R[3] * m0 + R[4] * m1 + R[5] * m2 + V[7];
+  F z = R[6] * m0 + R[7] * m1 + R[8] * m2 + V[11];
+  if (edge) { edge[0] = 0; edge[1] = 0; edge[2] = 0; edge[3] = z; edge[4] = 0; }
+  const bool z_ok = !(z < near_p || z > far_p);
+  if (!z_ok && !edge) return false;
+  const F zs = z_ok ? z : (z > 0 ? z : F(1));
+  const F q0 = quat[0], q1 = quat[1], q2 = quat[2], q3 = quat[3];
+  F qn = std::sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  F w = q0 / qn, qx = q1 / qn, qy = q2 / qn, qz = q3 / qn;
+  F Rq[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - w * qz), 2 * (qx * qz + w * qy),
+             2 * (qx * qy + w * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - w * qx),
+             2 * (qx * qz - w * qy), 2 * (qy * qz + w * qx), 1 - 2 * (qx * qx + qy * qy)};
+  F M[9], cov[9], t[9], cc3[9];
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) M[i * 3 + j] = Rq[i * 3 + j] * scale[j];
+    for (int j = 0; j < 3; ++j) M[i * 3 + j] = Rq[i * 3 + j] * (F)scale[j];
   mat3mul(M, M, cov, true);
   mat3mul(R, cov, t, false);
   mat3mul(t, R, cc3, true);
-  float tanx = 0.5f * W / fx, tany = 0.5f * H / fy;
-  float lxp = (W - cx) / fx + 0.3f * tanx, lxn = cx / fx + 0.3f * tanx;
-  float lyp = (H - cy) / fy + 0.3f * tany, lyn = cy / fy + 0.3f * tany;
-  float rz = 1.f / z;
-  float tx = z * std::min(lxp, std::max(-lxn, x * rz)), ty = z * std::min(lyp, std::max(-lyn, y * rz));
-  float J[6] = {fx * rz, 0.f, -fx * tx * rz * rz, 0.f, fy * rz, -fy * ty * rz * rz};
-  float JC[6];
+  F tanx = F(0.5) * W / fx, tany = F(0.5) * H / fy;
+  F lxp = (W - cx) / fx + F(0.3) * tanx, lxn = cx / fx + F(0.3) * tanx;
+  F lyp = (H - cy) / fy + F(0.3) * tany, lyn = cy / fy + F(0.3) * tany;
+  F rz = F(1) / zs;
+  F tx = zs * std::min(lxp, std::max(-lxn, x * rz)), ty = zs * std::min(lyp, std::max(-lyn, y * rz));
+  F J[6] = {fx * rz, 0, -fx * tx * rz * rz, 0, fy * rz, -fy * ty * rz * rz};
+  F JC[6];
   for (int r = 0; r < 2; ++r)
     for (int c = 0; c < 3; ++c)
       JC[r * 3 + c] = J[r * 3] * cc3[c] + J[r * 3 + 1] * cc3[3 + c] + J[r * 3 + 2] * cc3[6 + c];
-  float a = JC[0] * J[0] + JC[1] * J[1] + JC[2] * J[2];
-  float b = JC[0] * J[3] + JC[1] * J[4] + JC[2] * J[5];
-  float c = JC[3] * J[3] + JC[4] * J[4] + JC[5] * J[5];
-  float det0 = a * c - b * b;
+  F a = JC[0] * J[0] + JC[1] * J[1] + JC[2] * J[2];
+  F b = JC[0] * J[3] + JC[1] * J[4] + JC[2] * J[5];
+  F c = JC[3] * J[3] + JC[4] * J[4] + JC[5] * J[5];
+  F det0 = a * c - b * b;
   a += eps2d; c += eps2d;
-  float det = a * c - b * b;
-  if (det <= 0.f) return false;
-  float mid = 0.5f * (a + c);
-  float lam = mid + std::sqrt(std::max(0.01f, mid * mid - det));
-  float radius = std::ceil(3.f * std::sqrt(lam));
-  if (radius <= radius_clip) return false;
-  float mx = fx * x * rz + cx, my = fy * y * rz + cy;
-  if (mx + radius <= 0 || mx - radius >= W || my + radius <= 0 || my - radius >= H) return false;
-  s.mx = mx; s.my = my; s.depth = z;
+  F det = a * c - b * b;
+  const bool det_ok = det > 0;
+  if (!det_ok) return false;
+  F mid = F(0.5) * (a + c);
+  F lam = mid + std::sqrt(std::max(F(0.01), mid * mid - det));
+  F v3 = F(3) * std::sqrt(lam);
+  F radius = std::ceil(v3);
+  F mx = fx * x * rz + cx, my = fy * y * rz + cy;
+  s.mx = mx; s.my = my; s.depth = z; s.depth32 = (float)z;
   s.ca = c / det; s.cb = -b / det; s.cc = a / det;
   s.radius = (int)radius;
-  comp = std::sqrt(std::max(0.f, det0 / det));
+  comp = std::sqrt(std::max(F(0), det0 / det));
+  if (edge) { edge[0] = v3; edge[1] = mx; edge[2] = my; edge[3] = z; edge[4] = 1; }
+  if (!z_ok) return false;
+  if (radius <= radius_clip) return false;
+  if (mx + radius <= 0 || mx - radius >= W || my + radius <= 0 || my - radius >= H) return false;
   return true;
 }
 
 // A.2 step 6
-void sh_color(int deg, const float* mean, const float* campos, const float* coef, float* rgb) {
-  float dx = mean[0] - campos[0], dy = mean[1] - campos[1], dz = mean[2] - campos[2];
-  float inv = 1.f / std::sqrt(dx * dx + dy * dy + dz * dz);
-  float x = dx * inv, y = dy * inv, z = dz * inv;
-  float Y[16];
-  Y[0] = 0.2820947917738781f;
-  if (deg >= 1) { Y[1] = -0.48860251190292f * y; Y[2] = 0.48860251190292f * z; Y[3] = -0.48860251190292f * x; }
-  float z2 = z * z, fC1 = x * x - y * y, fS1 = 2.f * x * y;
+template <typename F>
+void sh_color(int deg, const float* mean, const F* campos, const float* coef, F* rgb) {
+  F dx = mean[0] - campos[0], dy = mean[1] - campos[1], dz = mean[2] - campos[2];
+  F inv = F(1) / std::sqrt(dx * dx + dy * dy + dz * dz);
+  F x = dx * inv, y = dy * inv, z = dz * inv;
+  F Y[16];
+  Y[0] = F(0.2820947917738781);
+  if (deg >= 1) { Y[1] = F(-0.48860251190292) * y; Y[2] = F(0.48860251190292) * z; Y[3] = F(-0.48860251190292) * x; }
+  F z2 = z * z, fC1 = x * x - y * y, fS1 = 2 * x * y;
   if (deg >= 2) {
-    float t = -1.092548430592079f * z;
-    Y[4] = 0.5462742152960395f * fS1; Y[5] = t * y; Y[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
-    Y[7] = t * x; Y[8] = 0.5462742152960395f * fC1;
+    F t = F(-1.092548430592079) * z;
+    Y[4] = F(0.5462742152960395) * fS1; Y[5] = t * y; Y[6] = F(0.9461746957575601) * z2 - F(0.3153915652525201);
+    Y[7] = t * x; Y[8] = F(0.5462742152960395) * fC1;
   }
   if (deg >= 3) {
-    float u = -2.285228997322329f * z2 + 0.4570457994644658f, w = 1.445305721320277f * z;
-    float fC2 = x * fC1 - y * fS1, fS2 = x * fS1 + y * fC1;
-    Y[9] = -0.5900435899266435f * fS2; Y[10] = w * fS1; Y[11] = u * y;
-    Y[12] = z * (1.865881662950577f * z2 - 1.119528997770346f); Y[13] = u * x; Y[14] = w * fC1;
-    Y[15] = -0.5900435899266435f * fC2;
+    F u = F(-2.285228997322329) * z2 + F(0.4570457994644658), w = F(1.445305721320277) * z;
+    F fC2 = x * fC1 - y * fS1, fS2 = x * fS1 + y * fC1;
+    Y[9] = F(-0.5900435899266435) * fS2; Y[10] = w * fS1; Y[11] = u * y;
+    Y[12] = z * (F(1.865881662950577) * z2 - F(1.119528997770346)); Y[13] = u * x; Y[14] = w * fC1;
+    Y[15] = F(-0.5900435899266435) * fC2;
   }
   int KC = (deg + 1) * (deg + 1);
   for (int c = 0; c < 3; ++c) {
-    float s = 0.f;
-    for (int k = 0; k < KC; ++k) s += Y[k] * coef[3 * k + c];
-    rgb[c] = std::max(0.f, s + 0.5f);
+    F s = 0;
+    for (int k = 0; k < KC; ++k) s += Y[k] * (F)coef[3 * k + c];
+    rgb[c] = std::max(F(0), s + F(0.5));
   }
 }
 
-}  // namespace
+struct Extras {            // optional outputs of the double build (all may be null)
+  float* margins = nullptr;        // [3,H,W]  alpha / T / sigma margins (inf where nothing was decided)
+  uint8_t* edge_mask = nullptr;    // [H,W]
+  long long* n_edge = nullptr;     // Gaussians with an uncertain tile rectangle
+  // backward of the blend (A.2 step 10), fp64 accumulation
+  const float* v_render = nullptr; // [H,W,ch]
+  const float* v_alpha = nullptr;  // [H,W]
+  double* g_means2d = nullptr;     // [N,2]
+  double* g_conics = nullptr;      // [N,3]
+  double* g_feats = nullptr;       // [N,ch]
+  double* g_opac = nullptr;        // [N]
+  // projected quantities as the oracle computed them (for the projection's autograd oracle)
+  double* o_means2d = nullptr;     // [N,2]
+  double* o_conics = nullptr;      // [N,3]
+  double* o_feats = nullptr;       // [N,ch]
+  int32_t* o_radii = nullptr;      // [N]
+};
 
-// Whole forward frame for one camera.  feat layout: channels = 3 (rgb) or 4 (rgb + depth).
-// Returns the number of tile intersections; counters[0] = visible Gaussians,
-// counters[1] = pixel-Gaussian pair evaluations (for throughput reporting).
-extern "C" long long gs_cpu_render(int n, const float* means, const float* quats,
-                                   const float* scales, const float* opacities, int sh_degree,
-                                   int coeff_stride, const float* sh, const float* viewmat,
-                                   const float* K, int width, int height, float eps2d,
-                                   float near_p, float far_p, float radius_clip, int channels,
-                                   const float* background, int n_threads, float* render,
-                                   float* alphas, long long* counters) {
+template <typename F>
+long long render_impl(int n, const float* means, const float* quats, const float* scales,
+                      const float* opacities, int sh_degree, int coeff_stride, const float* sh,
+                      const float* viewmat, const float* K, int width, int height, float eps2d,
+                      float near_p, float far_p, float radius_clip, int channels,
+                      const float* background, int n_threads, float* render, float* alphas,
+                      long long* counters, const Extras& ex) {
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
   const int T = 16, tw = (width + T - 1) / T, th = (height + T - 1) / T;
-  std::vector<Splat> sp(n);
-  std::vector<float> feat((size_t)n * channels);
+  const bool want_edges = ex.edge_mask != nullptr;
+  std::vector<Splat<F>> sp(n);
+  std::vector<F> feat((size_t)n * channels);
   std::vector<long long> cnt(n, 0);
   const float* V = viewmat;
-  float campos[3];
-  for (int i = 0; i < 3; ++i) campos[i] = -(V[0 + i] * V[3] + V[4 + i] * V[7] + V[8 + i] * V[11]);
-  long long n_vis = 0;
-#pragma omp parallel for schedule(static) reduction(+ : n_vis)
+  F campos[3];
+  for (int i = 0; i < 3; ++i)
+    campos[i] = -((F)V[0 + i] * (F)V[3] + (F)V[4 + i] * (F)V[7] + (F)V[8 + i] * (F)V[11]);
+  long long n_vis = 0, n_edge = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_vis, n_edge)
   for (int g = 0; g < n; ++g) {
-    float comp;
-    Splat s{};
-    if (!project_one(means + 3 * g, quats + 4 * g, scales + 3 * g, V, K, (float)width,
-                     (float)height, eps2d, near_p, far_p, radius_clip, s, comp)) {
+    F comp;
+    F edge[5];
+    Splat<F> s{};
+    const bool vis = project_one<F>(means + 3 * g, quats + 4 * g, scales + 3 * g, V, K, (F)width,
+                                    (F)height, (F)eps2d, (F)near_p, (F)far_p, (F)radius_clip, s,
+                                    comp, want_edges ? edge : nullptr);
+    s.opac = opacities[g];
+    if (want_edges && edge[4] != 0) {
+      // gaussian_edge_mask of oracle/gs_oracle_np.py: rectangles under the perturbations an fp32
+      // projection can apply (radius +-1 when 3 sqrt(lambda) is within 3e-5 relative of an integer,
+      // mean +-1e-3 px, depth 1e-5 relative around the near / far plane)
+      const F v3 = edge[0], mx = edge[1], my = edge[2], z = edge[3];
+      const F r = std::ceil(v3), fr = v3 - std::floor(v3);
+      const F tol = F(3e-5) * std::max(v3, F(1)) + F(1e-6);
+      const F r_lo = (fr > 0 && fr < tol) ? r - 1 : r;
+      const F r_hi = (1 - fr < tol || fr == 0) ? r + 1 : r;
+      const bool zin = z >= near_p * (1 + 1e-5) && z <= far_p * (1 - 1e-5);
+      const bool zout = z >= near_p * (1 - 1e-5) && z <= far_p * (1 + 1e-5);
+      auto rect = [&](F rr, F d, int& x0, int& y0, int& x1, int& y1) {
+        x0 = std::min(std::max(0, (int)std::floor((mx - rr - d) / T)), tw);
+        x1 = std::min(std::max(0, (int)std::ceil((mx + rr + d) / T)), tw);
+        y0 = std::min(std::max(0, (int)std::floor((my - rr - d) / T)), th);
+        y1 = std::min(std::max(0, (int)std::ceil((my + rr + d) / T)), th);
+        return !(mx + rr + d <= 0 || mx - rr - d >= width || my + rr + d <= 0 || my - rr - d >= height) &&
+               rr > radius_clip;
+      };
+      const F dmu = F(1e-3);
+      bool ion = rect(r_lo, -dmu, s.ix0, s.iy0, s.ix1, s.iy1) && zin;
+      bool oon = rect(r_hi, dmu, s.ox0, s.oy0, s.ox1, s.oy1) && zout;
+      if (!ion) s.ix0 = s.ix1 = s.iy0 = s.iy1 = 0;
+      s.inner_on = ion;
+      s.unsure = oon && (!ion || s.ox0 != s.ix0 || s.ox1 != s.ix1 || s.oy0 != s.iy0 || s.oy1 != s.iy1);
+      if (s.unsure) ++n_edge;
+    }
+    if (!vis) {
       s.radius = 0;
       sp[g] = s;
       continue;
     }
-    s.opac = opacities[g];
-    float tr = (float)s.radius / T, tx = s.mx / T, ty = s.my / T;
+    F tr = (F)s.radius / T, tx = s.mx / T, ty = s.my / T;
     s.x0 = std::min(std::max(0, (int)std::floor(tx - tr)), tw);
     s.x1 = std::min(std::max(0, (int)std::ceil(tx + tr)), tw);
     s.y0 = std::min(std::max(0, (int)std::floor(ty - tr)), th);
     s.y1 = std::min(std::max(0, (int)std::ceil(ty + tr)), th);
     cnt[g] = (long long)(s.x1 - s.x0) * (s.y1 - s.y0);
-    sh_color(sh_degree, means + 3 * g, campos, sh + (size_t)g * coeff_stride * 3, &feat[(size_t)g * channels]);
+    sh_color<F>(sh_degree, means + 3 * g, campos, sh + (size_t)g * coeff_stride * 3, &feat[(size_t)g * channels]);
     if (channels == 4) feat[(size_t)g * 4 + 3] = s.depth;
     sp[g] = s;
     ++n_vis;
   }
+  if (ex.o_radii)
+    for (int g = 0; g < n; ++g) {
+      ex.o_radii[g] = sp[g].radius;
+      const bool v = sp[g].radius > 0;
+      if (ex.o_means2d) { ex.o_means2d[2 * g] = v ? sp[g].mx : 0; ex.o_means2d[2 * g + 1] = v ? sp[g].my : 0; }
+      if (ex.o_conics) { ex.o_conics[3 * g] = v ? sp[g].ca : 0; ex.o_conics[3 * g + 1] = v ? sp[g].cb : 0; ex.o_conics[3 * g + 2] = v ? sp[g].cc : 0; }
+      if (ex.o_feats) for (int c = 0; c < channels; ++c) ex.o_feats[(size_t)g * channels + c] = v ? feat[(size_t)g * channels + c] : 0;
+    }
   // A.2 step 7: keys in Gaussian-index order
   std::vector<long long> off(n + 1, 0);
   for (int g = 0; g < n; ++g) off[g + 1] = off[g] + cnt[g];
@@ -171,9 +255,9 @@ extern "C" long long gs_cpu_render(int n, const float* means, const float* quats
 #pragma omp parallel for schedule(dynamic, 4096)
   for (int g = 0; g < n; ++g) {
     if (!cnt[g]) continue;
-    const Splat& s = sp[g];
+    const Splat<F>& s = sp[g];
     uint32_t db;
-    std::memcpy(&db, &s.depth, 4);
+    std::memcpy(&db, &s.depth32, 4);
     long long o = off[g];
     for (int y = s.y0; y < s.y1; ++y)
       for (int x = s.x0; x < s.x1; ++x) {
@@ -184,50 +268,220 @@ extern "C" long long gs_cpu_render(int n, const float* means, const float* quats
   // A.2 step 8: stable sort by key (permutation sort), tile ranges
   std::vector<long long> perm(n_isect);
   std::iota(perm.begin(), perm.end(), 0LL);
+  // parallel: bucket by tile (counting sort, stable), then sort each tile's slice by depth
+  std::vector<long long> tstart((size_t)tw * th + 1, 0);
+  for (long long i = 0; i < n_isect; ++i) ++tstart[(keys[i] >> 32) + 1];
+  for (size_t t = 0; t < (size_t)tw * th; ++t) tstart[t + 1] += tstart[t];
   {
-    // parallel: bucket by tile (counting sort, stable), then sort each tile's slice by depth
-    std::vector<long long> tstart((size_t)tw * th + 1, 0);
-    for (long long i = 0; i < n_isect; ++i) ++tstart[(keys[i] >> 32) + 1];
-    for (size_t t = 0; t < (size_t)tw * th; ++t) tstart[t + 1] += tstart[t];
     std::vector<long long> cur(tstart.begin(), tstart.end() - 1);
     for (long long i = 0; i < n_isect; ++i) perm[cur[keys[i] >> 32]++] = i;
+  }
 #pragma omp parallel for schedule(dynamic, 16)
-    for (long long t = 0; t < (long long)tw * th; ++t)
-      std::stable_sort(perm.begin() + tstart[t], perm.begin() + tstart[t + 1],
-                       [&](long long a, long long b) { return keys[a] < keys[b]; });
-    // A.2 step 9: blend
-    long long evals = 0;
+  for (long long t = 0; t < (long long)tw * th; ++t)
+    std::stable_sort(perm.begin() + tstart[t], perm.begin() + tstart[t + 1],
+                     [&](long long a, long long b) { return keys[a] < keys[b]; });
+
+  const bool want_margins = ex.margins != nullptr;
+  const bool want_bwd = ex.v_render != nullptr;
+  const size_t n_px = (size_t)width * height;
+  const float inf = std::numeric_limits<float>::infinity();
+  if (want_margins) std::fill(ex.margins, ex.margins + 3 * n_px, inf);
+  std::vector<long long> last_idx;     // backward: list position of the last blended Gaussian, -1 if none
+  std::vector<double> t_final;         // backward: final transmittance in full precision
+  if (want_bwd) { last_idx.assign(n_px, -1); t_final.assign(n_px, 1.0); }
+  // A.2 step 9: blend
+  long long evals = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : evals)
-    for (long long t = 0; t < (long long)tw * th; ++t) {
-      const int tx = (int)(t % tw), ty = (int)(t / tw);
-      for (int py = ty * T; py < std::min((ty + 1) * T, height); ++py)
-        for (int px = tx * T; px < std::min((tx + 1) * T, width); ++px) {
-          float Tr = 1.f, C[4] = {0.f, 0.f, 0.f, 0.f};
-          const float fx = px + 0.5f, fy = py + 0.5f;
-          for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
-            const int g = ids[perm[i]];
-            const Splat& s = sp[g];
-            ++evals;
-            float dx = s.mx - fx, dy = s.my - fy;
-            float sigma = 0.5f * (s.ca * dx * dx + s.cc * dy * dy) + s.cb * dx * dy;
-            if (sigma < 0.f) continue;
-            float alpha = std::min(0.999f, s.opac * std::exp(-sigma));
-            if (alpha < 1.f / 255.f) continue;
-            float nT = Tr * (1.f - alpha);
-            if (nT <= 1e-4f) break;
-            float wgt = alpha * Tr;
-            for (int c = 0; c < channels; ++c) C[c] += wgt * feat[(size_t)g * channels + c];
-            Tr = nT;
+  for (long long t = 0; t < (long long)tw * th; ++t) {
+    const int tx = (int)(t % tw), ty = (int)(t / tw);
+    for (int py = ty * T; py < std::min((ty + 1) * T, height); ++py)
+      for (int px = tx * T; px < std::min((tx + 1) * T, width); ++px) {
+        F Tr = 1, C[4] = {0, 0, 0, 0};
+        const F fx = px + F(0.5), fy = py + F(0.5);
+        F m_a = inf, m_t = inf, m_s = inf;
+        long long last = -1;
+        for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
+          const int g = ids[perm[i]];
+          const Splat<F>& s = sp[g];
+          ++evals;
+          F dx = s.mx - fx, dy = s.my - fy;
+          F sigma = F(0.5) * (s.ca * dx * dx + s.cc * dy * dy) + s.cb * dx * dy;
+          F alpha = std::min(F(0.999), s.opac * std::exp(-sigma));
+          F nT = Tr * (1 - alpha);
+          if (want_margins) {
+            m_a = std::min(m_a, std::abs(alpha * 255 - 1));
+            if (alpha >= F(0.5 / 255.0)) {
+              m_t = std::min(m_t, std::abs(nT / F(1e-4) - 1));
+              F S = F(0.5) * (std::abs(s.ca) * dx * dx + std::abs(s.cc) * dy * dy) + std::abs(s.cb * dx * dy);
+              if (S > 0) m_s = std::min(m_s, std::abs(sigma) / S);
+            }
           }
-          size_t p = (size_t)py * width + px;
-          for (int c = 0; c < channels; ++c)
-            render[p * channels + c] = C[c] + (background ? Tr * background[c] : 0.f);
-          alphas[p] = 1.f - Tr;
+          if (sigma < 0) continue;
+          if (alpha < F(1.0 / 255.0)) continue;
+          if (nT <= F(1e-4)) break;
+          F wgt = alpha * Tr;
+          for (int c = 0; c < channels; ++c) C[c] += wgt * feat[(size_t)g * channels + c];
+          Tr = nT;
+          last = i;
+        }
+        size_t p = (size_t)py * width + px;
+        for (int c = 0; c < channels; ++c)
+          render[p * channels + c] = (float)(C[c] + (background ? Tr * background[c] : 0));
+        alphas[p] = (float)(1 - Tr);
+        if (want_margins) {
+          ex.margins[p] = (float)m_a;
+          ex.margins[n_px + p] = (float)m_t;
+          ex.margins[2 * n_px + p] = (float)m_s;
+        }
+        if (want_bwd) { last_idx[p] = last; t_final[p] = (double)Tr; }
+      }
+  }
+  if (counters) { counters[0] = n_vis; counters[1] = evals; }
+
+  // pixels a per-Gaussian knife edge can reach (gaussian_edge_mask)
+  if (want_edges) {
+    std::memset(ex.edge_mask, 0, n_px);
+    for (int g = 0; g < n; ++g) {
+      const Splat<F>& s = sp[g];
+      if (!s.unsure) continue;
+      for (int ty = s.oy0; ty < s.oy1; ++ty)
+        for (int tx = s.ox0; tx < s.ox1; ++tx) {
+          if (s.inner_on && tx >= s.ix0 && tx < s.ix1 && ty >= s.iy0 && ty < s.iy1) continue;
+          for (int py = ty * T; py < std::min((ty + 1) * T, height); ++py)
+            for (int px = tx * T; px < std::min((tx + 1) * T, width); ++px) {
+              F dx = s.mx - (px + F(0.5)), dy = s.my - (py + F(0.5));
+              F sigma = F(0.5) * (s.ca * dx * dx + s.cc * dy * dy) + s.cb * dx * dy;
+              F alpha = std::min(F(0.999), s.opac * std::exp(-sigma));
+              if (alpha >= F((1.0 - 1e-3) / 255.0)) ex.edge_mask[(size_t)py * width + px] = 1;
+            }
         }
     }
-    if (counters) { counters[0] = n_vis; counters[1] = evals; }
+    if (ex.n_edge) *ex.n_edge = n_edge;
+  }
+
+  // A.2 step 10: backward of the blend, Gaussian-outer per tile, fp64 sums
+  if (want_bwd) {
+    std::fill(ex.g_means2d, ex.g_means2d + 2 * (size_t)n, 0.0);
+    std::fill(ex.g_conics, ex.g_conics + 3 * (size_t)n, 0.0);
+    std::fill(ex.g_feats, ex.g_feats + (size_t)channels * n, 0.0);
+    std::fill(ex.g_opac, ex.g_opac + (size_t)n, 0.0);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long long t = 0; t < (long long)tw * th; ++t) {
+      const int tx = (int)(t % tw), ty = (int)(t / tw);
+      const int x_lo = tx * T, x_hi = std::min((tx + 1) * T, width), y_lo = ty * T, y_hi = std::min((ty + 1) * T, height);
+      double Tcur[256], Tfin[256], Sbuf[256][4];
+      long long hi = -1;
+      for (int py = y_lo; py < y_hi; ++py)
+        for (int px = x_lo; px < x_hi; ++px) {
+          const int k = (py - y_lo) * T + (px - x_lo);
+          const size_t p = (size_t)py * width + px;
+          Tfin[k] = Tcur[k] = t_final[p];
+          for (int c = 0; c < 4; ++c) Sbuf[k][c] = 0.0;
+          hi = std::max(hi, last_idx[p]);
+        }
+      for (long long i = hi; i >= tstart[t]; --i) {
+        const int g = ids[perm[i]];
+        const Splat<F>& s = sp[g];
+        double gx = 0, gy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0, gf[4] = {0, 0, 0, 0};
+        bool any = false;
+        for (int py = y_lo; py < y_hi; ++py)
+          for (int px = x_lo; px < x_hi; ++px) {
+            const size_t p = (size_t)py * width + px;
+            if (i > last_idx[p]) continue;
+            const int k = (py - y_lo) * T + (px - x_lo);
+            const double dx = (double)s.mx - (px + 0.5), dy = (double)s.my - (py + 0.5);
+            const double sigma = 0.5 * ((double)s.ca * dx * dx + (double)s.cc * dy * dy) + (double)s.cb * dx * dy;
+            const double vis = std::exp(-sigma), ov = (double)s.opac * vis;
+            const double alpha = std::min(0.999, ov);
+            if (sigma < 0 || alpha < 1.0 / 255.0) continue;
+            any = true;
+            const double ra = 1.0 / (1.0 - alpha);
+            Tcur[k] *= ra;
+            const double Tk = Tcur[k], fac = alpha * Tk;
+            double v_alpha = 0;
+            for (int c = 0; c < channels; ++c) {
+              const double vc = ex.v_render[p * channels + c], fc = (double)feat[(size_t)g * channels + c];
+              gf[c] += fac * vc;
+              v_alpha += (fc * Tk - Sbuf[k][c] * ra) * vc;
+              Sbuf[k][c] += fc * fac;
+            }
+            double va = ex.v_alpha[p];
+            if (background)
+              for (int c = 0; c < channels; ++c) va -= (double)background[c] * ex.v_render[p * channels + c];
+            v_alpha += Tfin[k] * ra * va;
+            if (ov <= 0.999) {
+              const double v_sigma = -ov * v_alpha;
+              gca += 0.5 * v_sigma * dx * dx;
+              gcb += v_sigma * dx * dy;
+              gcc += 0.5 * v_sigma * dy * dy;
+              gx += v_sigma * ((double)s.ca * dx + (double)s.cb * dy);
+              gy += v_sigma * ((double)s.cb * dx + (double)s.cc * dy);
+              gop += vis * v_alpha;
+            }
+          }
+        if (!any) continue;
+#pragma omp atomic
+        ex.g_means2d[2 * (size_t)g] += gx;
+#pragma omp atomic
+        ex.g_means2d[2 * (size_t)g + 1] += gy;
+#pragma omp atomic
+        ex.g_conics[3 * (size_t)g] += gca;
+#pragma omp atomic
+        ex.g_conics[3 * (size_t)g + 1] += gcb;
+#pragma omp atomic
+        ex.g_conics[3 * (size_t)g + 2] += gcc;
+#pragma omp atomic
+        ex.g_opac[g] += gop;
+        for (int c = 0; c < channels; ++c) {
+#pragma omp atomic
+          ex.g_feats[(size_t)g * channels + c] += gf[c];
+        }
+      }
+    }
   }
   return n_isect;
+}
+
+}  // namespace
+
+// Whole forward frame for one camera, fp32 arithmetic (the timed CPU baseline).  feat layout:
+// channels = 3 (rgb) or 4 (rgb + depth).  Returns the number of tile intersections;
+// counters[0] = visible Gaussians, counters[1] = pixel-Gaussian pair evaluations.
+extern "C" long long gs_cpu_render(int n, const float* means, const float* quats,
+                                   const float* scales, const float* opacities, int sh_degree,
+                                   int coeff_stride, const float* sh, const float* viewmat,
+                                   const float* K, int width, int height, float eps2d,
+                                   float near_p, float far_p, float radius_clip, int channels,
+                                   const float* background, int n_threads, float* render,
+                                   float* alphas, long long* counters) {
+  return render_impl<float>(n, means, quats, scales, opacities, sh_degree, coeff_stride, sh, viewmat,
+                            K, width, height, eps2d, near_p, far_p, radius_clip, channels,
+                            background, n_threads, render, alphas, counters, Extras{});
+}
+
+// The same frame in fp64 (inputs are the fp32 arrays the GPU gets).  Optional outputs (null to skip):
+// margins [3,H,W] + edge_mask [H,W] + n_edge; blend backward given v_render [H,W,ch] / v_alpha [H,W]
+// into g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opac [N]; the projected quantities
+// o_means2d / o_conics / o_feats / o_radii.
+extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* quats,
+                                       const float* scales, const float* opacities, int sh_degree,
+                                       int coeff_stride, const float* sh, const float* viewmat,
+                                       const float* K, int width, int height, float eps2d,
+                                       float near_p, float far_p, float radius_clip, int channels,
+                                       const float* background, int n_threads, float* render,
+                                       float* alphas, long long* counters, float* margins,
+                                       uint8_t* edge_mask, long long* n_edge, const float* v_render,
+                                       const float* v_alpha, double* g_means2d, double* g_conics,
+                                       double* g_feats, double* g_opac, double* o_means2d,
+                                       double* o_conics, double* o_feats, int32_t* o_radii) {
+  Extras ex;
+  ex.margins = margins; ex.edge_mask = edge_mask; ex.n_edge = n_edge;
+  ex.v_render = v_render; ex.v_alpha = v_alpha;
+  ex.g_means2d = g_means2d; ex.g_conics = g_conics; ex.g_feats = g_feats; ex.g_opac = g_opac;
+  ex.o_means2d = o_means2d; ex.o_conics = o_conics; ex.o_feats = o_feats; ex.o_radii = o_radii;
+  return render_impl<double>(n, means, quats, scales, opacities, sh_degree, coeff_stride, sh, viewmat,
+                             K, width, height, eps2d, near_p, far_p, radius_clip, channels,
+                             background, n_threads, render, alphas, counters, ex);
 }
 
 extern "C" int gs_cpu_max_threads() {

@@ -140,7 +140,10 @@ def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3,
     valid &= ~((mu[:, 0] + radius <= 0) | (mu[:, 0] - radius >= W)
                | (mu[:, 1] + radius <= 0) | (mu[:, 1] - radius >= H))
 
+    zok = (z >= dtype(near_plane)) & (z <= dtype(far_plane))
     out = {
+        # un-masked intermediates (gaussian_edge_mask): lambda_1, raw means / depths / conics
+        "lam": lam, "mu": mu, "z": z, "det_ok": det > 0, "conics_all": conic, "z_ok": zok,
         "radii": np.where(valid, radius, 0).astype(np.int32),
         "means2d": np.where(valid[:, None], mu, 0),
         "depths": np.where(valid, z, 0),
@@ -262,7 +265,7 @@ def isect_offsets(isect_ids, n_cams, tile_w, tile_h):
 # A.2 step 9: forward blend (literal sequential loop; small cases only)
 # --------------------------------------------------------------------------------------
 def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, height,
-              tile_size=16, background=None, dtype=np.float64, exp=None):
+              tile_size=16, background=None, dtype=np.float64, exp=None, margins=False):
     """Per-tile front-to-back alpha compositing for ONE camera.
 
     colors [N,D]; offsets [th,tw] int32 (first sorted index per tile); the range of
@@ -271,7 +274,17 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
     `last_ids` is the sorted-list index of the last Gaussian that contributed (0-based,
     global index into flatten_ids); pixels with no contribution hold range_start - 1 ...
     they hold the value `range_start` is NOT touched: we use 0 like an all-zero init.
-    """
+
+    margins=True adds stats["margins"], float64 [3,H,W]: per pixel, the smallest RELATIVE distance
+    of any decision the blend took for it to the point where that decision flips (see
+    `explained_pixels`):
+      [0] alpha >= 1/255       |255 alpha - 1|                 over pairs evaluated on an open pixel
+      [1] T (1 - alpha) <= 1e-4   |T' / 1e-4 - 1|              over pairs that passed the alpha test
+      [2] sigma >= 0           sigma / S, S = 0.5 (|a| dx^2 + |c| dy^2) + |b dx dy|
+                                                              (the magnitude sigma's rounding scales with)
+    An implementation whose arithmetic differs from this one by a relative eps can take a different
+    branch only at a pixel whose margin is below ~eps; everywhere else it must agree to within the
+    propagated rounding error."""
     if exp is None:
         exp = np.exp
     mu = np.asarray(means2d, dtype=dtype)
@@ -285,6 +298,7 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
     img = np.zeros((height, width, D), dtype=dtype)
     alpha_img = np.zeros((height, width), dtype=dtype)
     last = np.zeros((height, width), dtype=np.int32)
+    marg = np.full((3, height, width), np.inf) if margins else None
     n_eval = 0
     n_contrib = 0
     half, one = dtype(0.5), dtype(1.0)
@@ -302,6 +316,7 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
             C = np.zeros(px.shape + (D,), dtype=dtype)
             done = np.zeros(px.shape, dtype=bool)
             cur_last = np.zeros(px.shape, dtype=np.int32)
+            tm = np.full((3,) + px.shape, np.inf) if margins else None
             for i in range(s, e):
                 if done.all():
                     break
@@ -314,6 +329,18 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
                 ok = (~done) & (sigma >= 0) & (a >= dtype(ALPHA_MIN))
                 n_eval += int((~done).sum())
                 Tn = T * (one - a)
+                if margins:
+                    live = ~done
+                    S = half * (abs(con[g, 0]) * dx * dx + abs(con[g, 2]) * dy * dy) \
+                        + abs(con[g, 1] * dx * dy)
+                    m_a = np.abs(a * dtype(255.0) - one)
+                    m_t = np.abs(Tn / dtype(T_STOP) - one)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        m_s = np.where(S > 0, np.abs(sigma) / S, np.inf)
+                    could_count = a >= dtype(0.5 * ALPHA_MIN)     # a sigma flip only matters if alpha would count
+                    tm[0] = np.where(live, np.minimum(tm[0], m_a), tm[0])
+                    tm[1] = np.where(live & (a >= dtype(0.5 * ALPHA_MIN)), np.minimum(tm[1], m_t), tm[1])
+                    tm[2] = np.where(live & could_count, np.minimum(tm[2], m_s), tm[2])
                 stop = ok & (Tn <= dtype(T_STOP))
                 done |= stop
                 acc = ok & ~stop
@@ -327,7 +354,118 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
             img[y_lo:y_hi, x_lo:x_hi] = C
             alpha_img[y_lo:y_hi, x_lo:x_hi] = one - T
             last[y_lo:y_hi, x_lo:x_hi] = cur_last
-    return img, alpha_img, last, {"pair_evals": n_eval, "contribs": n_contrib}
+            if margins:
+                marg[:, y_lo:y_hi, x_lo:x_hi] = tm
+    stats = {"pair_evals": n_eval, "contribs": n_contrib}
+    if margins:
+        stats["margins"] = marg
+    return img, alpha_img, last, stats
+
+
+# --------------------------------------------------------------------------------------
+# classification of threshold flips (the parity gate of tests/ and smoke())
+# --------------------------------------------------------------------------------------
+# Relative slack granted to an fp32 implementation before a decision of the fp64 blend counts as
+# "could have gone the other way".  Stage tests feed the blend IDENTICAL fp32 inputs: only the
+# evaluation of sigma / exp / the running product differs (a few ulp, 1e-6 relative).  Whole-path tests
+# also carry the fp32 projection (means2d to ~1e-4 px, conics to ~1e-5 relative), which moves sigma
+# by up to ~1e-4 absolute, i.e. alpha by ~1e-4 relative.
+EPS_STAGE = dict(alpha=2e-5, T=2e-5, sigma=2e-6)
+EPS_PATH = dict(alpha=1e-3, T=1e-3, sigma=2e-5)
+
+
+def explained_pixels(margins, eps, edge_mask=None):
+    """bool [H,W]: pixels where some decision of the fp64 blend sits within `eps` (dict alpha / T /
+    sigma, relative) of flipping, or that a per-Gaussian knife edge of the projection reaches
+    (`edge_mask`, see `gaussian_edge_mask`).  A test asserts that EVERY pixel over the 1e-4
+    tolerance is one of these -- zero unexplained pixels -- and bounds how many there are."""
+    m = (margins[0] < eps["alpha"]) | (margins[1] < eps["T"]) | (margins[2] < eps["sigma"])
+    if edge_mask is not None:
+        m = m | edge_mask
+    return m
+
+
+def check_frame(got, got_alpha, ref, ref_alpha, margins, eps, edge_mask=None, tol=1e-4,
+                expected_depth=False, max_explained=0.03, what="frame"):
+    """THE forward parity gate.  got / ref [H,W,D], alphas [H,W].  Asserts
+      * every pixel whose colour, depth-sum or alpha differs by more than `tol` (1e-4 abs, the
+        north-star tolerance) is a pixel where the fp64 blend took a decision within `eps` of
+        flipping (explained_pixels) -- ZERO unexplained pixels;
+      * such could-flip pixels are at most `max_explained` of the image (the gate is not vacuous).
+    expected_depth: the last channel is depth-sum / alpha ("ED"): ED = D / alpha, so
+    |dED| <= tol (1 + |ED|) / alpha is the same 1e-4 bound on D and alpha propagated through the divide.
+    Returns a dict of statistics (for printing)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    ga, ra = np.asarray(got_alpha, dtype=np.float64), np.asarray(ref_alpha, dtype=np.float64)
+    ga, ra = ga.reshape(ga.shape[:2]), ra.reshape(ra.shape[:2])
+    d = np.abs(got - ref)
+    lim = np.full(d.shape, tol)
+    if expected_depth:
+        lim[..., -1] = tol * (1.0 + np.abs(ref[..., -1])) / np.maximum(ra, 1e-10)
+    bad = (d > lim).any(-1) | (np.abs(ga - ra) > tol)
+    ex = explained_pixels(margins, eps, edge_mask)
+    unexplained = bad & ~ex
+    excess = np.where(ex[..., None], 0.0, d / lim)
+    stats = {"over_tol": int(bad.sum()), "unexplained": int(unexplained.sum()),
+             "could_flip_frac": float(ex.mean()),
+             "max_err_nonflip": float(np.where(ex[..., None], 0.0, d[..., :got.shape[-1] - (1 if expected_depth else 0)]).max())
+             if got.shape[-1] > (1 if expected_depth else 0) else 0.0,
+             "max_err_over_tol_nonflip": float(excess.max()), "max_err": float(d.max())}
+    assert stats["unexplained"] == 0, (
+        f"{what}: {stats['unexplained']} pixels differ from the oracle by more than {tol:g} without any "
+        f"threshold within eps of flipping (first at {tuple(np.argwhere(unexplained)[0])}); {stats}")
+    assert stats["could_flip_frac"] <= max_explained, f"{what}: gate is vacuous: {stats}"
+    return stats
+
+
+def gaussian_edge_mask(p, opacities, width, height, tile_size=16, eps_radius=3e-5, d_mu=1e-3,
+                       eps_alpha=1e-3, near_plane=0.01, far_plane=1e10):
+    """bool [H,W]: pixels that a Gaussian reaches with alpha >= (1 - eps_alpha)/255 inside a tile
+    whose membership in that Gaussian's tile rectangle depends on a knife edge of A.2 steps 2-5/7:
+    3 sqrt(lambda) within eps_radius (relative) of an integer (the ceil), mean2d +- radius within
+    d_mu pixels of a tile boundary or of the screen-cull limits, depth within 1e-5 relative of the
+    near / far plane.  `p` is the dict `project` returned ("lam" included)."""
+    mask = np.zeros((height, width), dtype=bool)
+    tw, th = -(-width // tile_size), -(-height // tile_size)
+    v = 3.0 * np.sqrt(p["lam"])
+    z, mu = p["z"], p["mu"]
+    r = np.ceil(v)
+    fr = v - np.floor(v)
+    tol = eps_radius * np.maximum(v, 1.0) + 1e-6
+    r_lo = np.where((fr > 0) & (fr < tol), r - 1, r)            # v barely above an integer: ceil may drop
+    r_hi = np.where((1.0 - fr < tol) | (fr == 0), r + 1, r)     # v barely below one: ceil may rise
+    zin = (z >= near_plane * (1 + 1e-5)) & (z <= far_plane * (1 - 1e-5)) & p["det_ok"]
+    zout = (z >= near_plane * (1 - 1e-5)) & (z <= far_plane * (1 + 1e-5)) & p["det_ok"]
+
+    def rect(rr, grow):
+        d = d_mu if grow else -d_mu
+        x0 = np.clip(np.floor((mu[:, 0] - rr - d) / tile_size), 0, tw)
+        x1 = np.clip(np.ceil((mu[:, 0] + rr + d) / tile_size), 0, tw)
+        y0 = np.clip(np.floor((mu[:, 1] - rr - d) / tile_size), 0, th)
+        y1 = np.clip(np.ceil((mu[:, 1] + rr + d) / tile_size), 0, th)
+        on = ~((mu[:, 0] + rr + d <= 0) | (mu[:, 0] - rr - d >= width)
+               | (mu[:, 1] + rr + d <= 0) | (mu[:, 1] - rr - d >= height)) & (rr > 0)
+        return x0.astype(int), x1.astype(int), y0.astype(int), y1.astype(int), on
+    ix0, ix1, iy0, iy1, ion = rect(r_lo, False)
+    ox0, ox1, oy0, oy1, oon = rect(r_hi, True)
+    ion &= zin
+    oon &= zout
+    ix0, ix1, iy0, iy1 = (np.where(ion, a, 0) for a in (ix0, ix1, iy0, iy1))
+    unsure = oon & ((ox0 != ix0) | (ox1 != ix1) | (oy0 != iy0) | (oy1 != iy1) | ~ion)
+    con, opa = p["conics_all"], np.asarray(opacities, dtype=np.float64)
+    for g in np.nonzero(unsure)[0]:
+        for ty in range(oy0[g], oy1[g]):
+            for tx in range(ox0[g], ox1[g]):
+                if ion[g] and ix0[g] <= tx < ix1[g] and iy0[g] <= ty < iy1[g]:
+                    continue
+                ys = np.arange(ty * tile_size, min((ty + 1) * tile_size, height)) + 0.5
+                xs = np.arange(tx * tile_size, min((tx + 1) * tile_size, width)) + 0.5
+                dy, dx = np.meshgrid(mu[g, 1] - ys, mu[g, 0] - xs, indexing="ij")
+                sig = 0.5 * (con[g, 0] * dx * dx + con[g, 2] * dy * dy) + con[g, 1] * dx * dy
+                a = np.minimum(ALPHA_MAX, opa[g] * np.exp(-sig))
+                hit = a >= (1.0 - eps_alpha) * ALPHA_MIN
+                mask[ty * tile_size:ty * tile_size + len(ys), tx * tile_size:tx * tile_size + len(xs)] |= hit
+    return mask, int(unsure.sum())
 
 
 # --------------------------------------------------------------------------------------
@@ -336,10 +474,11 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
 def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, height,
            sh_degree=None, tile_size=16, render_mode="RGB", eps2d=0.3,
            near_plane=0.01, far_plane=1e10, radius_clip=0.0, background=None,
-           rasterize_mode="classic", dtype=np.float64):
+           rasterize_mode="classic", dtype=np.float64, margins=False):
     """Full single-camera frame following SURVEY.md A.1/A.2.  Inputs are post-activation
     (scales = exp(log_s), opacities = sigmoid(logit)).  Returns (colors[H,W,D],
-    alpha[H,W,1], meta)."""
+    alpha[H,W,1], meta).  margins=True adds meta["margins"] (see `rasterize`) and
+    meta["edge_mask"] / meta["n_edge_gaussians"] (see `gaussian_edge_mask`)."""
     tile_w = -(-width // tile_size)
     tile_h = -(-height // tile_size)
     p = project(means, quats, scales, viewmat, K, width, height, eps2d, near_plane,
@@ -370,11 +509,15 @@ def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, hei
         bg = np.asarray(background, dtype=dtype)
     img, alpha, last, stats = rasterize(p["means2d"], p["conics"], feats, opac,
                                         flatten_ids, offs, width, height, tile_size,
-                                        bg, dtype)
+                                        bg, dtype, margins=margins)
     if render_mode in ("ED", "RGB+ED"):
         img = img.copy()
         img[..., -1] = img[..., -1] / np.maximum(alpha, dtype(1e-10))
     meta = dict(p)
+    if margins:
+        em, n_edge = gaussian_edge_mask(p, opac, width, height, tile_size,
+                                        near_plane=near_plane, far_plane=far_plane)
+        meta.update(edge_mask=em, n_edge_gaussians=n_edge)
     meta.update(tiles_per_gauss=tpg, isect_ids=isect_ids, flatten_ids=flatten_ids,
                 isect_offsets=offs, last_ids=last, colors=rgb, opacities=opac,
                 tile_width=tile_w, tile_height=tile_h, n_isect=len(flatten_ids),

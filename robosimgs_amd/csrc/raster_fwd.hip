@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
-    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull) {
+    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last) {
   constexpr int kWgWaves = TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES;
   __shared__ QueueEntry<CHT> queues[kWgWaves][kQueue + 1];
   QueueEntry<CHT>* queue = queues[threadIdx.x >> 6];
@@ -240,11 +240,17 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     const int x = ix + 8 * (k & 1), y = iy + 8 * (k >> 1);
     if (x < width && y < height) {
       const size_t p = (size_t)y * width + x;
+      const float alpha = 1.0f - fabsf(st[k].T);
+      // "ED": the last channel (depth sum) leaves as the expected depth, A.2 step 9
+      const float inv_alpha = expected_last ? 1.0f / fmaxf(alpha, 1e-10f) : 1.0f;
 #pragma unroll
       for (int c = 0; c < CHT; ++c)
-        if (c < channels)
-          render[p * channels + c] = st[k].C[c] + (background ? fabsf(st[k].T) * background[c] : 0.f);
-      alphas[p] = 1.0f - fabsf(st[k].T);
+        if (c < channels) {
+          float v = st[k].C[c] + (background ? fabsf(st[k].T) * background[c] : 0.f);
+          if (c == channels - 1) v *= inv_alpha;
+          render[p * channels + c] = v;
+        }
+      alphas[p] = alpha;
       if (TRACK_LAST) last_ids[p] = st[k].last;
     }
   }
@@ -274,8 +280,8 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
                                  const float* feats, const float* opacities, const float* splats,
                                  const float* background, int channels, int width, int height,
                                  int tile_w, int tile_h, const int32_t* tile_offsets,
-                                 const int32_t* flatten_ids, float* render, float* alphas,
-                                 int32_t* last_ids, mgs_stream_t stream) {
+                                 const int32_t* flatten_ids, int flags, float* render,
+                                 float* alphas, int32_t* last_ids, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_fwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
@@ -290,7 +296,8 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
                      dim3(64 * ((T) ? 1 : MGS_RASTER_WG_WAVES)), 0, s, means2d, conics,           \
                      feats, opacities, reinterpret_cast<const float4*>(splats), background,     \
                      channels, width, height, tile_w, n_tiles,                                 \
-                     tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull)
+                     tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull,            \
+                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0)
 #define MGS_RF_LAUNCH(C) do { if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)
   if (channels == 1) MGS_RF_LAUNCH(1);
   else if (channels == 2) MGS_RF_LAUNCH(2);

@@ -54,7 +54,7 @@ class _RenderSH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds,
                 width, height, sh_degree, eps2d, near_plane, far_plane, radius_clip,
-                antialiased, with_depth, isect_capacity, absgrad, meta_out, tight):
+                antialiased, with_depth, isect_capacity, absgrad, meta_out, tight, expected_depth):
         C = viewmats.shape[0]
         dev = means.device
         tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
@@ -84,13 +84,17 @@ class _RenderSH(torch.autograd.Function):
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
                                   out=(render[c], alphas[c], last_ids[c] if training else None),
-                                  splats=splats)
+                                  splats=splats, expected_last=expected_depth)
             per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl, splats))
         ctx.per_cam = per_cam
         ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks,
                               backgrounds, alphas, last_ids)
         ctx.cfg = (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
                    absgrad)
+        # "RGB+ED": the kernel's epilogue divided the depth channel by max(alpha, 1e-10); the
+        # backward undoes that with the saved frame (training with expected depth is the rare case)
+        ctx.expected_depth = bool(expected_depth)
+        ctx.render_out = render if (expected_depth and training) else None
         meta_out["per_cam"] = per_cam
         ctx.meta_out = meta_out
         return render, alphas.unsqueeze(-1)
@@ -104,6 +108,13 @@ class _RenderSH(torch.autograd.Function):
         C, n = viewmats.shape[0], means.shape[0]
         v_render = _f32c(v_render)
         v_alphas = _f32c(v_alphas).reshape(C, height, width)
+        if ctx.expected_depth:
+            # ED = D / max(alpha, 1e-10):  dL/dD = v_ED / a;  dL/dalpha += -v_ED * ED / a  (a > 1e-10)
+            a = alphas.clamp(min=1e-10)
+            v_ed = v_render[..., -1]
+            v_alphas = v_alphas - torch.where(alphas > 1e-10, v_ed * ctx.render_out[..., -1] / a,
+                                              torch.zeros_like(a))
+            v_render = torch.cat([v_render[..., :-1], (v_ed / a).unsqueeze(-1)], dim=-1)
         # the first camera overwrites the outputs, later ones accumulate: no zero-fill pass
         v_means = torch.empty_like(means)
         v_quats = torch.empty_like(quats)
@@ -149,7 +160,7 @@ class _RenderSH(torch.autograd.Function):
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[7]:
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 13
+        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 14
 
 
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
@@ -214,7 +225,7 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height,
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store,
-            tile_bounds == "tight")
+            tile_bounds == "tight", render_mode == "RGB+ED")
         per_cam = store.pop("per_cam")
 
         def _stk(xs):                 # no copy for the common single-camera call
@@ -262,9 +273,9 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
         meta.update(radii=radii, means2d=means2d, depths=depths, conics=conics, opacities=opac,
                     tiles_per_gauss=tpg, isect_ids=isect_ids, flatten_ids=flatten_ids,
                     isect_offsets=offsets)
-    if render_mode in ("ED", "RGB+ED"):
-        render = torch.cat([render[..., :-1],
-                            render[..., -1:] / alphas.clamp(min=1e-10)], dim=-1)
+        if render_mode in ("ED", "RGB+ED"):      # operator path (explicit features): divide here
+            render = torch.cat([render[..., :-1],
+                                render[..., -1:] / alphas.clamp(min=1e-10)], dim=-1)
     return render, alphas, meta
 
 

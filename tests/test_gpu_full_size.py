@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import cpu_ref
+from oracle import gs_oracle_np as O
 from robosimgs_amd import camera_ring, synthetic_scene
 
 pytestmark = pytest.mark.gpu
@@ -40,13 +41,15 @@ def test_config2_matches_cpu_port_and_survey_counts(config2):
     n_isect = int(meta["n_isects"][0])
     assert int((meta["radii"] > 0).sum()) == 764_945                 # SURVEY.md 8(d) calibration
     assert abs(n_isect - 5_019_708) <= 100                           # fp32 vs fp64 knife edges
-    ref, ra, info = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
-                                   cam.viewmat(), cam.K, 1920, 1080, 3)
-    assert abs(info["n_isect"] - n_isect) <= 100
-    d = np.abs(c[0].cpu().numpy() - ref).max(-1)
-    da = np.abs(a[0, ..., 0].cpu().numpy() - ra)
-    bad = (d > 1e-4) | (da > 1e-4)                                   # north-star tolerance
-    assert bad.mean() <= 5e-4, f"{bad.sum()} of {bad.size} pixels (max {d.max():.2e})"
+    # the fp64 instantiation of the C++ port is the reference answer; it also says where a branch of
+    # the blend (or a knife edge of the projection) came within O.EPS_PATH of flipping.  Every pixel
+    # over the north-star tolerance must be one of those: zero unexplained pixels out of 2 M.
+    ref, ra, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                       cam.viewmat(), cam.K, 1920, 1080, 3)
+    assert abs(info["n_isect"] - 5_019_708) <= 2 and abs(info["n_isect"] - n_isect) <= 100   # (fp32-rounded camera)
+    st = O.check_frame(c[0].cpu().numpy(), a[0].cpu().numpy(), ref, ra, info["margins"], O.EPS_PATH,
+                       info["edge_mask"], what="configs[1]")
+    print(f"\nconfigs[1] vs fp64 port: {st}, knife-edge Gaussians {info['n_edge_gaussians']}")
     al = a[0, ..., 0]
     assert float(al.min()) >= 0.0 and float(al.max()) < 1.0
 
@@ -117,12 +120,12 @@ def test_config5_stress_matches_cpu_port():
     del ct, at, mt
     assert int((meta["radii"] > 0).sum()) == 3_797_688
     assert abs(int(meta["n_isects"][0]) - 35_799_376) <= 600
-    ref, ra, info = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
-                                   cam.viewmat(), cam.K, 3840, 2160, 3)
-    d = np.abs(c[0].cpu().numpy() - ref).max(-1)
-    da = np.abs(a[0, ..., 0].cpu().numpy() - ra)
-    bad = (d > 1e-4) | (da > 1e-4)
-    assert bad.mean() <= 5e-4, f"{bad.sum()} of {bad.size} pixels"
+    ref, ra, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                       cam.viewmat(), cam.K, 3840, 2160, 3)
+    assert abs(info["n_isect"] - 35_799_376) <= 20
+    st = O.check_frame(c[0].cpu().numpy(), a[0].cpu().numpy(), ref, ra, info["margins"], O.EPS_PATH,
+                       info["edge_mask"], what="configs[4]")
+    print(f"\nconfigs[4] vs fp64 port: {st}, knife-edge Gaussians {info['n_edge_gaussians']}")
 
 
 def test_config3_backward_directional_derivatives(config2):
