@@ -3,12 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one forward render of the 1 M-Gaussian, SH-degree-3 synthetic scene at 1920x1080
-(BASELINE.json configs[1]) per rank: projection+SH, tile binning, tile raster, all through
-the C ABI of libmgs.so, replayed as one HIP graph with the scene resident in HBM.  For N > 1
-(launched by torch.distributed.run, one process per GPU over RCCL) every rank renders its own
-camera of the ring and rank 0 gathers the finished fp32 RGB frames (config 4's collective);
-value = frames all ranks rendered / max-over-ranks time, so scaling is weak.
+N = 1 (BASELINE.json configs[1]): a step is one forward render of the 1 M-Gaussian, SH-degree-3
+synthetic scene at 1920x1080 in the mode the north star describes -- RGB + expected depth + alpha
+(`render_mode="RGB+ED"`): projection+SH, tile binning, tile raster, all through the C ABI of
+libmgs.so, replayed as one HIP graph with the scene resident in HBM.
+
+N > 1 (configs[3]; launched by torch.distributed.run, one process per GPU over RCCL): a step is one
+pass over the 64-camera novel-view ring theta_k = 2 pi k / 64; rank r renders the contiguous block
+shard_cameras(64, N, r) through its FrameRenderer and rank 0 gathers all 64 finished frames (fp32
+RGB + depth + alpha by default, `--gather-dtype u8` for the 8-bit images a dataset writer stores).
+Total work is fixed as N grows: scaling is "strong"; value = frames all ranks rendered / time.
+
+Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks; regions are repeated until
+0.5 s have been timed (a single 20-frame region is 7 ms: too short to be stable) and the MEDIAN
+region gives ms_per_step and value.
 
 Rank 0 prints ONE JSON line.  Beside the contract fields it carries
   roofline      tile-raster forward kernel: algorithmic bytes / HIP-event time vs 8 TB/s
@@ -33,10 +42,13 @@ sys.path.insert(0, ROOT)
 
 from robosimgs_amd import camera_ring, synthetic_scene  # noqa: E402
 from robosimgs_amd import ops  # noqa: E402
+from robosimgs_amd.distributed import shard_cameras  # noqa: E402
 from robosimgs_amd.rendering import rasterization  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
-RASTER_PMC_TRAFFIC_BYTES = 315_551_744   # 2 x FETCH_SIZE + WRITE_SIZE of raster_fwd_kernel<3,false>, config 2 (profiles/r1/11)
+MODE = "RGB+ED"                # what splatfacto renders and INTEGRATION.md tells users to call
+RING = 64                      # configs[3]: 64 novel-view cameras
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def parse():
@@ -50,13 +62,13 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--bwd-steps", type=int, default=30)
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step region until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    # N > 1: what rank 0 collects.  "u8" (default) = the 8-bit images a dataset writer stores,
-    # quantised on the device inside the timed region ("or gather uint8 RGB"); "fp32" =
-    # the raw renders, 4x the bytes (7 x 24.9 MB per step into rank 0 at 8 ranks: about one frame time
-    # of xGMI bandwidth).  The render itself is fp32 either way.
-    ap.add_argument("--gather-dtype", choices=("fp32", "u8"), default="u8")
+    # N > 1: what rank 0 collects.  "fp32" (default) = the raw renders, RGB + depth + alpha, 41.5 MB per
+    # frame (332 MB per rank and pass at 8 ranks); "u8" = the 8-bit RGB images a dataset
+    # writer stores, quantised on the device inside the timed region (6.2 MB per frame).
+    ap.add_argument("--gather-dtype", choices=("fp32", "u8"), default="fp32")
     ap.add_argument("--gather-batch", type=int, default=4, help="frames per collective (N > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
@@ -64,7 +76,7 @@ def parse():
     # debugging aid for the N > 1 control flow on a single-GPU box: all ranks share cuda:0 and the
     # collectives run over gloo with host staging.  Never used for a reported number.
     ap.add_argument("--debug-single-device-gloo", action="store_true")
-    # debugging aid: run the gather code path in a world of one (checks the RCCL plumbing on a 1-GPU box)
+    # debugging aid: run the N > 1 leg (camera ring + gather) in a world of one
     ap.add_argument("--force-gather", action="store_true")
     return ap.parse_args()
 
@@ -96,56 +108,73 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ring = use_dist                       # the N > 1 workload: configs[3]'s camera ring
 
     W, H, deg = a.width, a.height, a.sh_degree
     scene = synthetic_scene(a.n, a.log_scale_mean, deg, seed=0)
-    theta = 0.3 + 2.0 * math.pi * rank / world
-    cam = camera_ring(1, W, H, thetas=[theta])[0]
     t = scene.to_torch(dev, deg)
-    vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)[None]
-    K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)[None]
     tile_w, tile_h = -(-W // 16), -(-H // 16)
+    # cameras: the single theta = 0.3 view of configs[1], or this rank's block of the 64-camera ring
+    if ring:
+        mine = shard_cameras(RING, world, rank)
+        thetas = [2.0 * math.pi * k / RING for k in mine]
+    else:
+        mine = range(1)
+        thetas = [0.3]
+    cams = camera_ring(len(thetas), W, H, thetas=thetas) if thetas else []
+    sizing_cam = camera_ring(1, W, H, thetas=[0.3])[0]
 
-    def forward(cap=None, bounds="tight"):
+    def cam_tensors(c):
+        return (torch.from_numpy(c.viewmat().astype(np.float32)).to(dev)[None],
+                torch.from_numpy(c.K.astype(np.float32)).to(dev)[None])
+
+    vm, K = cam_tensors(sizing_cam)
+
+    def forward(vm_, K_, cap=None, bounds="tight"):
         return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
-                             vm, K, W, H, sh_degree=deg, render_mode="RGB", isect_capacity=cap,
+                             vm_, K_, W, H, sh_degree=deg, render_mode=MODE, isect_capacity=cap,
                              tile_bounds=bounds)
 
     # sizing passes (read n_isect back, outside every timed region).  n_isect is the classic
-    # mean +- radius count SURVEY.md 8(d) calibrates (5,019,7xx at config 2) and the algorithmic
-    # bytes are priced on; the frames run on the tightened lists (n_isect_binned, same image).
-    colors, alphas, meta = forward(bounds="classic")
+    # mean +- radius count SURVEY.md 8(d) calibrates (5,019,7xx at config 2); the frames run on the
+    # tightened lists (n_isect_binned, bit-identical image), so both are reported and priced.
+    colors, alphas, meta = forward(vm, K, bounds="classic")
     torch.cuda.synchronize()
     n_isect = int(meta["n_isects"][0])
     n_vis = int((meta["radii"] > 0).sum())
-    colors_t, alphas_t, meta_t = forward()
+    colors_t, alphas_t, meta_t = forward(vm, K)
     assert torch.equal(colors_t, colors) and torch.equal(alphas_t, alphas), "tight tile bounds changed the image"
     n_isect_binned = int(meta_t["n_isects"][0])
-    del colors_t, alphas_t, meta_t
-    cap = int(n_isect_binned * 1.25) + 4096
+    del colors_t, alphas_t, meta_t, colors, alphas, meta
+    need = n_isect_binned
+    for c in cams:                       # the ring's views differ: size the lists for the largest
+        v_, k_ = cam_tensors(c)
+        need = max(need, int(forward(v_, k_)[2]["n_isects"][0]))
+    cap = int(need * 1.25) + 4096
 
     # ---- forward frames through the library's FrameRenderer ---------------------------------
     # One HIP graph per in-flight slot, camera in device buffers, `inflight` independent frames
     # on their own streams: the latency-bound binning kernels of one frame run under the
-    # VALU-bound raster of another.  Every step submits one whole frame (projection + binning +
-    # raster) and the timed region ends with a full sync.
+    # VALU-bound raster of another.  Every submit is one whole frame (projection + binning +
+    # raster) and every timed region ends with a full sync.
     from robosimgs_amd import FrameRenderer, frame_to_u8
     n_fl = max(1, a.inflight)
-    fr = FrameRenderer(t, W, H, render_mode="RGB", frames_in_flight=n_fl, isect_capacity=cap)
-    vm_np, K_np = vm[0].cpu().numpy(), K[0].cpu().numpy()
+    fr = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap)
+    cam_devs = [FrameRenderer.pack_camera(*[x[0].contiguous() for x in cam_tensors(c)]) for c in cams]
     vm_dev, K_dev = vm[0].contiguous(), K[0].contiguous()
-    cam_dev = FrameRenderer.pack_camera(vm_dev, K_dev)      # one device tensor: one copy per submit
+    frames_per_step = len(cam_devs)                    # 1 at N = 1, this rank's share of the ring otherwise
 
     do_gather = use_dist and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
     g_u8 = a.gather_dtype == "u8"
     g_dtype = torch.uint8 if g_u8 else torch.float32
-    # Frames leave in batches of `gather_batch` through a double-buffered staging area: the frame
-    # is converted (u8) or copied (fp32) into its place in the batch, the slot is released at once,
-    # and every gather_batch-th frame one collective ships the whole batch -- a per-frame
-    # collective costs ~80 us of launch / stream hand-over each, a quarter of a frame time.
-    GB = max(1, a.gather_batch)
-    batch_shape = (GB, H, W, 3)
+    g_ch = 3 if g_u8 else 5                            # u8: RGB; fp32: RGB, expected depth, alpha
+    # Frames leave in batches of `gather_batch` through a double-buffered staging area: the frame is
+    # converted (u8) or copied (fp32) into its place in the batch, the slot is released at once, and
+    # every gather_batch-th frame one collective ships the whole batch -- a per-frame collective
+    # costs ~80 us of launch / stream hand-over each, a quarter of a frame time.
+    GB = max(1, min(a.gather_batch, max(1, math.ceil(RING / world)))) if ring else 1
+    batch_shape = (GB, H, W, g_ch)
     staging = [torch.empty(batch_shape, device=dev, dtype=g_dtype) for _ in range(2)] if do_gather else None
     host_staging = ([torch.empty(batch_shape, device="cpu", dtype=g_dtype) for _ in range(2)]
                     if do_gather and debug_gloo else None)          # gloo debugging mode only
@@ -154,7 +183,7 @@ def main():
         gather_bufs = [[torch.empty(batch_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
                        for _ in range(2)]
     pending = [None, None]
-    state = {"cur": 0, "fill": 0}
+    state = {"cur": 0, "fill": 0, "shipped": 0}
     tickets = []
 
     def ship():
@@ -166,6 +195,7 @@ def main():
             src = host_staging[cur]
         pending[cur] = dist.gather(src, gather_bufs[cur] if rank == 0 else None, dst=0, async_op=True)
         state["cur"], state["fill"] = cur ^ 1, 0
+        state["shipped"] += 1
 
     def retire():
         """Fetch the oldest frame; with N > 1 stage it for the (asynchronous) RCCL gather."""
@@ -178,17 +208,22 @@ def main():
                 pending[cur] = None
             if g_u8:                                   # quantise on the device, inside the timed region
                 frame_to_u8(f["colors"], f["alphas"], out=staging[cur][j].view(-1, 3))
-            else:
-                staging[cur][j].copy_(f["colors"], non_blocking=True)
+            else:                                      # RGB + depth | alpha, straight from the slot's buffers
+                staging[cur][j][..., :4].copy_(f["colors"], non_blocking=True)
+                staging[cur][j][..., 4:].copy_(f["alphas"], non_blocking=True)
             state["fill"] = j + 1
             if state["fill"] == GB:
                 ship()
         fr.release(tk)
 
-    def step(i):
+    def submit(cam_dev):
         if len(tickets) == n_fl:
             retire()
         tickets.append(fr.submit(cam_dev))
+
+    def step():
+        for cd in cam_devs:
+            submit(cd)
 
     def drain():
         while tickets:
@@ -200,20 +235,29 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
-    for i in range(a.warmup):
-        step(i)
+    def region(k_steps):
+        barrier_sync(use_dist)
+        t0 = time.perf_counter()
+        for _ in range(k_steps):
+            step()
+        drain()
+        barrier_sync(use_dist)
+        dt = time.perf_counter() - t0
+        if use_dist:                                   # MAX over ranks; every rank sees the same number
+            tt = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    for _ in range(a.warmup):
+        step()
     drain()
-    barrier_sync(use_dist)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    drain()
-    barrier_sync(use_dist)
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    regions = []
+    while True:                                        # identical trip count on every rank (dt is all-reduced)
+        regions.append(region(a.steps))
+        if sum(regions) >= a.min_seconds or len(regions) >= 400:
+            break
+    elapsed = float(np.median(regions))
     # single-frame latency (one slot, nothing else in flight), for reference
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -230,78 +274,108 @@ def main():
             assert float(gather_bufs[0][r_][0].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
     status = max(int(o[2]["isect_status"].max().item()) for o in outs)
     assert status == 0, "tile-intersection capacity overflow inside the timed region"
-    frames_per_s = world * a.steps / elapsed
+    total_frames = (RING if ring else 1) * a.steps     # all ranks together, per region
+    frames_per_s = total_frames / elapsed
     ms_per_step = elapsed / a.steps * 1e3
 
+    if ring:
+        workload = (f"configs[3]: {a.n} Gaussians, SH degree {deg}, {RING} novel-view cameras {W}x{H} "
+                    f"(theta_k = 2 pi k / {RING}), sharded {math.ceil(RING / world)} views per GPU over "
+                    f"{world} GPU(s), RCCL gather to rank 0; one step = one pass over the ring")
+    else:
+        workload = (f"configs[1]: {a.n} Gaussians, SH degree {deg}, {W}x{H} forward render "
+                    f"(render_mode {MODE}: RGB + expected depth + alpha), one camera per step")
+    nccl_ver = None
+    if use_dist and not debug_gloo:
+        try:
+            nccl_ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            nccl_ver = "unknown"
     result = {
         "metric": "frames/sec + ms/frame (fwd, fwd+bwd) at 1M Gaussians 1920x1080",
         "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {a.n} Gaussians, SH degree {deg}, {W}x{H} forward "
-                               "render, one camera per GPU",
+        "scaling": "strong" if ring else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "render_mode": MODE,
                    "n_gaussians": a.n, "n_visible": n_vis, "n_isect": n_isect,
                    "n_isect_binned": n_isect_binned,
-                   "tiles": tile_w * tile_h, "cameras_per_step": world,
-                   "gather": (("8-bit RGB images (frame_to_u8 on the device, inside the timed region)" if g_u8
-                               else "fp32 RGB frames") + f" to rank 0 (RCCL), {GB} frames per collective") if do_gather else "none",
+                   "tiles": tile_w * tile_h,
+                   "world_size": dist.get_world_size() if use_dist else 1, "rccl_version": nccl_ver,
+                   "frames_per_step_all_ranks": RING if ring else 1,
+                   "frames_per_step_this_rank": frames_per_step,
+                   "frames_per_rank": [len(shard_cameras(RING, world, r)) for r in range(world)] if ring else [1],
+                   "gather": ((("8-bit RGB images (frame_to_u8 on the device, inside the timed region)" if g_u8
+                                else "fp32 RGB + expected depth + alpha (20 B per pixel)")
+                               + f" to rank 0 (RCCL), {GB} frames per collective, "
+                                 f"{state['shipped']} collectives issued") if do_gather else "none"),
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
                              "frames in flight on separate HIP streams",
-                   "frames_in_flight": n_fl, "single_frame_latency_ms": round(latency_ms, 4)},
+                   "frames_in_flight": n_fl, "single_frame_latency_ms": round(latency_ms, 4),
+                   "timing": f"median of {len(regions)} regions of {a.steps} steps, each bracketed by "
+                             f"barrier + synchronize, MAX over ranks (min {min(regions) * 1e3:.2f} ms, "
+                             f"max {max(regions) * 1e3:.2f} ms per region)"},
     }
 
     if rank == 0:
+        ch = 4
         # ---- roofline of the dominant kernel (tile raster forward), HIP events on the stream
         radii, m2d, depths, con, _, feats, splats = ops.project_color_fwd_raw(
             t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W,
-            H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
+            H, 0.3, 0.01, 1e10, 0.0, False, True, want_splats=True)
         tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False,
                                  conics=con, opacities=t["opacities"])
-        # the inference variant (no last_ids), i.e. the kernel the timed frames above run
+        # the inference variant (no last_ids), 4 channels, expected-depth epilogue: the kernel the
+        # timed frames above run
         out = None
         reps = 50
-        for _ in range(5):
-            out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
-                                        tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
-                                        splats=splats)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def raster():
+            return ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
+                                         tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
+                                         splats=splats, expected_last=True)
+        for _ in range(5):
+            out = raster()
         e0.record()
         for _ in range(reps):
-            ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
-                                  tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
-                                  splats=splats)
+            raster()
         e1.record()
         torch.cuda.synchronize()
         raster_ms = e0.elapsed_time(e1) / reps
         n_px = W * H
-        algo_bytes = n_isect * 44 + n_px * 24 + tile_w * tile_h * 8     # SURVEY.md 8(d) (kept as is: the
-        # inference variant skips the 4 B/px last_ids store the formula includes)
+        # n_isect * 44 (id 4 + mean 8 + conic 12 + opacity 4 + rgb 12 + depth 4)
+        #                 + n_px * 24 (rgb 12 + depth 4 + alpha 4 + last_id 4) + tiles * 8.
+        # The contract figure prices the classic lists; the kernel walks the tightened ones and the
+        # inference variant does not store last_ids, so the bytes it really needs are fewer: both fracs.
+        algo_bytes = n_isect * 44 + n_px * 24 + tile_w * tile_h * 8
+        walked_bytes = n_isect_binned * 44 + n_px * 20 + tile_w * tile_h * 8
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
-        result["roofline"] = {"kernel": "raster_fwd_kernel<3, false>", "bound": "hbm",
+        achieved_walked = walked_bytes / (raster_ms * 1e-3) / 1e9
+        traffic, traffic_note = pmc_traffic("raster_fwd", (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3))
+        result["roofline"] = {"kernel": f"raster_fwd_kernel<{ch}, false>", "bound": "hbm",
                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4),
-                              # PMC passes cannot run inside bench.py; value measured with
-                              # scripts/pmc.sh on this kernel and workload (profiles/r1/11)
-                              "traffic": RASTER_PMC_TRAFFIC_BYTES if (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3) else None,
-                              "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes: "
-                                                "2 x 140.3 MB (gfx950 counts 128-byte requests at 64 B; calibrated "
-                                                "on this gather pattern) + 34.9 MB per launch (profiles/r1/11_pmc_final.md)",
+                              "traffic": traffic, "traffic_source": traffic_note,
                               "algorithmic_bytes": algo_bytes,
                               "kernel_ms": round(raster_ms, 4),
-                              "valu_busy_frac": 0.92,
-                              "note": "VALU-bound kernel: SQ_ACTIVE_INST_VALU = 92 % of SIMD cycles "
-                                      "(profiles/r1/11); the HBM fraction is reported as the "
-                                      "contract asks; see DESIGN.md 4.3"}
+                              "on_walked_lists": {"bytes": walked_bytes, "achieved": round(achieved_walked, 1),
+                                                  "frac": round(achieved_walked / HBM_PEAK_GBS, 4),
+                                                  "note": "n_isect_binned * 44 + n_px * 20 + tiles * 8: the "
+                                                          "tightened lists the kernel walks, no last_ids store"},
+                              "note": "VALU-bound kernel (DESIGN.md 4.3); the HBM fraction is reported as "
+                                      "the contract asks"}
 
         # the second-largest forward kernel is HBM-bound: projection + SH colour (SURVEY.md 8(d):
         # N*236 + n_vis*48 algorithmic bytes), timed the same way
+        def proj():
+            return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg,
+                                             t["colors"], vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0, False,
+                                             True, want_splats=True)
         for _ in range(5):
-            ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"],
-                                      vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
+            proj()
         e0.record()
         for _ in range(reps):
-            ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"],
-                                      vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
+            proj()
         e1.record()
         torch.cuda.synchronize()
         proj_ms = e0.elapsed_time(e1) / reps
@@ -313,6 +387,27 @@ def main():
             "algorithmic_bytes": proj_bytes, "kernel_ms": round(proj_ms, 4),
             "note": "also writes the 48-byte splat records (n_vis * 48 more bytes, not counted)"}
 
+        # binning stage (depth keys .. tile offsets) as one HIP-event interval; SURVEY.md 8(d):
+        # n_vis*20 + n_isect*12 (count + emit) + n_isect*24 (sort, ideal 1R+1W) + n_isect*8 + tiles*4
+        def binning():
+            return ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False,
+                                       conics=con, opacities=t["opacities"])
+        for _ in range(5):
+            binning()
+        e0.record()
+        for _ in range(reps):
+            binning()
+        e1.record()
+        torch.cuda.synchronize()
+        bin_ms = e0.elapsed_time(e1) / reps
+        bin_bytes = n_vis * 20 + n_isect * 44 + tile_w * tile_h * 4
+        result["roofline_binning"] = {
+            "kernels": "mgs_isect_tiles: depth keys, radix sorts, scan, emit, tile offsets", "bound": "hbm",
+            "achieved": round(bin_bytes / (bin_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(bin_bytes / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes": bin_bytes, "stage_ms": round(bin_ms, 4),
+            "note": "eager launches back to back on one stream (the frame graph replays the same kernels)"}
+
         # ---- training-step variant (configs[2]): forward + L1 + backward ------------------
         try:
             result["fwd_bwd"] = bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev)
@@ -321,25 +416,47 @@ def main():
 
         # ---- CPU baseline: the oracle's C++/OpenMP port on this box's host cores -----------
         if world == 1 and not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(scene, cam, W, H, deg, a.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(scene, sizing_cam, W, H, deg, a.cpu_seconds)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def pmc_traffic(kernel_key, standard_workload):
+    """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (scripts/pmc_traffic.sh
+    writes profiles/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 correction
+    applied).  Counter passes cannot run inside bench.py, so the number is only printed when it was
+    taken from THIS build of libmgs.so (the file records the library's build stamp) on this workload."""
+    if not standard_workload:
+        return None, "not the configs[1] workload: no PMC measurement applies"
+    try:
+        with open(PMC_FILE) as f:
+            rec = json.load(f)
+        from robosimgs_amd.csrc import build as hip_build
+        stamp = hip_build.current_stamp()
+        k = rec["kernels"][kernel_key]
+        if rec.get("stamp") != stamp:
+            return None, (f"profiles/pmc_traffic.json was measured on build {str(rec.get('stamp'))[:12]}, this is "
+                          f"{stamp[:12]}: stale, not printed (re-run scripts/pmc_traffic.sh)")
+        return int(k["traffic_bytes"]), k.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
+    except Exception as e:
+        return None, f"no PMC record ({type(e).__name__})"
+
+
 def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
     from robosimgs_amd import l1_loss
     names = ("means", "quats", "scales", "opacities", "colors")
     params = {k: t[k].detach().clone().requires_grad_(True) for k in names}
-    target = torch.rand(1, H, W, 3, device=dev, generator=torch.Generator(dev).manual_seed(1))
+    # L1 to a U(0,1) target (seed 1) on all four channels of the RGB+ED frame
+    target = torch.rand(1, H, W, 4, device=dev, generator=torch.Generator(dev).manual_seed(1))
 
     def train_step():
         for p in params.values():
             p.grad = None
         colors, alphas, meta = rasterization(params["means"], params["quats"], params["scales"],
                                              params["opacities"], params["colors"], vm, K, W, H,
-                                             sh_degree=deg, render_mode="RGB", isect_capacity=cap)
+                                             sh_degree=deg, render_mode=MODE, isect_capacity=cap)
         loss = l1_loss(colors, target)      # fused HIP L1 (== (colors - target).abs().mean())
         loss.backward()
         return loss
@@ -364,14 +481,17 @@ def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
     for _ in range(3):
         runner()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.bwd_steps):
-        runner()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.bwd_steps
-    return {"workload": "configs[2]: forward + L1 loss to U(0,1) target (seed 1) + backward",
+    times = []
+    while sum(times) < 0.5 and len(times) < 50:
+        t0 = time.perf_counter()
+        for _ in range(a.bwd_steps):
+            runner()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times)) / a.bwd_steps
+    return {"workload": f"configs[2]: forward ({MODE}) + L1 loss to U(0,1) target (seed 1) + backward",
             "ms_per_step": round(dt * 1e3, 4), "steps_per_s": round(1.0 / dt, 2),
-            "steps": a.bwd_steps, "launch": mode}
+            "steps": a.bwd_steps, "regions": len(times), "launch": mode}
 
 
 def cpu_baseline(scene, cam, W, H, deg, budget_s):
@@ -379,12 +499,14 @@ def cpu_baseline(scene, cam, W, H, deg, budget_s):
     threads = cpu_ref.max_threads()
     args = (scene.means, scene.quats, scene.scales, scene.opacities, scene.sh_coeffs,
             cam.viewmat(), cam.K, W, H, deg)
-    cpu_ref.render(*args)                                   # warm-up (page-in, thread pool)
+    kw = dict(with_depth=True)                              # RGB + depth sum + alpha, like the GPU frames
+    for _ in range(3):                                      # BASELINE.md protocol: 3 warm-ups
+        cpu_ref.render(*args, **kw)
     times = []
     t_start = time.perf_counter()
     while (time.perf_counter() - t_start) < budget_s and len(times) < 50:
         t0 = time.perf_counter()
-        _, _, info = cpu_ref.render(*args)
+        _, _, info = cpu_ref.render(*args, **kw)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     model = ""
@@ -394,9 +516,10 @@ def cpu_baseline(scene, cam, W, H, deg, budget_s):
     except Exception:
         pass
     return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} full frames of the same 1M-Gaussian 1080p workload after 1 "
-                      f"warm-up, median {med * 1e3:.1f} ms/frame; oracle/gs_cpu.cpp, OpenMP, "
-                      f"{threads} threads on {model}",
+            "sample": f"{len(times)} full frames of the same 1M-Gaussian 1080p RGB+depth+alpha workload "
+                      f"after 3 warm-ups, median {med * 1e3:.1f} ms/frame; oracle/gs_cpu.cpp (fp32 "
+                      f"instantiation), OpenMP, {threads} threads on {model}; built with g++ -O3 WITHOUT "
+                      "-march=native (the .so is compiled in the dev container and must run on any host)",
             "pair_evals": info["pair_evals"]}
 
 

@@ -67,7 +67,7 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
                want_projected=False):
     """The frame in fp64 arithmetic on the fp32 inputs the GPU gets (the full-size reference
     answer).  Returns (render[H,W,ch] f32, alpha[H,W] f32, info).  info carries
-      margins [3,H,W], edge_mask [H,W] bool, n_edge_gaussians        (margins=True; feed
+      margins [4,H,W], edge_mask [H,W] bool, n_edge_gaussians        (margins=True; feed
           oracle.gs_oracle_np.explained_pixels)
       g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opacities [N]  f64: the blend's backward
           (A.2 step 10) for upstream v_render [H,W,ch] / v_alpha [H,W]
@@ -82,7 +82,7 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
     bg = f(background) if background is not None else None
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
     cf = ctypes.c_float
-    marg = np.empty((3, height, width), np.float32) if margins else None
+    marg = np.empty((4, height, width), np.float32) if margins else None
     edge = np.empty((height, width), np.uint8) if margins else None
     n_edge = np.zeros(1, np.int64)
     bwd = v_render is not None

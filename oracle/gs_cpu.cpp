@@ -149,7 +149,7 @@ void sh_color(int deg, const float* mean, const F* campos, const float* coef, F*
 }
 
 struct Extras {            // optional outputs of the double build (all may be null)
-  float* margins = nullptr;        // [3,H,W]  alpha / T / sigma margins (inf where nothing was decided)
+  float* margins = nullptr;        // [4,H,W]  alpha / T / sigma / depth-order margins (inf where nothing was decided)
   uint8_t* edge_mask = nullptr;    // [H,W]
   long long* n_edge = nullptr;     // Gaussians with an uncertain tile rectangle
   // backward of the blend (A.2 step 10), fp64 accumulation
@@ -285,7 +285,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
   const bool want_bwd = ex.v_render != nullptr;
   const size_t n_px = (size_t)width * height;
   const float inf = std::numeric_limits<float>::infinity();
-  if (want_margins) std::fill(ex.margins, ex.margins + 3 * n_px, inf);
+  if (want_margins) std::fill(ex.margins, ex.margins + 4 * n_px, inf);
   std::vector<long long> last_idx;     // backward: list position of the last blended Gaussian, -1 if none
   std::vector<double> t_final;         // backward: final transmittance in full precision
   if (want_bwd) { last_idx.assign(n_px, -1); t_final.assign(n_px, 1.0); }
@@ -298,7 +298,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
       for (int px = tx * T; px < std::min((tx + 1) * T, width); ++px) {
         F Tr = 1, C[4] = {0, 0, 0, 0};
         const F fx = px + F(0.5), fy = py + F(0.5);
-        F m_a = inf, m_t = inf, m_s = inf;
+        F m_a = inf, m_t = inf, m_s = inf, m_z = inf, z_prev = -1;
         long long last = -1;
         for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
           const int g = ids[perm[i]];
@@ -318,6 +318,10 @@ long long render_impl(int n, const float* means, const float* quats, const float
           }
           if (sigma < 0) continue;
           if (alpha < F(1.0 / 255.0)) continue;
+          if (want_margins) {      // consecutive contributors whose depths are within rounding of a tie may swap
+            if (z_prev > 0) m_z = std::min(m_z, (s.depth - z_prev) / s.depth);
+            z_prev = s.depth;
+          }
           if (nT <= F(1e-4)) break;
           F wgt = alpha * Tr;
           for (int c = 0; c < channels; ++c) C[c] += wgt * feat[(size_t)g * channels + c];
@@ -332,6 +336,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
           ex.margins[p] = (float)m_a;
           ex.margins[n_px + p] = (float)m_t;
           ex.margins[2 * n_px + p] = (float)m_s;
+          ex.margins[3 * n_px + p] = (float)m_z;
         }
         if (want_bwd) { last_idx[p] = last; t_final[p] = (double)Tr; }
       }
@@ -460,7 +465,7 @@ extern "C" long long gs_cpu_render(int n, const float* means, const float* quats
 }
 
 // The same frame in fp64 (inputs are the fp32 arrays the GPU gets).  Optional outputs (null to skip):
-// margins [3,H,W] + edge_mask [H,W] + n_edge; blend backward given v_render [H,W,ch] / v_alpha [H,W]
+// margins [4,H,W] + edge_mask [H,W] + n_edge; blend backward given v_render [H,W,ch] / v_alpha [H,W]
 // into g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opac [N]; the projected quantities
 // o_means2d / o_conics / o_feats / o_radii.
 extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* quats,

@@ -265,7 +265,7 @@ def isect_offsets(isect_ids, n_cams, tile_w, tile_h):
 # A.2 step 9: forward blend (literal sequential loop; small cases only)
 # --------------------------------------------------------------------------------------
 def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, height,
-              tile_size=16, background=None, dtype=np.float64, exp=None, margins=False):
+              tile_size=16, background=None, dtype=np.float64, exp=None, margins=False, depths=None):
     """Per-tile front-to-back alpha compositing for ONE camera.
 
     colors [N,D]; offsets [th,tw] int32 (first sorted index per tile); the range of
@@ -275,13 +275,16 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
     global index into flatten_ids); pixels with no contribution hold range_start - 1 ...
     they hold the value `range_start` is NOT touched: we use 0 like an all-zero init.
 
-    margins=True adds stats["margins"], float64 [3,H,W]: per pixel, the smallest RELATIVE distance
+    margins=True adds stats["margins"], float64 [4,H,W]: per pixel, the smallest RELATIVE distance
     of any decision the blend took for it to the point where that decision flips (see
     `explained_pixels`):
       [0] alpha >= 1/255       |255 alpha - 1|                 over pairs evaluated on an open pixel
       [1] T (1 - alpha) <= 1e-4   |T' / 1e-4 - 1|              over pairs that passed the alpha test
       [2] sigma >= 0           sigma / S, S = 0.5 (|a| dx^2 + |c| dy^2) + |b dx dy|
                                                               (the magnitude sigma's rounding scales with)
+      [3] depth order          (z_i - z_prev) / z_i            over consecutive CONTRIBUTORS of the pixel: two
+                               Gaussians whose depths are within rounding of a tie may be sorted the other way
+                               round by an fp32 projection (needs `depths`; inf without)
     An implementation whose arithmetic differs from this one by a relative eps can take a different
     branch only at a pixel whose margin is below ~eps; everywhere else it must agree to within the
     propagated rounding error."""
@@ -298,7 +301,8 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
     img = np.zeros((height, width, D), dtype=dtype)
     alpha_img = np.zeros((height, width), dtype=dtype)
     last = np.zeros((height, width), dtype=np.int32)
-    marg = np.full((3, height, width), np.inf) if margins else None
+    marg = np.full((4, height, width), np.inf) if margins else None
+    zs = np.asarray(depths, dtype=np.float64) if depths is not None else None
     n_eval = 0
     n_contrib = 0
     half, one = dtype(0.5), dtype(1.0)
@@ -316,7 +320,8 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
             C = np.zeros(px.shape + (D,), dtype=dtype)
             done = np.zeros(px.shape, dtype=bool)
             cur_last = np.zeros(px.shape, dtype=np.int32)
-            tm = np.full((3,) + px.shape, np.inf) if margins else None
+            tm = np.full((4,) + px.shape, np.inf) if margins else None
+            z_prev = np.full(px.shape, -1.0)
             for i in range(s, e):
                 if done.all():
                     break
@@ -341,6 +346,10 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
                     tm[0] = np.where(live, np.minimum(tm[0], m_a), tm[0])
                     tm[1] = np.where(live & (a >= dtype(0.5 * ALPHA_MIN)), np.minimum(tm[1], m_t), tm[1])
                     tm[2] = np.where(live & could_count, np.minimum(tm[2], m_s), tm[2])
+                    if zs is not None:
+                        m_z = np.where(z_prev > 0, (zs[g] - z_prev) / zs[g], np.inf)
+                        tm[3] = np.where(ok, np.minimum(tm[3], m_z), tm[3])
+                        z_prev = np.where(ok, zs[g], z_prev)
                 stop = ok & (Tn <= dtype(T_STOP))
                 done |= stop
                 acc = ok & ~stop
@@ -369,17 +378,24 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
 # "could have gone the other way".  Stage tests feed the blend IDENTICAL fp32 inputs: only the
 # evaluation of sigma / exp / the running product differs (a few ulp, 1e-6 relative).  Whole-path tests
 # also carry the fp32 projection (means2d to ~1e-4 px, conics to ~1e-5 relative), which moves sigma
-# by up to ~1e-4 absolute, i.e. alpha by ~1e-4 relative.
-EPS_STAGE = dict(alpha=2e-5, T=2e-5, sigma=2e-6)
-EPS_PATH = dict(alpha=1e-3, T=1e-3, sigma=2e-5)
+# by up to ~1e-4 absolute, i.e. alpha by ~1e-4 relative, and depths by 2-3 ulps (2e-7 relative), which
+# can swap the order of two Gaussians whose depths are within that of a tie.  Calibration at
+# configs[1] (fp32 instantiation of the C++ port against its fp64 instantiation, 2 M pixels, 258 over
+# 1e-4): alpha = T = 1e-4 and depth = 3e-7 already explain every one of them (largest error at a
+# pixel nothing explains: 2.2e-5); the values below carry a factor ~2-3 on top and flag 1.6 % of
+# the pixels of that frame.
+EPS_STAGE = dict(alpha=2e-5, T=2e-5, sigma=2e-6, depth=0.0)
+EPS_PATH = dict(alpha=3e-4, T=3e-4, sigma=2e-5, depth=5e-7)
 
 
 def explained_pixels(margins, eps, edge_mask=None):
     """bool [H,W]: pixels where some decision of the fp64 blend sits within `eps` (dict alpha / T /
-    sigma, relative) of flipping, or that a per-Gaussian knife edge of the projection reaches
+    sigma / depth, relative) of flipping, or that a per-Gaussian knife edge of the projection reaches
     (`edge_mask`, see `gaussian_edge_mask`).  A test asserts that EVERY pixel over the 1e-4
     tolerance is one of these -- zero unexplained pixels -- and bounds how many there are."""
     m = (margins[0] < eps["alpha"]) | (margins[1] < eps["T"]) | (margins[2] < eps["sigma"])
+    if len(margins) > 3:
+        m = m | (margins[3] < eps.get("depth", 0.0))
     if edge_mask is not None:
         m = m | edge_mask
     return m
@@ -509,7 +525,7 @@ def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, hei
         bg = np.asarray(background, dtype=dtype)
     img, alpha, last, stats = rasterize(p["means2d"], p["conics"], feats, opac,
                                         flatten_ids, offs, width, height, tile_size,
-                                        bg, dtype, margins=margins)
+                                        bg, dtype, margins=margins, depths=p["depths"] if margins else None)
     if render_mode in ("ED", "RGB+ED"):
         img = img.copy()
         img[..., -1] = img[..., -1] / np.maximum(alpha, dtype(1e-10))

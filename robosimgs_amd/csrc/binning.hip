@@ -158,6 +158,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
   __shared__ uint32_t ws[kScanThreads / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t running = 0;
+  bool wrapped = false;            // the uint32 total overflowed: report it, the lists are not usable
   for (uint32_t b0 = 0; b0 < nblk; b0 += kScanThreads * kScanPerThread) {
     const uint32_t b = b0 + threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread], sum = 0;
@@ -186,11 +187,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
       if (b + j < nblk) blocksums[b + j] = ex;
       ex += v[j];
     }
+    wrapped |= running + tot < running;
     running += tot;
   }
   if (threadIdx.x == 0 && n_isect) {
-    *n_isect = running;
-    *status = running > capacity ? MGS_STATUS_ISECT_OVERFLOW : 0u;   // this call's result: no zero-fill needed
+    *n_isect = wrapped ? 0xffffffffu : running;
+    *status = (wrapped || running > capacity) ? MGS_STATUS_ISECT_OVERFLOW : 0u;   // this call's result: no zero-fill needed
   }
 }
 

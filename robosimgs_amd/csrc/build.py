@@ -45,6 +45,12 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
+def current_stamp() -> str:
+    """Hash of the sources, headers and flags libmgs.so is built from (bench.py keys measured PMC
+    traffic to it, so a number taken on another build is never printed)."""
+    return _stamp()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     stamp_file = os.path.join(OBJ_DIR, "stamp")
     stamp = _stamp()

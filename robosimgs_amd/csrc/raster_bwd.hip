@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES) void raster_bwd_kerne
     float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
     float* __restrict__ v_feats, float* __restrict__ v_opacities,
     const int4* __restrict__ pair_info, float* __restrict__ records,
-    uint8_t* __restrict__ flags) {
+    uint8_t* __restrict__ flags, uint32_t capacity) {
   __shared__ BwdEntry<CHT> queues[MGS_RASTER_BWD_WG_WAVES][kQueue];
   __shared__ float reds[MGS_RASTER_BWD_WG_WAVES][RECORDS ? 8 : 1][64];   // wave-private transpose buffer of the record reduction
   BwdEntry<CHT>* queue = queues[threadIdx.x >> 6];
@@ -247,6 +247,9 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES) void raster_bwd_kerne
       }
       if (__ballot(any) == 0ull) continue;
       if constexpr (RECORDS) {
+        // overflowed tile lists (status word set by the binning): slot bases run up to the true
+        // n_isect, the workspace only to the capacity -- nothing is written past it
+        if ((uint32_t)gid >= capacity) continue;
         // reduce-scatter butterfly: 8 values at a time, totals land in 8 lanes that store the
         // record slice with one instruction
         constexpr int NV = 6 + CHT + (ABSGRAD ? 2 : 0);
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES) void raster_bwd_kerne
 template <int CHT, bool ABSGRAD>
 __global__ __launch_bounds__(256) void reduce_records_kernel(
     int n, const int4* __restrict__ pair_info, const float* __restrict__ records,
-    const uint8_t* __restrict__ flags, const float* __restrict__ conics,
+    const uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ conics,
     const float4* __restrict__ splats, int channels, float* __restrict__ v_means2d,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
     float* __restrict__ v_feats, float* __restrict__ v_opacities) {
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   for (int sl = 0; sl < cnt; sl += 4) {
     bool on[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) on[i] = sl + i < cnt && flags[(size_t)info.x + sl + i] != 0;
+    for (int i = 0; i < 4; ++i)      // slots at or past the capacity do not exist (overflowed lists)
+      on[i] = sl + i < cnt && (uint32_t)(info.x + sl + i) < capacity && flags[(size_t)info.x + sl + i] != 0;
     float r[4][6], rf[4][CHT], ra[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -434,7 +438,7 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
                      width, height, tile_w,                                                    \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities,                 \
-                     (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr)
+                     (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr, 0u)
 #define MGS_RB(C) if (v_means2d_abs) MGS_RB_LAUNCH(C, true); else MGS_RB_LAUNCH(C, false)
   if (channels == 1) { MGS_RB(1); }
   else if (channels == 2) { MGS_RB(2); }
@@ -494,9 +498,10 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                      background, channels, width, height, tile_w,                              \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
-                     (float*)nullptr, info, records, flags);                                   \
+                     (float*)nullptr, info, records, flags, (uint32_t)cap);                    \
   hipLaunchKernelGGL((reduce_records_kernel<C, A>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
-                     info, records, flags, conics, reinterpret_cast<const float4*>(splats),    \
+                     info, records, flags, (uint32_t)cap, conics,                              \
+                     reinterpret_cast<const float4*>(splats),                                  \
                      channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities)
 #define MGS_RD(C) if (v_means2d_abs) { MGS_RD_LAUNCH(C, true); } else { MGS_RD_LAUNCH(C, false); }
   if (channels == 1) { MGS_RD(1) }

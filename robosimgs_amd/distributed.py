@@ -109,7 +109,7 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
                                           Ks[sel], width, height,
                                           sh_degree=tensors.get("sh_degree"), **kw)
     else:
-        d = 3 if kw.get("render_mode", "RGB") == "RGB" else 4
+        d = {"RGB": 3, "D": 1, "ED": 1}.get(kw.get("render_mode", "RGB"), 4)   # RGB+D / RGB+ED: 4
         colors = torch.zeros(0, height, width, d, device=viewmats.device)
         alphas = torch.zeros(0, height, width, 1, device=viewmats.device)
     if as_u8:

@@ -182,9 +182,11 @@ def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, heig
 
 def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                           tile_h, tl: "TileLists", alphas, last_ids, v_render, v_alphas,
-                          absgrad=False, splats=None):
+                          absgrad=False, splats=None, canary_bytes=0):
     """Atomic-free, bit-reproducible raster backward (needs tl.pair_info from the binning).
-    Returns freshly written (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None)."""
+    Returns freshly written (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None).
+    canary_bytes (tests): that many 0xA5 bytes are kept behind the workspace the library asked for
+    and returned as a sixth value, so a test can see that nothing was written past the workspace."""
     n = means2d.shape[0]
     ch = feats.shape[-1]
     dev = means2d.device
@@ -201,10 +203,12 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det(size query)")
-    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-    nbytes = ctypes.c_size_t(ws.numel())
+    ws = torch.full((nbytes.value + canary_bytes,), 0xA5, dtype=torch.uint8, device=dev) if canary_bytes \
+        else torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
     check(L.mgs_rasterize_bwd_det(*args, ptr(ws), ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det")
+    if canary_bytes:
+        return v_means2d, v_conics, v_feats, v_opac, v_abs, ws[nbytes.value:]
     return v_means2d, v_conics, v_feats, v_opac, v_abs
 
 

@@ -87,14 +87,15 @@ class _RenderSH(torch.autograd.Function):
                                   splats=splats, expected_last=expected_depth)
             per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl, splats))
         ctx.per_cam = per_cam
+        # "RGB+ED": the kernel's epilogue divided the depth channel by max(alpha, 1e-10); the
+        # backward undoes that with the saved frame (an OUTPUT: it must go through
+        # save_for_backward -- parked on ctx it forms a reference cycle that crashes HIP graph capture)
+        ctx.expected_depth = bool(expected_depth)
         ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks,
-                              backgrounds, alphas, last_ids)
+                              backgrounds, alphas, last_ids,
+                              render if (expected_depth and training) else None)
         ctx.cfg = (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
                    absgrad)
-        # "RGB+ED": the kernel's epilogue divided the depth channel by max(alpha, 1e-10); the
-        # backward undoes that with the saved frame (training with expected depth is the rare case)
-        ctx.expected_depth = bool(expected_depth)
-        ctx.render_out = render if (expected_depth and training) else None
         meta_out["per_cam"] = per_cam
         ctx.meta_out = meta_out
         return render, alphas.unsqueeze(-1)
@@ -102,7 +103,7 @@ class _RenderSH(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alphas):
         (means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds, alphas,
-         last_ids) = ctx.saved_tensors
+         last_ids, render_out) = ctx.saved_tensors
         (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
          absgrad) = ctx.cfg
         C, n = viewmats.shape[0], means.shape[0]
@@ -112,7 +113,7 @@ class _RenderSH(torch.autograd.Function):
             # ED = D / max(alpha, 1e-10):  dL/dD = v_ED / a;  dL/dalpha += -v_ED * ED / a  (a > 1e-10)
             a = alphas.clamp(min=1e-10)
             v_ed = v_render[..., -1]
-            v_alphas = v_alphas - torch.where(alphas > 1e-10, v_ed * ctx.render_out[..., -1] / a,
+            v_alphas = v_alphas - torch.where(alphas > 1e-10, v_ed * render_out[..., -1] / a,
                                               torch.zeros_like(a))
             v_render = torch.cat([v_render[..., :-1], (v_ed / a).unsqueeze(-1)], dim=-1)
         # the first camera overwrites the outputs, later ones accumulate: no zero-fill pass
@@ -249,6 +250,13 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             meta["means2d"] = meta["means2d"].detach().requires_grad_(True)   # see _RenderSH.backward
     else:
         # feature path: colours are given per Gaussian (or evaluated from SH for "D"/"ED")
+        if isect_capacity is not None:
+            # this path sizes its lists by reading the intersection count back (as the reference
+            # operator does), so it can neither honour a fixed capacity nor be captured in a graph
+            raise NotImplementedError(
+                "isect_capacity (read-back-free, graph-capturable frames) is only available on the "
+                "SH colour path (sh_degree given and an RGB render mode); render 'RGB+D' / 'RGB+ED' "
+                "and take the depth channel, or drop isect_capacity")
         radii, means2d, depths, conics, comps = ops.fully_fused_projection(
             means, None, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
             radius_clip, calc_compensations=antialiased)

@@ -7,6 +7,7 @@ from robosimgs_amd import synthetic_scene, camera_ring, ops
 stage = sys.argv[1] if len(sys.argv) > 1 else "raster"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n, mu, W, H, deg = int(os.environ.get("N", 1_000_000)), float(os.environ.get("MU", 0.012)), int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080)), 3
+CH = int(os.environ.get("CH", 4))      # 4 = RGB + depth (the headline "RGB+ED" frames), 3 = RGB
 dev = "cuda"
 g = synthetic_scene(n, math.log(mu), deg, 0)
 cam = camera_ring(1, W, H, thetas=[0.3])[0]
@@ -15,7 +16,7 @@ vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)
 K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)
 tw, th = -(-W // 16), -(-H // 16)
 def project():
-    return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, False, want_splats=True)
+    return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, CH == 4, want_splats=True)
 radii, m2d, dep, con, _, feats, splats = project()
 TIGHT = os.environ.get("TIGHT", "1") != "0"      # tightened tile rectangles (the render path's default)
 tkw = dict(conics=con, opacities=t["opacities"]) if TIGHT else {}
@@ -23,12 +24,12 @@ tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 el
 out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats)
 torch.cuda.synchronize()
 print("n_isect", int(tl.n_isect))
-vr = torch.rand(H, W, 3, device=dev); va = torch.rand(H, W, device=dev)
+vr = torch.rand(H, W, CH, device=dev); va = torch.rand(H, W, device=dev)
 for _ in range(reps):
     if stage == "raster":
         ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out, splats=splats)
     elif stage == "raster_inf":          # the inference variant (no last_ids): the kernel bench.py times
-        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=(out[0], out[1], None), track_last=False, splats=splats)
+        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=(out[0], out[1], None), track_last=False, splats=splats, expected_last=CH == 4)
     elif stage == "raster_bwd":
         ops.rasterize_bwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out[1], out[2], vr, va)
     elif stage == "raster_bwd_det":
@@ -37,7 +38,7 @@ for _ in range(reps):
         from robosimgs_amd.rendering import rasterization
         ps = {k: t[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
         c, a_, _ = rasterization(ps["means"], ps["quats"], ps["scales"], ps["opacities"], ps["colors"], vm[None], K[None], W, H, sh_degree=deg, isect_capacity=8_000_000, tile_bounds="tight" if TIGHT else "classic")
-        (c - vr[None]).abs().mean().backward()
+        (c - vr[None, ..., :3]).abs().mean().backward()
     elif stage == "binning":
         ops.isect_tiles_raw(m2d, radii, dep, tw, th, 8_000_000, want_tiles_per_gauss=False, **tkw)
     elif stage == "project":

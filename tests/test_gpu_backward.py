@@ -378,3 +378,29 @@ def test_deterministic_backward_many_channels(ch):
     for x, y in zip(a, d):
         scale = float(x.abs().max()) + 1e-20
         assert float((x - y).abs().max()) / scale < 1e-4
+
+
+def test_deterministic_backward_with_overflowed_lists_stays_inside_its_workspace():
+    """include/mgs.h: on a capacity overflow "nothing is written out of bounds".  The record
+    backward's slot bases run up to the TRUE n_isect; with an undersized capacity the kernels must
+    skip every slot at or past it.  Canary bytes behind the workspace must survive, and the status
+    word must say that the gradients are not to be trusted."""
+    from robosimgs_amd import ops
+    g, cam = _scene(6000, 0.12, 1, 160, 128)
+    t = g.to_torch(DEV, 1)
+    vm, K = _t(cam.viewmat()), _t(cam.K)
+    radii, m2d, dep, con, _, feats, splats = ops.project_color_fwd_raw(
+        t["means"], t["quats"], t["scales"], t["opacities"], 1, t["colors"], vm, K, 160, 128, 0.3, 0.01,
+        1e10, 0.0, False, False, want_splats=True)
+    tw, th = 10, 8
+    need = int(ops.isect_tiles_raw(m2d, radii, dep, tw, th, 1_000_000).n_isect.item())
+    for cap in (need // 3, 1000, 7):
+        tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, cap, want_pair_info=True)
+        assert int(tl.status.item()) != 0 and int(tl.n_isect.item()) == need
+        render, alphas, last = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, 160, 128, tw, th,
+                                                     tl.tile_offsets, tl.flatten_ids, splats=splats)
+        v_r, v_a = torch.randn_like(render), torch.randn_like(alphas)
+        out = ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, 160, 128, tw, th, tl, alphas,
+                                        last, v_r, v_a, splats=splats, canary_bytes=1 << 20)
+        torch.cuda.synchronize()
+        assert bool((out[5] == 0xA5).all()), f"capacity {cap}: the backward wrote past its workspace"
