@@ -2,16 +2,20 @@
 //
 // The textbook pipeline (gsplat `isect_tiles`) emits one 64-bit key (tile << 32 | depth bits)
 // per (Gaussian, tile) pair and radix-sorts all n_isect pairs on ~45 bits: six 8-bit passes
-// over 12-byte elements.  The same ordering is produced here with ~4.5x less sort traffic:
-//   1. radix-sort the N Gaussians by their 32 depth bits (culled ones keyed 0xffffffff);
-//   2. gather each Gaussian's (tile rectangle, count) into depth order and exclusive-scan the
-//      counts (total = n_isect, kept on the device);
-//   3. emit (tile, gaussian) pairs in depth order with a load-balanced search so that stores
-//      are lane-linear;
-//   4. stable radix sort on the tile bits only (13 bits at 1080p: a 7-bit and a 6-bit pass over
-//      8-byte pairs).
-// Stable sort on tile of a depth-ordered stream == stable sort on (tile, depth); ties in
-// depth keep Gaussian-index order in both formulations.
+// over 12-byte elements.  The same ordering is produced here with ~4.5x less sort traffic and
+// a third of the dependent launches of this repo's first version:
+//   1. per Gaussian: tile rectangle and tile count; exclusive scan of the counts in INDEX order
+//      (total = n_isect, kept on the device; the same scan gives the backward's record slots);
+//   2. emit (tile, gaussian) pairs in index order with a load-balanced search so that stores are
+//      lane-linear;
+//   3. stable radix sort on the tile bits only (13 bits at 1080p: a 7-bit and a 6-bit pass over
+//      8-byte pairs): every tile's list is now contiguous, in Gaussian-index order;
+//   4. first index of every tile;
+//   5. tile_sort.hip: one workgroup per tile orders its list by (depth bits, index).
+// Sorting each tile's index-ordered list by (depth, index) == the stable sort on (tile, depth)
+// with index-order ties: flatten_ids / isect_ids are bit-identical to
+// the single-key formulation.  (Round 1 sorted the N Gaussians by depth first -- twelve dependent
+// launches for 1 M keys -- and gathered their rectangles into rank order.)
 #include "mgs_common.h"
 
 namespace mgs {
@@ -83,18 +87,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
-__global__ __launch_bounds__(kBlock) void depth_key_kernel(
+// per Gaussian: tile rectangle (packed) + tile count, and the count sum of each block of kBlock
+__global__ __launch_bounds__(kBlock) void tile_count_kernel(
     int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-    const float* __restrict__ depths, const float* __restrict__ conics,
-    const float* __restrict__ opacities, float tile_size, int tile_w, int tile_h,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ ginfo,
-    int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ n_gauss_dev,
+    const float* __restrict__ conics, const float* __restrict__ opacities, float tile_size,
+    int tile_w, int tile_h, uint2* __restrict__ ginfo, int32_t* __restrict__ tiles_per_gauss,
     uint32_t* __restrict__ index_blocksums) {
   __shared__ uint32_t ws[kBlock / 64];
   int g = blockIdx.x * kBlock + threadIdx.x;
-  if (g == 0) *n_gauss_dev = (uint32_t)n;
   int radius = g < n ? radii[g] : 0;
-  uint32_t key = 0xffffffffu, cnt = 0, pack = 1u << 20;
+  uint32_t cnt = 0, pack = 1u << 20;
   if (radius > 0) {
     float2 m = reinterpret_cast<const float2*>(means2d)[g];
     TileRect r = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
@@ -103,15 +105,12 @@ __global__ __launch_bounds__(kBlock) void depth_key_kernel(
                        conics[3 * (size_t)g + 2], opacities[g], tile_size);
     cnt = (uint32_t)(r.w * r.h);
     pack = (uint32_t)r.x0 | ((uint32_t)r.y0 << 10) | ((uint32_t)max(r.w, 1) << 20);
-    key = __float_as_uint(depths[g]);
   }
   if (g < n) {
-    keys[g] = key;
-    vals[g] = (uint32_t)g;
     ginfo[g] = make_uint2(pack, cnt);     // tile rectangle (x0 | y0 << 10 | w << 20) and tile count
     if (tiles_per_gauss) tiles_per_gauss[g] = (int32_t)cnt;
   }
-  if (index_blocksums) {   // training: tile counts per block in INDEX order (slot bases of pair_info)
+  {
     const uint32_t c = wave_sum(cnt);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -121,31 +120,6 @@ __global__ __launch_bounds__(kBlock) void depth_key_kernel(
       for (int w = 0; w < kBlock / 64; ++w) sum += ws[w];
       index_blocksums[blockIdx.x] = sum;
     }
-  }
-}
-
-// sum of tile counts of the 256 depth-ranks owned by each workgroup.  With sorted_ids the
-// per-Gaussian (rectangle, count) record is gathered ONCE here and re-written in rank order, so
-// the emit pass reads it lane-linear instead of chasing ids again.
-__global__ __launch_bounds__(kBlock) void rank_blocksum_kernel(
-    int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ ginfo,
-    uint2* __restrict__ rank_info, uint32_t* __restrict__ blocksums) {
-  __shared__ uint32_t ws[kBlock / 64];
-  int r = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t c = 0;
-  if (r < n) {
-    uint2 info = ginfo[sorted_ids ? sorted_ids[r] : (uint32_t)r];
-    if (rank_info) rank_info[r] = info;
-    c = info.y;
-  }
-  c = wave_sum(c);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t sum = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) sum += ws[w];
-    blocksums[blockIdx.x] = sum;
   }
 }
 
@@ -226,22 +200,20 @@ __global__ __launch_bounds__(kBlock) void pair_info_kernel(
   }
 }
 
-// Load-balanced emit: a workgroup owns 256 consecutive depth ranks; its output range is
+// Load-balanced emit: a workgroup owns kBlock consecutive Gaussians; its output range is
 // walked lane-linearly and each slot finds its Gaussian by binary search in LDS.
 __global__ __launch_bounds__(kBlock) void emit_kernel(
-    int n, const uint32_t* __restrict__ sorted_ids, const uint2* __restrict__ rank_info,
-    int tile_w, const uint32_t* __restrict__ blockbase, uint32_t capacity,
-    uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out) {
+    int n, const uint2* __restrict__ ginfo, int tile_w, const uint32_t* __restrict__ blockbase,
+    uint32_t capacity, uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out) {
   __shared__ uint32_t prefix[kBlock + 1];
   __shared__ uint32_t gid[kBlock];
   __shared__ uint32_t rpack[kBlock];
   __shared__ uint32_t ws[kBlock / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int r = blockIdx.x * kBlock + threadIdx.x;
-  uint32_t cnt = 0, g = 0, pack = 1u << 20;
+  uint32_t cnt = 0, g = (uint32_t)r, pack = 1u << 20;
   if (r < n) {
-    g = sorted_ids[r];
-    uint2 info = rank_info[r];
+    uint2 info = ginfo[r];
     pack = info.x;
     cnt = info.y;
   }
@@ -373,20 +345,16 @@ int bits_for(uint32_t count) {   // bits needed to hold values 0..count-1
 
 struct Workspace {
   size_t total;
-  size_t keys_a, vals_a, keys_b, vals_b, ginfo, rank_info, blocksums, blocksums2, n_gauss, tile_alt, id_alt, radix;
+  size_t ginfo, blocksums, tile_alt, id_alt, radix, tsort;
   Workspace(int n, uint32_t cap) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     size_t nn = (size_t)(n > 0 ? n : 1), cc = cap ? cap : 1;
-    keys_a = take(nn * 4); vals_a = take(nn * 4); keys_b = take(nn * 4); vals_b = take(nn * 4);
     ginfo = take(nn * 8);
-    rank_info = take(nn * 8);
     blocksums = take((size_t)div_up((unsigned)nn, kBlock) * 4);
-    blocksums2 = take((size_t)div_up((unsigned)nn, kBlock) * 4);
-    n_gauss = take(4);
     tile_alt = take(cc * 4); id_alt = take(cc * 4);
-    size_t r1 = radix_sort_temp_bytes((uint32_t)nn), r2 = radix_sort_temp_bytes((uint32_t)cc);
-    radix = take(r1 > r2 ? r1 : r2);
+    radix = take(radix_sort_temp_bytes((uint32_t)cc));
+    tsort = take(tile_depth_sort_temp_bytes((uint32_t)cc));
     total = o;
   }
 };
@@ -426,7 +394,6 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(w + off); };
   const int n_tiles = tile_w * tile_h;
   const uint32_t cap = isect_capacity;
-  uint32_t* n_gauss_dev = u32(ws.n_gauss);
   int rc;
 
   if (n == 0) {
@@ -434,18 +401,10 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     (void)hipMemsetAsync(status, 0, 4, s);
   } else {
     const unsigned nblk = div_up(n, kBlock);
-    hipLaunchKernelGGL(depth_key_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii,
-                       depths, conics, opacities, (float)tile_size, tile_w, tile_h, u32(ws.keys_a),
-                       u32(ws.vals_a),
-                       reinterpret_cast<uint2*>(w + ws.ginfo), tiles_per_gauss, n_gauss_dev,
-                       pair_info ? u32(ws.blocksums2) : (uint32_t*)nullptr);
-    // 4 passes (even): the depth order ends in (keys_a, vals_a)
-    rc = radix_sort_pairs(n_gauss_dev, (uint32_t)n, 32, u32(ws.keys_a), u32(ws.vals_a),
-                          u32(ws.keys_b), u32(ws.vals_b), w + ws.radix, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(rank_blocksum_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a),
-                       reinterpret_cast<const uint2*>(w + ws.ginfo),
-                       reinterpret_cast<uint2*>(w + ws.rank_info), u32(ws.blocksums));
+    uint2* ginfo = reinterpret_cast<uint2*>(w + ws.ginfo);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii, conics,
+                       opacities, (float)tile_size, tile_w, tile_h, ginfo, tiles_per_gauss,
+                       u32(ws.blocksums));
     hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
                        u32(ws.blocksums), cap, n_isect, status);
     // tile sort: result must land in the caller's buffers
@@ -455,22 +414,22 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     uint32_t* user_i = reinterpret_cast<uint32_t*>(flatten_ids);
     uint32_t *a_t = user_t, *a_i = user_i, *b_t = u32(ws.tile_alt), *b_i = u32(ws.id_alt);
     if (passes & 1) { a_t = u32(ws.tile_alt); a_i = u32(ws.id_alt); b_t = user_t; b_i = user_i; }
-    hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, u32(ws.vals_a),
-                       reinterpret_cast<const uint2*>(w + ws.rank_info), tile_w, u32(ws.blocksums), cap,
-                       a_t, a_i);
-    if (pair_info) {   // training only: index-major slot bases (block sums come from depth_key_kernel)
-      hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
-                         u32(ws.blocksums2), cap, (uint32_t*)nullptr, (uint32_t*)nullptr);
-      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n,
-                         reinterpret_cast<const uint2*>(w + ws.ginfo), tile_h, u32(ws.blocksums2),
-                         reinterpret_cast<int4*>(pair_info));
-    }
+    hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_w,
+                       u32(ws.blocksums), cap, a_t, a_i);
+    if (pair_info)     // training only: the record slots of the backward are the same index-order scan
+      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h,
+                         u32(ws.blocksums), reinterpret_cast<int4*>(pair_info));
     rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
     if (rc) return rc;
   }
-  const unsigned gblk = div_up(cap, kBlock);
   hipLaunchKernelGGL(tile_offsets_kernel, dim3(div_up(cap, kBlock * kOffsetsPerThread)), dim3(kBlock), 0,
                      s, n_isect, cap, tile_ids, n_tiles, tile_offsets);
+  if (n > 0) {        // depth order inside every tile's list
+    rc = tile_depth_sort(n_tiles, tile_offsets, depths, cap, reinterpret_cast<uint32_t*>(flatten_ids),
+                         w + ws.tsort, s);
+    if (rc) return rc;
+  }
+  const unsigned gblk = div_up(cap, kBlock);
   if (isect_ids) {
     const int tile_bits_key = bits_for((uint32_t)n_tiles + 1);   // floor(log2(n_tiles)) + 1
     hipLaunchKernelGGL(isect_ids_kernel, dim3(gblk), dim3(kBlock), 0, s, n_isect, cap, tile_ids,

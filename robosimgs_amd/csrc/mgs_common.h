@@ -51,5 +51,11 @@ int radix_sort_pairs(const uint32_t* n_dev, uint32_t capacity, int key_bits, uin
                      uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, void* temp,
                      hipStream_t stream);
 
+// Orders flatten_ids[offsets[t] .. offsets[t+1]) of every tile by (depth bits, Gaussian id)
+// (tile_sort.hip).  temp: tile_depth_sort_temp_bytes(capacity).
+size_t tile_depth_sort_temp_bytes(uint32_t capacity);
+int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depths, uint32_t capacity,
+                    uint32_t* flatten_ids, void* temp, hipStream_t stream);
+
 }  // namespace mgs
 #endif

@@ -1,0 +1,337 @@
+// tile_sort.hip -- depth order INSIDE each tile's list, one workgroup per tile (gfx950).
+//
+// The binning partitions the (tile, Gaussian) pairs by tile with a stable radix sort on the tile
+// bits only, which leaves every tile's list in Gaussian-index order.  This kernel then sorts each
+// list by (depth bits, Gaussian index) -- exactly the order of the textbook single sort on
+// (tile << 32 | depth) with index-order ties -- so the 1 M-key global
+// depth sort (12 dependent launches) and the rank gather of the first version disappear: one
+// fully parallel launch, no cross-workgroup dependency, ~8160 independent segments of ~450 entries.
+//
+// Per segment: most-significant-digit bucketing on the 64-bit composite key (depth << 32 | id):
+//   min / max of the composites -> highest differing bit hb -> 10-bit digit (comp >> (hb - 9)) & 1023
+//   LDS histogram (atomics), exclusive scan, scatter into the other scratch buffer (bucket order,
+//   arbitrary order inside a bucket), then every element of a bucket of <= 48 entries finds its final
+//   place by counting the smaller composites of its own bucket.  Depth keys of one tile share their
+//   exponent bits, so the digit lands on the top mantissa bits and buckets hold ~1 element: O(n).
+//   A bucket of more than 48 entries (many near-identical depths) goes onto an LDS stack and is
+//   bucketed again on ITS highest differing bit (ten bits further down at least), so any input
+//   terminates in at most seven levels; composites are distinct (ids are), ties cannot loop.
+// Lists of up to kFast entries (nearly all of them) take the fast path: ids and gathered depth keys
+// stay in registers through the histogram and the scatter, the scattered list sits in LDS, and the
+// only global traffic is the id load, the depth gather and the final store.  Longer lists, and the
+// heavy buckets of any list, run the generic loop whose elements live in two global scratch buffers
+// (L2-resident for the workgroup) -- only the 1024 counters are in LDS, so any length is handled.
+#include "mgs_common.h"
+
+namespace mgs {
+namespace {
+
+constexpr int kTS = 256;            // threads per tile
+constexpr int kBuckets = 1024;
+constexpr int kSmall = 48;          // buckets up to this size are finished by rank counting
+constexpr int kStack = 96;          // pending heavy buckets; beyond it a bucket is rank-counted whatever its size
+constexpr int kFast = 2048;         // longest list of the LDS-resident fast path
+constexpr int kItems = kFast / kTS;
+constexpr uint32_t kBrute = 0x80000000u;
+
+__device__ __forceinline__ bool comp_less(uint32_t ka, uint32_t ia, uint32_t kb, uint32_t ib) {
+  return ka < kb || (ka == kb && ia < ib);
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int d) {
+  unsigned lo = __shfl_xor((unsigned)v, d), hi = __shfl_xor((unsigned)(v >> 32), d);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// exclusive scan of one value per thread over the workgroup; *total = sum
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(incl, d);
+    if (lane >= (unsigned)d) incl += t;
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kTS / 64; ++w) {
+    uint32_t s = wave_sums[w];
+    if ((unsigned)w < wave) off += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return off + incl - v;
+}
+
+__global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
+    int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
+    uint32_t* ids_final, uint32_t* key0, uint32_t* id0, uint32_t* key1, uint32_t* id1) {
+  __shared__ uint32_t cnt[kBuckets];
+  __shared__ uint32_t cur[kBuckets];
+  __shared__ unsigned long long red_min[kTS / 64], red_max[kTS / 64];
+  __shared__ uint32_t wave_sums[kTS / 64];
+  __shared__ int stack_lo[kStack], stack_hi[kStack];
+  __shared__ uint8_t stack_src[kStack];
+  __shared__ int stack_n;
+  __shared__ uint32_t lk[kFast], li[kFast];
+  const int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  const int s = offsets[tile], e = offsets[tile + 1];
+  if (e - s <= 1) return;
+  const int tid = threadIdx.x;
+  const int n = e - s;
+
+  if (n <= kFast) {
+    // ---- fast path: registers + LDS ------------------------------------------------------------
+    uint32_t rk[kItems], ri[kItems];
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int idx = it * kTS + tid;
+      ri[it] = idx < n ? ids_final[s + idx] : 0u;
+    }
+    unsigned long long mn = ~0ull, mx = 0ull;
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int idx = it * kTS + tid;
+      rk[it] = 0u;
+      if (idx < n) {
+        rk[it] = __float_as_uint(depths[ri[it]]);
+        const unsigned long long c = ((unsigned long long)rk[it] << 32) | ri[it];
+        mn = c < mn ? c : mn;
+        mx = c > mx ? c : mx;
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long a = shfl_xor_u64(mn, d), b = shfl_xor_u64(mx, d);
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    }
+    if ((tid & 63) == 0) { red_min[tid >> 6] = mn; red_max[tid >> 6] = mx; }
+#pragma unroll
+    for (int k = 0; k < kBuckets / kTS; ++k) cnt[tid + k * kTS] = 0;
+    if (tid == 0) stack_n = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kTS / 64; ++w) {
+      mn = red_min[w] < mn ? red_min[w] : mn;
+      mx = red_max[w] > mx ? red_max[w] : mx;
+    }
+    const int hb = 63 - __clzll((long long)(mn ^ mx));
+    const int shift = hb > 9 ? hb - 9 : 0;
+    auto digit = [&](uint32_t k, uint32_t id) -> unsigned {
+      const unsigned long long c = ((unsigned long long)k << 32) | id;
+      return (unsigned)(c >> shift) & (kBuckets - 1);
+    };
+#pragma unroll
+    for (int it = 0; it < kItems; ++it)
+      if (it * kTS + tid < n) atomicAdd(&cnt[digit(rk[it], ri[it])], 1u);
+    __syncthreads();
+    uint32_t htot;
+    {
+      // one scan for both: bucket sizes in the low 16 bits (n <= 2048), heavy-bucket count above
+      uint32_t c4[kBuckets / kTS], packed = 0;
+#pragma unroll
+      for (int k = 0; k < kBuckets / kTS; ++k) {
+        c4[k] = cnt[tid * (kBuckets / kTS) + k];
+        packed += c4[k] + (c4[k] > (uint32_t)kSmall ? 0x10000u : 0u);
+      }
+      uint32_t tot;
+      uint32_t exp = block_scan_excl(packed, wave_sums, &tot);
+      uint32_t ex = exp & 0xffffu, hx = exp >> 16;
+      htot = tot >> 16;
+#pragma unroll
+      for (int k = 0; k < kBuckets / kTS; ++k) {
+        const int d = tid * (kBuckets / kTS) + k;
+        cur[d] = ex;
+        if (c4[k] > (uint32_t)kSmall) {            // the generic loop below takes it from buffer 1
+          if ((int)hx < kStack) {
+            stack_lo[hx] = s + (int)ex; stack_hi[hx] = s + (int)(ex + c4[k]); stack_src[hx] = 1;
+          } else {
+            cnt[d] = c4[k] | kBrute;
+          }
+          ++hx;
+        }
+        ex += c4[k];
+      }
+      if (tid == 0) stack_n = (int)htot < kStack ? (int)htot : kStack;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kItems; ++it)
+      if (it * kTS + tid < n) {
+        const uint32_t p = atomicAdd(&cur[digit(rk[it], ri[it])], 1u);
+        lk[p] = rk[it];
+        li[p] = ri[it];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int i = it * kTS + tid;
+      if (i < n) {
+        const uint32_t k = lk[i], id = li[i];
+        const unsigned d = digit(k, id);
+        const uint32_t craw = cnt[d];
+        const uint32_t b = craw & ~kBrute;
+        if (b > (uint32_t)kSmall && !(craw & kBrute)) {   // heavy: hand it to the generic loop
+          key1[s + i] = k;
+          id1[s + i] = id;
+        } else {
+          const int be = (int)cur[d], bs = be - (int)b;
+          int c = 0;
+          for (int j = bs; j < be; ++j) c += comp_less(lk[j], li[j], k, id) ? 1 : 0;
+          ids_final[s + bs + c] = id;
+        }
+      }
+    }
+    if (htot == 0) return;                          // uniform
+    __syncthreads();
+  } else {
+    // level 0 input: the tile's ids in index order; keys are gathered once and parked in buffer 0
+    for (int i = s + tid; i < e; i += kTS) {
+      const uint32_t id = ids_final[i];
+      key0[i] = __float_as_uint(depths[id]);
+      id0[i] = id;
+    }
+    if (tid == 0) {
+      stack_n = 1;
+      stack_lo[0] = s; stack_hi[0] = e; stack_src[0] = 0;
+    }
+    __syncthreads();
+  }
+
+  while (true) {
+    const int sn = stack_n;                        // uniform: read behind a barrier
+    if (sn == 0) break;
+    const int lo = stack_lo[sn - 1], hi = stack_hi[sn - 1];
+    const int src = stack_src[sn - 1];
+    __syncthreads();
+    if (tid == 0) stack_n = sn - 1;
+    const uint32_t* sk = src ? key1 : key0;
+    const uint32_t* si = src ? id1 : id0;
+    uint32_t* dk = src ? key0 : key1;
+    uint32_t* di = src ? id0 : id1;
+    const int m = hi - lo;
+
+    if (m <= kSmall) {                             // whole segment by rank counting
+      for (int i = lo + tid; i < hi; i += kTS) {
+        const uint32_t k = sk[i], id = si[i];
+        int c = 0;
+        for (int j = lo; j < hi; ++j) c += comp_less(sk[j], si[j], k, id) ? 1 : 0;
+        ids_final[lo + c] = id;
+      }
+      __syncthreads();
+      continue;
+    }
+
+    // highest differing bit of the composites
+    unsigned long long mn = ~0ull, mx = 0ull;
+    for (int i = lo + tid; i < hi; i += kTS) {
+      const unsigned long long c = ((unsigned long long)sk[i] << 32) | si[i];
+      mn = c < mn ? c : mn;
+      mx = c > mx ? c : mx;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long a = shfl_xor_u64(mn, d), b = shfl_xor_u64(mx, d);
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    }
+    if ((tid & 63) == 0) { red_min[tid >> 6] = mn; red_max[tid >> 6] = mx; }
+#pragma unroll
+    for (int k = 0; k < kBuckets / kTS; ++k) cnt[tid + k * kTS] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kTS / 64; ++w) {
+      mn = red_min[w] < mn ? red_min[w] : mn;
+      mx = red_max[w] > mx ? red_max[w] : mx;
+    }
+    const int hb = 63 - __clzll((long long)(mn ^ mx));       // composites are distinct: mn != mx
+    const int shift = hb > 9 ? hb - 9 : 0;
+    auto digit = [&](uint32_t k, uint32_t id) -> unsigned {
+      const unsigned long long c = ((unsigned long long)k << 32) | id;
+      return (unsigned)(c >> shift) & (kBuckets - 1);
+    };
+
+    for (int i = lo + tid; i < hi; i += kTS) atomicAdd(&cnt[digit(sk[i], si[i])], 1u);
+    __syncthreads();
+
+    // exclusive scan of the bucket sizes (four consecutive buckets per thread); heavy buckets get their
+    // stack slots here, deterministically -- past the stack's room they are finished by rank counting
+    {
+      uint32_t c4[kBuckets / kTS], sum = 0, heavy = 0;
+#pragma unroll
+      for (int k = 0; k < kBuckets / kTS; ++k) {
+        c4[k] = cnt[tid * (kBuckets / kTS) + k];
+        sum += c4[k];
+        heavy += c4[k] > (uint32_t)kSmall ? 1u : 0u;
+      }
+      uint32_t tot, htot;
+      uint32_t ex = block_scan_excl(sum, wave_sums, &tot);
+      uint32_t hx = block_scan_excl(heavy, wave_sums, &htot);
+      const int base = sn - 1;                     // stack height after the pop
+#pragma unroll
+      for (int k = 0; k < kBuckets / kTS; ++k) {
+        const int d = tid * (kBuckets / kTS) + k;
+        cur[d] = ex;
+        if (c4[k] > (uint32_t)kSmall) {
+          const int slot = base + (int)hx;
+          if (slot < kStack) {
+            stack_lo[slot] = lo + (int)ex; stack_hi[slot] = lo + (int)(ex + c4[k]); stack_src[slot] = (uint8_t)(src ^ 1);
+          } else {
+            cnt[d] = c4[k] | kBrute;
+          }
+          ++hx;
+        }
+        ex += c4[k];
+      }
+      if (tid == 0) stack_n = base + (int)htot < kStack ? base + (int)htot : kStack;
+    }
+    __syncthreads();
+
+    for (int i = lo + tid; i < hi; i += kTS) {
+      const uint32_t k = sk[i], id = si[i];
+      const uint32_t p = atomicAdd(&cur[digit(k, id)], 1u);
+      dk[lo + p] = k;
+      di[lo + p] = id;
+    }
+    __syncthreads();                               // the scattered segment is visible to the workgroup
+
+    // cur[d] is now the END of bucket d: every element of a light bucket ranks itself inside it
+    for (int i = lo + tid; i < hi; i += kTS) {
+      const uint32_t k = dk[i], id = di[i];
+      const unsigned d = digit(k, id);
+      const uint32_t craw = cnt[d];
+      const uint32_t b = craw & ~kBrute;
+      if (b > (uint32_t)kSmall && !(craw & kBrute)) continue;     // on the stack
+      const int be = lo + (int)cur[d], bs = be - (int)b;
+      int c = 0;
+      for (int j = bs; j < be; ++j) c += comp_less(dk[j], di[j], k, id) ? 1 : 0;
+      ids_final[bs + c] = id;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+size_t tile_depth_sort_temp_bytes(uint32_t capacity) {
+  return 4 * align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256);
+}
+
+// Sorts flatten_ids[offsets[t] .. offsets[t+1]) of every tile by (depth bits, id).  temp:
+// tile_depth_sort_temp_bytes(capacity) bytes.
+int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depths, uint32_t capacity,
+                    uint32_t* flatten_ids, void* temp, hipStream_t stream) {
+  if (n_tiles <= 0) return MGS_OK;
+  const size_t stride = align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256) / sizeof(uint32_t);
+  uint32_t* t = static_cast<uint32_t*>(temp);
+  hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, tile_offsets,
+                     depths, flatten_ids, t, t + stride, t + 2 * stride, t + 3 * stride);
+  return check_launch("tile_depth_sort");
+}
+
+}  // namespace mgs

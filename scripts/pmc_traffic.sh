@@ -27,7 +27,7 @@ def agg(d):
             a[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return a
 rec = {"stamp": hip_build.current_stamp(), "workload": "configs[1]: 1M Gaussians, SH 3, 1920x1080, tight lists, 4 channels (RGB+ED)", "kernels": {}, "raw": {}}
-pick = {"raster_inf": ("raster_fwd", "raster_fwd_kernel"), "raster_bwd_det": ("raster_bwd", "raster_bwd_kernel"), "project": ("project", "project_color_fwd_kernel")}
+pick = {"raster_inf": ("raster_fwd", "raster_fwd_kernel<4, false>"), "raster_bwd_det": ("raster_bwd", "raster_bwd_kernel"), "project": ("project", "project_color_fwd_kernel")}
 for stage in ("raster_inf", "raster_bwd_det", "project", "binning"):
     F, Wr, S = agg(stage + "_FETCH_SIZE"), agg(stage + "_WRITE_SIZE"), agg(stage + "_SQ_INSTS_VALU")
     for k in set(F) | set(Wr) | set(S):
@@ -43,4 +43,7 @@ for stage in ("raster_inf", "raster_bwd_det", "project", "binning"):
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes: 2 x %.1f MB (gfx950 counts 128-byte requests at 64 B) + %.1f MB per launch (profiles/pmc_traffic.json, scripts/pmc_traffic.sh)" % (row["FETCH_SIZE_KiB"] * 1024 / 1e6, row["WRITE_SIZE_KiB"] * 1024 / 1e6)}
 json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(rec["kernels"], indent=1))
+for k, v in rec["raw"].items():
+    if k.startswith("raster_inf:") and "raster_fwd_kernel<4, false>" in k or k.startswith("raster_bwd_det:") and "raster_bwd" in k:
+        print(k[:60], {a: (round(b) if b else b) for a, b in v.items()})
 PY

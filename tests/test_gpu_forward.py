@@ -113,6 +113,42 @@ def test_isect_tiles_bit_exact(ops, n, mu, w, h):
     np.testing.assert_array_equal(offs.cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th))
 
 
+@pytest.mark.parametrize("n,span,kind", [(1500, 40.0, "ties"), (1500, 40.0, "clustered"), (30_000, 40.0, "ties"),
+                                         (30_000, 40.0, "clustered"), (30_000, 40.0, "uniform"),
+                                         (9_000, 6.0, "equal")])
+def test_tile_depth_order_long_lists_and_depth_ties(ops, n, span, kind):
+    """The per-tile depth sort (csrc/tile_sort.hip) on inputs built to leave its common path: lists far
+    longer than its LDS-resident fast path (30 k entries per tile), thousands of bit-identical depths
+    (order then falls to the Gaussian index), depths clustered in a few narrow groups with one far
+    outlier (buckets that must be refined more than once).  Lists must be bit-identical to the stable
+    sort on (tile, depth bits)."""
+    rng = np.random.default_rng(n + len(kind))
+    w = h = 32                                            # 2 x 2 tiles, every Gaussian covers all of them
+    means2d = rng.uniform(0, 32, size=(n, 2)).astype(np.float32)
+    radii = np.full(n, int(span), np.int32)
+    if kind == "equal":
+        depths = np.full(n, 3.25, np.float32)
+    elif kind == "ties":
+        depths = rng.choice(np.array([1.5, 2.0, 2.0000002, 7.25, 7.2500005], np.float32), size=n)
+        depths[rng.random(n) < 0.3] = rng.uniform(1.0, 9.0, size=int((rng.random(n) < 0.3).sum()) or 1)[0]
+    elif kind == "clustered":
+        base = rng.choice(np.array([4.0, 4.0001, 4.0002], np.float32), size=n)
+        depths = (base + rng.integers(0, 40, size=n).astype(np.float32) * np.float32(4.76837158203125e-07)).astype(np.float32)
+        depths[0] = 0.011                                  # one far outlier stretches the key range
+        depths[1] = 9.0e9
+    else:
+        depths = rng.uniform(0.5, 20.0, size=n).astype(np.float32)
+    radii[rng.random(n) < 0.05] = 0                        # some culled
+    tl = ops.isect_tiles_raw(_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), 2, 2, 4 * n + 16,
+                             want_isect_ids=True)
+    cnt = int(tl.n_isect.item())
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, 2, 2, dtype=np.float32)
+    assert cnt == len(r_flat) and int(tl.status.item()) == 0
+    np.testing.assert_array_equal(tl.flatten_ids[:cnt].cpu().numpy(), r_flat)
+    np.testing.assert_array_equal(tl.isect_ids[:cnt].cpu().numpy(), r_ids)
+    np.testing.assert_array_equal(tl.tile_ids[:cnt].cpu().numpy(), (r_ids >> 32).astype(np.int32))
+
+
 def test_isect_tiles_empty_and_overflow(ops):
     from robosimgs_amd import _lib
     w = h = 64
