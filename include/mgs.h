@@ -114,6 +114,11 @@ int mgs_sh_bwd(int n, int degree, int coeff_stride, const float *dirs, const flo
  * (opacity already multiplied by the compensation when antialiased; f = feats, zero padded):
  * the raster kernels gather ONE record per list entry instead of four separate arrays
  * (means2d, conics, opacities, feats), which cuts their cache-line traffic: 266 -> 240 us.
+ * bin_info[N,2] u32 + bin_sums[ceil(N/64)] u32 (nullable, together): the SEED of the tile binning
+ * at tile size 16 -- per Gaussian {x0 | y0 << 10 | max(w,1) << 20, tile count} of its tile
+ * rectangle (bin_tight != 0: tightened to the tiles it can reach with alpha >= 1/255, see
+ * mgs_isect_tiles) and the count sum of every 64 consecutive Gaussians.  Handed to
+ * mgs_isect_tiles as seed_info / seed_sums they save the binning a pass and a launch.
  * ----------------------------------------------------------------------------------- */
 int mgs_project_color_fwd(int n, const float *means, const float *quats, const float *scales,
                           const float *opacities, int sh_degree, int coeff_stride,
@@ -121,7 +126,8 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
                           int width, int height, float eps2d, float near_plane,
                           float far_plane, float radius_clip, int32_t *radii, float *means2d,
                           float *depths, float *conics, float *opac_out, int feat_stride,
-                          float *feats, float *splats, mgs_stream_t stream);
+                          float *feats, float *splats, int bin_tight, uint32_t *bin_info,
+                          uint32_t *bin_sums, mgs_stream_t stream);
 
 /* -------------------------------------------------------------------------------------
  * Tile binning  (gsplat `isect_tiles` with sort=True + `isect_offset_encode`, one camera)
@@ -151,6 +157,10 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * rectangle; the pair (g, tile (tx,ty)) owns slot slot_base + (ty - y0) * w + (tx - x0) in
  * [0, n_isect); slot bases ascend with the Gaussian index.  Consumed by
  * mgs_rasterize_bwd_det.
+ * seed_info / seed_sums (nullable, together): bin_info / bin_sums as written by
+ * mgs_project_color_fwd for the same camera, tile grid and tight / classic choice; when given,
+ * means2d / radii / conics / opacities are not read (and may be NULL) and seed_sums is
+ * overwritten (scanned in place).
  * ----------------------------------------------------------------------------------- */
 int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const float *depths,
                     const float *conics, const float *opacities, int tile_size, int tile_w,
@@ -158,6 +168,7 @@ int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const flo
                     uint32_t isect_capacity, int32_t *tiles_per_gauss, uint32_t *n_isect,
                     uint32_t *tile_ids, int32_t *flatten_ids, int64_t *isect_ids,
                     int32_t *tile_offsets, int32_t *pair_info, uint32_t *status,
+                    const uint32_t *seed_info, uint32_t *seed_sums,
                     void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
 
 /* gsplat `isect_offset_encode`: first sorted index per (cam, tile) from sorted int64 keys.

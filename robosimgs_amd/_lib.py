@@ -38,9 +38,9 @@ def _load() -> ctypes.CDLL:
         "mgs_projection_bwd": ([i, p, p, p, p, p, i, i, f, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_sh_fwd": ([i, i, i, p, p, p, p, p], c_int),
         "mgs_sh_bwd": ([i, i, i, p, p, p, p, p, p, p], c_int),
-        "mgs_project_color_fwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, f, f, f, p, p, p, p, p, i, p, p, p], c_int),
+        "mgs_project_color_fwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, f, f, f, p, p, p, p, p, i, p, p, i, p, p, p], c_int),
         "mgs_project_color_bwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, i, p], c_int),
-        "mgs_isect_tiles": ([i, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_isect_tiles": ([i, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
         "mgs_rasterize_fwd": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, i, p, p, p, p], c_int),
         "mgs_rasterize_bwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),

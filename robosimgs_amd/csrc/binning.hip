@@ -17,6 +17,7 @@
 // the single-key formulation.  (Round 1 sorted the N Gaussians by depth first -- twelve dependent
 // launches for 1 M keys -- and gathered their rectangles into rank order.)
 #include "mgs_common.h"
+#include "tile_rect.h"
 
 namespace mgs {
 namespace {
@@ -25,107 +26,39 @@ namespace {
 // frames/s at three frames in flight); 64 makes the kernels themselves slower (binning 224 -> 235 us).
 constexpr int kBlock = 128;
 
-struct TileRect { int x0, y0, w, h; };
-
-// A.2 step 7: axis-aligned tile rectangle of the square mean2d +- radius
-__device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, float tile_size,
-                                              int tile_w, int tile_h) {
-  TileRect r;
-  float tr = (float)radius / tile_size;
-  float tx = mx / tile_size, ty = my / tile_size;
-  int x0 = min(max(0, (int)floorf(tx - tr)), tile_w);
-  int x1 = min(max(0, (int)ceilf(tx + tr)), tile_w);
-  int y0 = min(max(0, (int)floorf(ty - tr)), tile_h);
-  int y1 = min(max(0, (int)ceilf(ty + tr)), tile_h);
-  r.x0 = x0; r.y0 = y0; r.w = x1 - x0; r.h = y1 - y0;
-  return r;
-}
-
-// Tiles that hold a pixel centre the Gaussian can reach with alpha >= 1/255: the bounding box of
-// the ellipse sigma <= ln(255 opacity) (half extents sqrt(2 lim Sigma_xx), sqrt(2 lim Sigma_yy)),
-// intersected with the classic rectangle `r`.  Every dropped (tile, Gaussian) pair fails the
-// raster's alpha test at all 256 pixels, so the image and the gradients do not change by a bit
-// (tests/test_gpu_forward.py, test_gpu_backward.py) while the lists shrink by ~27 % at config 2.
-// Sigma = conic^-1 is taken from the fp32 conic the blend itself evaluates; a*c - b*b cancels
-// catastrophically for elongated footprints, so the determinant is Kahan-compensated (fma
-// residuals: exact to an ulp of the true value) and the extents carry a 1e-4 relative margin.
-// `lim` carries the same fp32 slack as the raster's own quadrant cull (raster_common.h).
-__device__ __forceinline__ TileRect tighten_rect(TileRect r, float mx, float my, float a, float b,
-                                                 float c, float opac, float tile_size) {
-  if (!(opac >= 1.0f / 255.0f)) { r.w = 0; r.h = 0; return r; }   // alpha <= opacity < 1/255
-  // det = a c - b b with Kahan's compensated 2x2 determinant: exact products via fma residuals
-  const float w = b * b, e = fmaf(-b, b, w), f = fmaf(a, c, -w);
-  const float det = f + e;
-  if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return r;          // degenerate: keep classic
-  const float inv_det = 1.0f / det;
-  const float sxx = c * inv_det, syy = a * inv_det;
-  const float thr = __logf(255.0f * opac);
-  const float e2 = 2.0f * (thr + 0.05f) * (sxx + syy);
-  const float slack = 0.05f + 8e-6f * (fabsf(a) + fabsf(c) + 2.f * fabsf(b)) * (e2 + 512.f);
-  const float lim = 2.0f * (thr + slack);
-  const float ex = sqrtf(lim * sxx) * 1.0001f + 0.01f;
-  const float ey = sqrtf(lim * syy) * 1.0001f + 0.01f;
-  // pixel centres are i + 0.5: first / last pixel column and row inside the box
-  const float plx = ceilf(mx - ex - 0.5f), phx = floorf(mx + ex - 0.5f);
-  const float ply = ceilf(my - ey - 0.5f), phy = floorf(my + ey - 0.5f);
-  if (!(phx >= plx) || !(phy >= ply)) {
-    if (phx < plx || phy < ply) { r.w = 0; r.h = 0; }               // no pixel centre inside
-    return r;                                                      // NaN: keep classic
-  }
-  const int x0 = max(r.x0, (int)fmaxf(floorf(plx / tile_size), -1.f));
-  const int y0 = max(r.y0, (int)fmaxf(floorf(ply / tile_size), -1.f));
-  const int x1 = min(r.x0 + r.w, (int)fminf(floorf(phx / tile_size), 65535.f) + 1);
-  const int y1 = min(r.y0 + r.h, (int)fminf(floorf(phy / tile_size), 65535.f) + 1);
-  if (x1 <= x0 || y1 <= y0) { r.w = 0; r.h = 0; return r; }
-  r.x0 = x0; r.y0 = y0; r.w = x1 - x0; r.h = y1 - y0;
-  return r;
-}
-
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
 
-// per Gaussian: tile rectangle (packed) + tile count, and the count sum of each block of kBlock
+// per Gaussian: tile rectangle (packed) + tile count, and the count sum of every 64 consecutive
+// Gaussians (the standalone operator's version of what mgs_project_color_fwd seeds the binning with)
+constexpr int kSum = 64;
 __global__ __launch_bounds__(kBlock) void tile_count_kernel(
     int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float* __restrict__ conics, const float* __restrict__ opacities, float tile_size,
-    int tile_w, int tile_h, uint2* __restrict__ ginfo, int32_t* __restrict__ tiles_per_gauss,
-    uint32_t* __restrict__ index_blocksums) {
-  __shared__ uint32_t ws[kBlock / 64];
+    int tile_w, int tile_h, uint2* __restrict__ ginfo, uint32_t* __restrict__ sums) {
   int g = blockIdx.x * kBlock + threadIdx.x;
   int radius = g < n ? radii[g] : 0;
-  uint32_t cnt = 0, pack = 1u << 20;
+  uint2 info = make_uint2(kEmptyTileRect, 0u);
   if (radius > 0) {
     float2 m = reinterpret_cast<const float2*>(means2d)[g];
     TileRect r = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
     if (conics)
       r = tighten_rect(r, m.x, m.y, conics[3 * (size_t)g], conics[3 * (size_t)g + 1],
                        conics[3 * (size_t)g + 2], opacities[g], tile_size);
-    cnt = (uint32_t)(r.w * r.h);
-    pack = (uint32_t)r.x0 | ((uint32_t)r.y0 << 10) | ((uint32_t)max(r.w, 1) << 20);
+    info = pack_tile_rect(r);
   }
-  if (g < n) {
-    ginfo[g] = make_uint2(pack, cnt);     // tile rectangle (x0 | y0 << 10 | w << 20) and tile count
-    if (tiles_per_gauss) tiles_per_gauss[g] = (int32_t)cnt;
-  }
-  {
-    const uint32_t c = wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t sum = 0;
-#pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) sum += ws[w];
-      index_blocksums[blockIdx.x] = sum;
-    }
-  }
+  if (g < n) ginfo[g] = info;
+  const uint32_t c = wave_sum(info.y);
+  const int first = blockIdx.x * kBlock + (int)(threadIdx.x & ~63u);
+  if ((threadIdx.x & 63) == 0 && first < n) sums[first / kSum] = c;
 }
 
 // single workgroup: exclusive scan of the block sums in place; publishes n_isect / overflow
 constexpr int kScanThreads = 1024;
-constexpr int kScanPerThread = 8;     // consecutive block sums per thread: 8192 per trip, one trip at 1 M Gaussians
+constexpr int kScanPerThread = 16;    // consecutive sums per thread: 16384 per trip, one trip at 1 M Gaussians (64 per sum)
 __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
     uint32_t nblk, uint32_t* __restrict__ blocksums, uint32_t capacity,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
@@ -194,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void pair_info_kernel(
     if ((unsigned)w < wave) off += ws[w];
   if (g < n) {
     const uint32_t w = info.x >> 20;
-    pair_info[g] = cnt ? make_int4((int)(blockbase[blockIdx.x] + off + incl - cnt), (int)(info.x & 1023u),
+    pair_info[g] = cnt ? make_int4((int)(blockbase[blockIdx.x * (kBlock / kSum)] + off + incl - cnt), (int)(info.x & 1023u),
                                    (int)((info.x >> 10) & 1023u), (int)(w | ((cnt / w) << 16)))
                        : make_int4(0, 0, 0, 0);
   }
@@ -204,7 +137,8 @@ __global__ __launch_bounds__(kBlock) void pair_info_kernel(
 // walked lane-linearly and each slot finds its Gaussian by binary search in LDS.
 __global__ __launch_bounds__(kBlock) void emit_kernel(
     int n, const uint2* __restrict__ ginfo, int tile_w, const uint32_t* __restrict__ blockbase,
-    uint32_t capacity, uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out) {
+    uint32_t capacity, uint32_t* __restrict__ tile_out, uint32_t* __restrict__ id_out,
+    int32_t* __restrict__ tiles_per_gauss) {
   __shared__ uint32_t prefix[kBlock + 1];
   __shared__ uint32_t gid[kBlock];
   __shared__ uint32_t rpack[kBlock];
@@ -216,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
     uint2 info = ginfo[r];
     pack = info.x;
     cnt = info.y;
+    if (tiles_per_gauss) tiles_per_gauss[r] = (int32_t)cnt;
   }
   uint32_t incl = cnt;
 #pragma unroll
@@ -235,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
   gid[threadIdx.x] = g;
   rpack[threadIdx.x] = pack;
   __syncthreads();
-  const uint32_t base = blockbase[blockIdx.x];
+  const uint32_t base = blockbase[blockIdx.x * (kBlock / kSum)];
   // each thread emits four consecutive slots: one binary search, then a linear walk
   for (uint32_t k0 = threadIdx.x * 4u; k0 < total; k0 += kBlock * 4u) {
     int lo = 0, hi = kBlock;   // invariant: prefix[lo] <= k0 < prefix[hi]
@@ -351,7 +286,7 @@ struct Workspace {
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     size_t nn = (size_t)(n > 0 ? n : 1), cc = cap ? cap : 1;
     ginfo = take(nn * 8);
-    blocksums = take((size_t)div_up((unsigned)nn, kBlock) * 4);
+    blocksums = take((size_t)div_up((unsigned)nn, kSum) * 4);
     tile_alt = take(cc * 4); id_alt = take(cc * 4);
     radix = take(radix_sort_temp_bytes((uint32_t)cc));
     tsort = take(tile_depth_sort_temp_bytes((uint32_t)cc));
@@ -370,7 +305,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                                int cam_id, int n_cams, uint32_t isect_capacity,
                                int32_t* tiles_per_gauss, uint32_t* n_isect, uint32_t* tile_ids,
                                int32_t* flatten_ids, int64_t* isect_ids, int32_t* tile_offsets,
-                               int32_t* pair_info, uint32_t* status, void* workspace,
+                               int32_t* pair_info, uint32_t* status, const uint32_t* seed_info,
+                               uint32_t* seed_sums, void* workspace,
                                size_t* workspace_bytes, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "isect_tiles: bad sizes");
   MGS_REQUIRE(tile_w <= 1023 && tile_h <= 1023, "isect_tiles: tile grid %dx%d exceeds 1023x1023", tile_w, tile_h);
@@ -387,7 +323,9 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   MGS_REQUIRE(isect_capacity > 0, "isect_tiles: zero capacity");
   MGS_REQUIRE((conics == nullptr) == (opacities == nullptr),
               "isect_tiles: tight tile bounds need both conics and opacities");
-  MGS_REQUIRE((n == 0 || (means2d && radii && depths)) && n_isect && tile_ids && flatten_ids &&
+  MGS_REQUIRE(n == 0 || (seed_info == nullptr) == (seed_sums == nullptr),
+              "isect_tiles: seed_info and seed_sums come together (mgs_project_color_fwd writes both)");
+  MGS_REQUIRE((n == 0 || ((seed_info || (means2d && radii)) && depths)) && n_isect && tile_ids && flatten_ids &&
                   tile_offsets && status, "isect_tiles: null pointer");
   hipStream_t s = (hipStream_t)stream;
   char* w = static_cast<char*>(workspace);
@@ -400,13 +338,19 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     (void)hipMemsetAsync(n_isect, 0, 4, s);
     (void)hipMemsetAsync(status, 0, 4, s);
   } else {
-    const unsigned nblk = div_up(n, kBlock);
-    uint2* ginfo = reinterpret_cast<uint2*>(w + ws.ginfo);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii, conics,
-                       opacities, (float)tile_size, tile_w, tile_h, ginfo, tiles_per_gauss,
-                       u32(ws.blocksums));
-    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nblk,
-                       u32(ws.blocksums), cap, n_isect, status);
+    const unsigned nblk = div_up(n, kBlock), nsum = div_up(n, kSum);
+    // rectangles + counts + per-64 sums: seeded by the fused projection kernel, or computed here
+    const uint2* ginfo = reinterpret_cast<const uint2*>(seed_info);
+    uint32_t* sums = seed_sums;
+    if (!seed_info) {
+      uint2* gi = reinterpret_cast<uint2*>(w + ws.ginfo);
+      sums = u32(ws.blocksums);
+      hipLaunchKernelGGL(tile_count_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii, conics,
+                         opacities, (float)tile_size, tile_w, tile_h, gi, sums);
+      ginfo = gi;
+    }
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nsum, sums, cap,
+                       n_isect, status);
     // tile sort: result must land in the caller's buffers
     const int tile_bits = bits_for((uint32_t)n_tiles);
     const int passes = (tile_bits + 7) / 8;
@@ -414,11 +358,11 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     uint32_t* user_i = reinterpret_cast<uint32_t*>(flatten_ids);
     uint32_t *a_t = user_t, *a_i = user_i, *b_t = u32(ws.tile_alt), *b_i = u32(ws.id_alt);
     if (passes & 1) { a_t = u32(ws.tile_alt); a_i = u32(ws.id_alt); b_t = user_t; b_i = user_i; }
-    hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_w,
-                       u32(ws.blocksums), cap, a_t, a_i);
+    hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_w, sums, cap, a_t,
+                       a_i, tiles_per_gauss);
     if (pair_info)     // training only: the record slots of the backward are the same index-order scan
-      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h,
-                         u32(ws.blocksums), reinterpret_cast<int4*>(pair_info));
+      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h, sums,
+                         reinterpret_cast<int4*>(pair_info));
     rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
     if (rc) return rc;
   }

@@ -12,6 +12,7 @@
 #include "mgs_common.h"
 #include "mgs_math.h"
 #include "sh_staging.h"
+#include "tile_rect.h"
 
 namespace mgs {
 namespace {
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     float far_plane, float radius_clip, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ conics,
     float* __restrict__ opac_out, int feat_stride, float* __restrict__ feats,
-    float4* __restrict__ splats) {
+    float4* __restrict__ splats, uint2* __restrict__ bin_info, uint32_t* __restrict__ bin_sums,
+    int bin_tight, int tile_w, int tile_h) {
   __shared__ float4 lds[STAGED ? (kBlock / kWave) * kWave * kShPitchF4 : 1];
   int g = blockIdx.x * kBlock + threadIdx.x;
   CameraParams cam = load_camera(viewmat, Kmat);
@@ -163,6 +165,24 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     if (opac_out) opac_out[g] = opacities[g] * p.compensation;
   }
   bool active = p.radius > 0;
+  // seed of the binning (mgs_isect_tiles seed_info / seed_sums): this Gaussian's tile rectangle and
+  // tile count, and the count sum of the wave's 64 Gaussians -- saves the binning its own pass over
+  // means2d / radii / conics / opacities and one launch
+  if (bin_info) {
+    uint2 info = make_uint2(kEmptyTileRect, 0u);
+    if (active) {
+      TileRect r = tile_rect(p.mean2d[0], p.mean2d[1], p.radius, (float)MGS_TILE_SIZE, tile_w, tile_h);
+      if (bin_tight)
+        r = tighten_rect(r, p.mean2d[0], p.mean2d[1], p.conic[0], p.conic[1], p.conic[2],
+                         opacities[g] * (opac_out ? p.compensation : 1.f), (float)MGS_TILE_SIZE);
+      info = pack_tile_rect(r);
+    }
+    if (g < n) bin_info[g] = info;
+    uint32_t c = info.y;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & (kWave - 1)) == 0 && g < n) bin_sums[g / kWave] = c;
+  }
   unsigned long long wave_mask = __ballot(active);
   int g0 = blockIdx.x * kBlock + (threadIdx.x & ~(kWave - 1));
   float c[sh_reg_floats(DEG)];
@@ -249,7 +269,8 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
                                      float far_plane, float radius_clip, int32_t* radii,
                                      float* means2d, float* depths, float* conics,
                                      float* opac_out, int feat_stride, float* feats,
-                                     float* splats, mgs_stream_t stream) {
+                                     float* splats, int bin_tight, uint32_t* bin_info,
+                                     uint32_t* bin_sums, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "project_color_fwd: bad sizes");
   MGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_color_fwd: sh_degree %d not in 0..3", sh_degree);
   MGS_REQUIRE(coeff_stride >= (sh_degree + 1) * (sh_degree + 1), "project_color_fwd: coeff_stride too small");
@@ -259,6 +280,10 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
                   depths && conics && feats, "project_color_fwd: null pointer");
   MGS_REQUIRE(!opac_out || opacities, "project_color_fwd: opac_out needs opacities");
   MGS_REQUIRE(!splats || opacities, "project_color_fwd: splats needs opacities");
+  MGS_REQUIRE((bin_info == nullptr) == (bin_sums == nullptr), "project_color_fwd: bin_info and bin_sums come together");
+  MGS_REQUIRE(!(bin_info && bin_tight) || opacities, "project_color_fwd: tight tile bounds need opacities");
+  const int tile_w = (width + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE, tile_h = (height + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE;
+  MGS_REQUIRE(!bin_info || (tile_w <= 1023 && tile_h <= 1023), "project_color_fwd: tile grid exceeds 1023x1023");
   dim3 grid(div_up(n, kBlock)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
   int sf = coeff_stride * 3;
@@ -268,7 +293,8 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
                      scales, opacities, sf, sh_coeffs, viewmat, K, (float)width,              \
                      (float)height, eps2d, near_plane, far_plane, radius_clip, radii,         \
                      means2d, depths, conics, opac_out, feat_stride, feats,                    \
-                     reinterpret_cast<float4*>(splats))
+                     reinterpret_cast<float4*>(splats), reinterpret_cast<uint2*>(bin_info),     \
+                     bin_sums, bin_tight, tile_w, tile_h)
   switch (sh_degree) {
     case 0: MGS_PC_LAUNCH(0, false); break;
     case 1: MGS_PC_LAUNCH(1, false); break;

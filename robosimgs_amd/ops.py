@@ -54,9 +54,10 @@ def projection_fwd_raw(means, quats, scales, viewmat, K, width, height, eps2d, n
 
 def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmat, K,
                           width, height, eps2d, near_plane, far_plane, radius_clip,
-                          antialiased, with_depth, want_splats=False):
+                          antialiased, with_depth, want_splats=False, bin_seed=None):
     """Returns (radii, means2d, depths, conics, opac_aa|None, feats) and, with want_splats, a 7th
-    item: the packed [N,12] records the raster kernels gather from."""
+    item: the packed [N,12] records the raster kernels gather from.  bin_seed = "tight" | "classic":
+    an 8th item (seed_info [N,2] i32, seed_sums [ceil(N/64)] i32) for isect_tiles_raw(seed=...)."""
     n = means.shape[0]
     dev = means.device
     radii = torch.empty(n, dtype=torch.int32, device=dev)
@@ -67,14 +68,22 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
     stride = 4 if with_depth else 3
     feats = torch.empty(n, stride, dtype=torch.float32, device=dev)
     splats = torch.empty(n, 12, dtype=torch.float32, device=dev) if want_splats else None
+    seed = None
+    if bin_seed is not None and n > 0:
+        seed = (torch.empty(n, 2, dtype=torch.int32, device=dev),
+                torch.empty(max(1, -(-n // 64)), dtype=torch.int32, device=dev))
     check(_lib.lib().mgs_project_color_fwd(
         n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), sh_degree, sh_coeffs.shape[1],
         ptr(sh_coeffs), ptr(viewmat), ptr(K), width, height, eps2d, near_plane, far_plane,
         radius_clip, ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(opac), stride,
-        ptr(feats), ptr(splats), stream_handle()), "mgs_project_color_fwd")
-    if want_splats:
-        return radii, means2d, depths, conics, opac, feats, splats
-    return radii, means2d, depths, conics, opac, feats
+        ptr(feats), ptr(splats), int(bin_seed == "tight"), ptr(seed[0]) if seed else None,
+        ptr(seed[1]) if seed else None, stream_handle()), "mgs_project_color_fwd")
+    out = (radii, means2d, depths, conics, opac, feats)
+    if want_splats or bin_seed is not None:
+        out = out + (splats,)
+    if bin_seed is not None:
+        out = out + (seed,)
+    return out
 
 
 class TileLists:
@@ -100,9 +109,11 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_id=0, n_cams=1,
                     want_isect_ids=False, want_tiles_per_gauss=True,
-                    want_pair_info=False, conics=None, opacities=None) -> TileLists:
+                    want_pair_info=False, conics=None, opacities=None, seed=None) -> TileLists:
     """conics + opacities given: tile rectangles tightened to the tiles a Gaussian can reach with
-    alpha >= 1/255 (shorter lists, bit-identical render); None: gsplat's classic rectangles."""
+    alpha >= 1/255 (shorter lists, bit-identical render); None: gsplat's classic rectangles.
+    seed = (seed_info, seed_sums) from project_color_fwd_raw(bin_seed=...): the rectangles come from
+    there (means2d / radii / conics / opacities are then not read; seed_sums is consumed)."""
     n = means2d.shape[0]
     dev = means2d.device
     L = _lib.lib()
@@ -122,7 +133,7 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
             tile_w, tile_h, cam_id, n_cams,
             capacity, ptr(out.tiles_per_gauss), ptr(out.n_isect), ptr(out.tile_ids),
             ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.pair_info),
-            ptr(out.status)]
+            ptr(out.status), ptr(seed[0]) if seed else None, ptr(seed[1]) if seed else None]
     check(L.mgs_isect_tiles(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_isect_tiles(size query)")
     ws = _workspace(nbytes.value, dev)

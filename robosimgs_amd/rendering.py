@@ -67,10 +67,11 @@ class _RenderSH(torch.autograd.Function):
                     else None)
         per_cam = []
         for c in range(C):
-            radii, means2d, depths, conics, opac_aa, feats, splats = ops.project_color_fwd_raw(
+            # the projection kernel also seeds the binning (tile rectangle + count per Gaussian)
+            radii, means2d, depths, conics, opac_aa, feats, splats, seed = ops.project_color_fwd_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats[c], Ks[c], width,
                 height, eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth,
-                want_splats=True)
+                want_splats=True, bin_seed="tight" if tight else "classic")
             opac = opac_aa if antialiased else opacities
             cap = isect_capacity
             if cap is None:
@@ -79,7 +80,7 @@ class _RenderSH(torch.autograd.Function):
                                      want_isect_ids=False, want_tiles_per_gauss=True,
                                      want_pair_info=training,
                                      conics=conics if tight else None,
-                                     opacities=opac if tight else None)
+                                     opacities=opac if tight else None, seed=seed)
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
