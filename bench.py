@@ -330,18 +330,25 @@ def main():
         reps = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def raster():
-            return ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
-                                         tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
-                                         splats=splats, expected_last=True)
-        for _ in range(5):
-            out = raster()
-        e0.record()
-        for _ in range(reps):
-            raster()
-        e1.record()
-        torch.cuda.synchronize()
-        raster_ms = e0.elapsed_time(e1) / reps
+        # two schedules of the same blend (identical pixels): one wave per tile -- fewest instructions, what
+        # the frames in flight above run -- and one wave per 8x8 block (MGS_RASTER_LATENCY), the choice for a
+        # launch that has the GPU to itself.  The roofline line is the kernel the timed frames ran.
+        timed_latency = n_fl == 1
+        raster_times = {}
+        for lat in (False, True):
+            def raster():
+                return ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
+                                             tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
+                                             splats=splats, expected_last=True, latency=lat)
+            for _ in range(5):
+                out = raster()
+            e0.record()
+            for _ in range(reps):
+                raster()
+            e1.record()
+            torch.cuda.synchronize()
+            raster_times[lat] = e0.elapsed_time(e1) / reps
+        raster_ms = raster_times[timed_latency]
         n_px = W * H
         # n_isect * 44 (id 4 + mean 8 + conic 12 + opacity 4 + rgb 12 + depth 4)
         #                 + n_px * 24 (rgb 12 + depth 4 + alpha 4 + last_id 4) + tiles * 8.
@@ -351,13 +358,16 @@ def main():
         walked_bytes = n_isect_binned * 44 + n_px * 20 + tile_w * tile_h * 8
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
         achieved_walked = walked_bytes / (raster_ms * 1e-3) / 1e9
-        traffic, traffic_note = pmc_traffic("raster_fwd", (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3))
-        result["roofline"] = {"kernel": f"raster_fwd_kernel<{ch}, false>", "bound": "hbm",
+        traffic, traffic_note = pmc_traffic("raster_fwd_q" if timed_latency else "raster_fwd", (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3))
+        result["roofline"] = {"kernel": (f"raster_fwd_q_kernel<{ch}, false>" if timed_latency
+                                         else f"raster_fwd_kernel<{ch}, false>"), "bound": "hbm",
                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "traffic_source": traffic_note,
                               "algorithmic_bytes": algo_bytes,
                               "kernel_ms": round(raster_ms, 4),
+                              "kernel_ms_by_schedule": {"throughput (one wave per tile)": round(raster_times[False], 4),
+                                                        "latency (one wave per 8x8 block)": round(raster_times[True], 4)},
                               "on_walked_lists": {"bytes": walked_bytes, "achieved": round(achieved_walked, 1),
                                                   "frac": round(achieved_walked / HBM_PEAK_GBS, 4),
                                                   "note": "n_isect_binned * 44 + n_px * 20 + tiles * 8: the "

@@ -47,6 +47,10 @@ extern "C" {
 
 /* mgs_rasterize_fwd flags */
 #define MGS_RASTER_EXPECTED_LAST 1 /* last channel leaves as channel / max(alpha, 1e-10): "ED" */
+#define MGS_RASTER_LATENCY 2       /* one wave per 8x8 block instead of one per tile (<= 4 channels):
+                                      -19 % time for a launch that has the GPU to itself, +7 % vector
+                                      instructions -- for single frames and training steps, not for
+                                      several frames in flight; same pixels bit for bit */
 
 #define MGS_TILE_SIZE 16
 #define MGS_MAX_CHANNELS 32
@@ -59,6 +63,10 @@ const char *mgs_last_error_string(void);
 /* Test hook (process-global, not for production): 0 disables the raster forward's exact
  * per-quadrant cull so that tests can prove the cull never changes a pixel. */
 void mgs_debug_set_raster_cull(int enabled);
+/* Measurement hook (process-global): scheduling options of the raster forward; bit 0 = issue
+ * priority by tile-list length, bit 1 = honour MGS_RASTER_LATENCY, bit 2 = force the per-block
+ * kernel, bits 8.. = KiB of padding LDS (default 3).  Never changes a pixel. */
+void mgs_debug_set_raster_opts(int opts);
 
 /* -------------------------------------------------------------------------------------
  * Projection  (gsplat `fully_fused_projection` forward, packed=False, one camera)

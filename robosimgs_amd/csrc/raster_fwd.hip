@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
-    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last) {
+    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last, int opts) {
   constexpr int kWgWaves = TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES;
   __shared__ QueueEntry<CHT> queues[kWgWaves][kQueue + 1];
   QueueEntry<CHT>* queue = queues[threadIdx.x >> 6];
@@ -98,6 +98,16 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
   const int tx = tile % tile_w, ty = tile / tile_w;
   const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  if (opts & 1) {
+    // Issue priority by list length.  A tile is one wave's serial job; while every SIMD is full each of
+    // its five waves advances at a fifth of the SIMD's rate, so the longest lists -- started no earlier
+    // than the others -- set the kernel's duration.  Waves with long lists get priority and finish at
+    // their own issue limit; short ones fill the gaps.
+    const int avg = tile_offsets[n_tiles] / n_tiles, len = end - start;
+    if (len > 2 * avg) __builtin_amdgcn_s_setprio(3);
+    else if (2 * len > 3 * avg) __builtin_amdgcn_s_setprio(2);
+    else if (len > avg) __builtin_amdgcn_s_setprio(1);
+  }
 
   // pixel centres of quadrant 0; quadrant k adds (8*(k&1), 8*(k>>1))
   const int ix = tx * 16 + (int)(lane & 7), iy = ty * 16 + (int)(lane >> 3);
@@ -256,6 +266,153 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
   }
 }
 
+
+// ---- one wave per 8x8 block ------------------------------------------------------------------
+// Same blend, finer work units: a workgroup is one tile, wave k of it owns quadrant k with ONE pixel
+// per lane.  Four times the waves, each a quarter of the serial work and half the registers (8 waves
+// per SIMD instead of 5): the chip is filled in ~4 even rounds instead of 1.6 uneven ones, no
+// quadrant branches in the inner loop, and a quadrant that saturates frees its wave slot at once.
+// The price is that the list is fetched and culled by each of the four waves (L2 hits) and that the
+// pixel offset (2 subtractions) is paid per evaluation instead of per queue entry.
+template <int CHT, bool TRACK_LAST>
+__global__ __launch_bounds__(256) void raster_fwd_q_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ feats, const float* __restrict__ opacities,
+    const float4* __restrict__ splats, const float* __restrict__ background, int channels,
+    int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
+    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last) {
+  __shared__ QueueEntry<CHT> queues[4][kQueue];
+  const int k = (int)(threadIdx.x >> 6);
+  QueueEntry<CHT>* queue = queues[k];
+  const int tile = blockIdx.x;
+  const unsigned lane = threadIdx.x & 63u;
+  const int tx = tile % tile_w, ty = tile / tile_w;
+  const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  const int ix = tx * 16 + 8 * (k & 1) + (int)(lane & 7), iy = ty * 16 + 8 * (k >> 1) + (int)(lane >> 3);
+  const float pxf = (float)ix + 0.5f, pyf = (float)iy + 0.5f;
+  const bool inside = ix < width && iy < height;
+  QuadRect rect;
+  rect.x0 = (float)(tx * 16 + 8 * (k & 1)) + 0.5f; rect.x1 = rect.x0 + 7.f;
+  rect.y0 = (float)(ty * 16 + 8 * (k >> 1)) + 0.5f; rect.y1 = rect.y0 + 7.f;
+  const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
+
+  PixelState<CHT> st;
+  st.T = inside ? 1.f : -1.f;
+  st.last = 0;
+#pragma unroll
+  for (int c = 0; c < CHT; ++c) st.C[c] = 0.f;
+
+  int r_idx = start + (int)lane;
+  bool r_ok = r_idx < end;
+  float2 r_xy = make_float2(0.f, 0.f);
+  float r_ca = 1.f, r_cb = 0.f, r_cc = 1.f, r_op = 0.f;
+  float r_feat[CHT];
+#pragma unroll
+  for (int c = 0; c < CHT; ++c) r_feat[c] = 0.f;
+  auto fetch = [&](int idx, bool ok) {
+    if (ok && CHT <= 4 && splats) {
+      int g = flatten_ids[idx];
+      const float4 p0 = splats[3 * (size_t)g], p1 = splats[3 * (size_t)g + 1], p2 = splats[3 * (size_t)g + 2];
+      r_xy = make_float2(p0.x, p0.y);
+      r_ca = p0.z; r_cb = p0.w; r_cc = p1.x; r_op = p1.y;
+      const float ff[4] = {p1.z, p1.w, p2.x, p2.y};
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) r_feat[c] = ff[c & 3];
+    } else if (ok) {
+      int g = flatten_ids[idx];
+      r_xy = reinterpret_cast<const float2*>(means2d)[g];
+      r_ca = conics[3 * (size_t)g + 0];
+      r_cb = conics[3 * (size_t)g + 1];
+      r_cc = conics[3 * (size_t)g + 2];
+      r_op = opacities[g];
+#pragma unroll
+      for (int c = 0; c < CHT; ++c) r_feat[c] = c < channels ? feats[(size_t)g * channels + c] : 0.f;
+    }
+  };
+  fetch(r_idx, r_ok);
+
+  for (int b = start; b < end; b += kQueue) {
+    if (__ballot(st.T > 0.f) == 0ull) break;          // every pixel of the block is finished
+    const int c_idx = r_idx;
+    const bool c_ok = r_ok;
+    const float2 c_xy = r_xy;
+    const float c_ca = r_ca, c_cb = r_cb, c_cc = r_cc, c_op = r_op;
+    float c_feat[CHT];
+#pragma unroll
+    for (int c = 0; c < CHT; ++c) c_feat[c] = r_feat[c];
+    r_idx = b + kQueue + (int)lane;
+    r_ok = r_idx < end;
+    fetch(r_idx, r_ok);
+
+    // same exact test as quadrant_mask (raster_common.h), for this block only
+    bool keep_me = false;
+    if (c_ok) {
+      keep_me = true;
+      if (cull) {
+        keep_me = false;
+        if (c_op >= kAlphaMin) {
+          const float thr = __logf(255.0f * c_op);
+          const float fx = fmaxf(fabsf(tile_x - c_xy.x), fabsf(tile_x + 16.f - c_xy.x));
+          const float fy = fmaxf(fabsf(tile_y - c_xy.y), fabsf(tile_y + 16.f - c_xy.y));
+          const float slack = 0.05f + 4e-6f * (fabsf(c_ca) + fabsf(c_cc) + 2.f * fabsf(c_cb)) * (fx * fx + fy * fy);
+          const float smin = rect_min_sigma(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, 1.0f / c_ca, 1.0f / c_cc, rect);
+          keep_me = !(smin > thr + slack);
+        }
+      }
+    }
+    const unsigned long long keep = __ballot(keep_me);
+    const int count = __popcll(keep);
+    if (keep_me) {
+      QueueEntry<CHT>& e = queue[mask_rank(keep)];
+      e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
+      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, c_op, 0.f, __int_as_float(c_idx));
+#pragma unroll
+      for (int f = 0; f < (CHT + 3) / 4; ++f) {
+        float4 v;
+        v.x = c_feat[4 * f];
+        v.y = 4 * f + 1 < CHT ? c_feat[4 * f + 1] : 0.f;
+        v.z = 4 * f + 2 < CHT ? c_feat[4 * f + 2] : 0.f;
+        v.w = 4 * f + 3 < CHT ? c_feat[4 * f + 3] : 0.f;
+        e.feat[f] = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = 0; j < count; ++j) {
+      const QueueEntry<CHT>& e = queue[j];
+      const float4 g0 = e.geo0, g1 = e.geo1;
+      float feat[CHT];
+#pragma unroll
+      for (int f = 0; f < (CHT + 3) / 4; ++f) {
+        const float4 v = e.feat[f];
+        feat[4 * f] = v.x;
+        if (4 * f + 1 < CHT) feat[4 * f + 1] = v.y;
+        if (4 * f + 2 < CHT) feat[4 * f + 2] = v.z;
+        if (4 * f + 3 < CHT) feat[4 * f + 3] = v.w;
+      }
+      blend_pixel<CHT, TRACK_LAST>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (inside) {
+    const size_t p = (size_t)iy * width + ix;
+    const float alpha = 1.0f - fabsf(st.T);
+    const float inv_alpha = expected_last ? 1.0f / fmaxf(alpha, 1e-10f) : 1.0f;
+#pragma unroll
+    for (int c = 0; c < CHT; ++c)
+      if (c < channels) {
+        float v = st.C[c] + (background ? fabsf(st.T) * background[c] : 0.f);
+        if (c == channels - 1) v *= inv_alpha;
+        render[p * channels + c] = v;
+      }
+    alphas[p] = alpha;
+    if (TRACK_LAST) last_ids[p] = st.last;
+  }
+}
+
 }  // namespace
 }  // namespace mgs
 
@@ -265,6 +422,13 @@ using namespace mgs;
 // live quadrant).  The image must not change; tests/test_gpu_forward.py checks that bit for bit.
 static int g_raster_cull = 1;
 extern "C" void mgs_debug_set_raster_cull(int enabled) { g_raster_cull = enabled; }
+// Scheduling knobs for A/B measurements (scripts/raster_ab.py); they never change a pixel.
+//   bit 0: issue priority by tile-list length in the one-wave-per-tile kernel (default on)
+//   bit 1: honour MGS_RASTER_LATENCY (one wave per 8x8 block, raster_fwd_q_kernel, <= 4 channels); default on
+//   bit 2: use that kernel whatever the flags say
+//   bits 8..: KiB of unused dynamic LDS per workgroup of that kernel (caps its occupancy: experiments)
+static int g_raster_opts = 3;
+extern "C" void mgs_debug_set_raster_opts(int opts) { g_raster_opts = opts; }
 
 #ifdef MGS_RASTER_STATS
 // instrumented build only: copy the counters out (synchronous) and zero them
@@ -291,14 +455,22 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
                   flatten_ids && render && alphas, "rasterize_fwd: null pointer");
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
+  const bool per_block = (g_raster_opts & 4) || ((g_raster_opts & 2) && (flags & MGS_RASTER_LATENCY));
 #define MGS_RF_LAUNCH_T(C, T)                                                                  \
   hipLaunchKernelGGL((raster_fwd_kernel<C, T>), dim3(div_up(n_tiles, (T) ? 1 : MGS_RASTER_WG_WAVES)),   \
                      dim3(64 * ((T) ? 1 : MGS_RASTER_WG_WAVES)), 0, s, means2d, conics,           \
                      feats, opacities, reinterpret_cast<const float4*>(splats), background,     \
                      channels, width, height, tile_w, n_tiles,                                 \
                      tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull,            \
-                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0)
-#define MGS_RF_LAUNCH(C) do { if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)
+                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, g_raster_opts)
+#define MGS_RQ_LAUNCH_T(C, T)                                                                  \
+  hipLaunchKernelGGL((raster_fwd_q_kernel<C, T>), dim3(n_tiles), dim3(256), (size_t)(g_raster_opts >> 8) * 1024, s, means2d, conics, feats,  \
+                     opacities, reinterpret_cast<const float4*>(splats), background, channels, width,      \
+                     height, tile_w, n_tiles, tile_offsets, flatten_ids, render, alphas, last_ids,         \
+                     g_raster_cull, (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0)
+#define MGS_RF_LAUNCH(C) do {                                                                      \
+    if (per_block && (C) <= 4) { if (last_ids) MGS_RQ_LAUNCH_T(C, true); else MGS_RQ_LAUNCH_T(C, false); } \
+    else if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)
   if (channels == 1) MGS_RF_LAUNCH(1);
   else if (channels == 2) MGS_RF_LAUNCH(2);
   else if (channels == 3) MGS_RF_LAUNCH(3);
@@ -308,5 +480,6 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   else MGS_RF_LAUNCH(32);
 #undef MGS_RF_LAUNCH
 #undef MGS_RF_LAUNCH_T
+#undef MGS_RQ_LAUNCH_T
   return check_launch("rasterize_fwd");
 }

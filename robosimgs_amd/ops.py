@@ -145,10 +145,12 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                       tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None,
-                      expected_last=False):
+                      expected_last=False, latency=False):
     """out = (render, alphas, last_ids|None) to write into existing buffers.  track_last=False (or
     last_ids None) is the inference variant: no last_ids, one select less per pair.
-    expected_last: the last channel leaves divided by max(alpha, 1e-10) ("ED" modes)."""
+    expected_last: the last channel leaves divided by max(alpha, 1e-10) ("ED" modes).
+    latency: MGS_RASTER_LATENCY -- one wave per 8x8 block; faster when the launch has the GPU to itself
+    (a single frame, a training step), slower in total work when several frames are in flight."""
     n = means2d.shape[0]
     ch = feats.shape[-1]
     dev = means2d.device
@@ -161,7 +163,7 @@ def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, heig
         render, alphas, last_ids = out
     check(_lib.lib().mgs_rasterize_fwd(n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities),
                                        ptr(splats), ptr(background), ch, width, height, tile_w, tile_h,
-                                       ptr(tile_offsets), ptr(flatten_ids), int(bool(expected_last)),
+                                       ptr(tile_offsets), ptr(flatten_ids), int(bool(expected_last)) | (2 if latency else 0),
                                        ptr(render), ptr(alphas), ptr(last_ids), stream_handle()),
           "mgs_rasterize_fwd")
     return render, alphas, last_ids

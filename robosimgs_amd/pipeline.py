@@ -53,6 +53,8 @@ class FrameRenderer:
         self.dev = tensors["means"].device
         self.width, self.height, self.mode = int(width), int(height), render_mode
         self.kw = dict(raster_kw)
+        # several frames in flight: total work matters, not one launch's duration (rendering.py)
+        self.kw.setdefault("raster_schedule", "throughput" if int(frames_in_flight) > 1 else "latency")
         self.bg = background
         if isect_capacity is None:
             if sizing_camera is None:

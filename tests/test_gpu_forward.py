@@ -338,6 +338,25 @@ def test_degenerate_inputs_do_not_crash_or_leak():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("deg,w,h", [(0, 256, 256), (3, 200, 120), (1, 97, 83)])
+def test_raster_schedules_give_identical_bits(ops, deg, w, h):
+    """MGS_RASTER_LATENCY (one wave per 8x8 block) and the default one-wave-per-tile kernel must agree
+    on every bit of render, alpha and last_ids, with and without background / expected depth."""
+    g, cam = _scene(15_000, 0.07, deg, w, h, seed=5)
+    t, radii, means2d, depths, conics, feats, tl, tw, th = _raster_inputs(ops, g, cam, w, h, deg)
+    bg = torch.tensor([0.1, 0.2, 0.3, 0.5], device=DEV)
+    for track in (True, False):
+        for kw in (dict(), dict(expected_last=True)):
+            a = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], bg, w, h, tw, th, tl.tile_offsets,
+                                      tl.flatten_ids, track_last=track, latency=False, **kw)
+            b = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], bg, w, h, tw, th, tl.tile_offsets,
+                                      tl.flatten_ids, track_last=track, latency=True, **kw)
+            for x, y, name in zip(a, b, ("render", "alphas", "last_ids")):
+                if x is not None:
+                    assert torch.equal(x, y), f"{name} differs (track_last={track}, {kw})"
+    assert float(a[1].max()) > 0.5
+
+
 @pytest.mark.parametrize("aniso", [1.0, 30.0, 300.0])
 def test_quadrant_cull_never_changes_a_pixel(ops, aniso):
     """The raster forward drops (Gaussian, quadrant) pairs that cannot reach alpha >= 1/255.  With
@@ -350,18 +369,19 @@ def test_quadrant_cull_never_changes_a_pixel(ops, aniso):
     g.log_scales[:, 0] += math.log(aniso)                       # stretch one axis
     g.opacity_logits[::7] = rng.uniform(-6.5, -5.0, size=len(g.opacity_logits[::7]))   # around 1/255
     t, radii, means2d, depths, conics, feats, tl, tw, th = _raster_inputs(ops, g, cam, 208, 144, 1)
-    try:
-        _lib.lib().mgs_debug_set_raster_cull(1)
-        a = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
-                                  tl.tile_offsets, tl.flatten_ids)
-        _lib.lib().mgs_debug_set_raster_cull(0)
-        b = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
-                                  tl.tile_offsets, tl.flatten_ids)
-    finally:
-        _lib.lib().mgs_debug_set_raster_cull(1)
-    assert float(a[1].max()) > 0.5
-    for x, y, name in zip(a, b, ("render", "alphas", "last_ids")):
-        assert torch.equal(x, y), f"{name}: cull changed {int((x != y).sum())} values"
+    for latency in (False, True):          # both raster kernels carry the cull
+        try:
+            _lib.lib().mgs_debug_set_raster_cull(1)
+            a = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
+                                      tl.tile_offsets, tl.flatten_ids, latency=latency)
+            _lib.lib().mgs_debug_set_raster_cull(0)
+            b = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
+                                      tl.tile_offsets, tl.flatten_ids, latency=latency)
+        finally:
+            _lib.lib().mgs_debug_set_raster_cull(1)
+        assert float(a[1].max()) > 0.5
+        for x, y, name in zip(a, b, ("render", "alphas", "last_ids")):
+            assert torch.equal(x, y), f"{name}: cull changed {int((x != y).sum())} values (latency={latency})"
 
 
 def test_equal_depths_keep_gaussian_index_order():
