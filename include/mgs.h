@@ -223,13 +223,18 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
  * slot; a second kernel sums each Gaussian's records.  Outputs are OVERWRITTEN for all N
  * rows (zeros where nothing contributed).  Workspace: two-phase size query as above
  * (capacity * (record floats * 4 + 1) bytes).  Scattered device atomics sustain only ~30 G/s
- * on MI355X, which makes the atomic variant 3x slower at 1 M Gaussians. */
+ * on MI355X, which makes the atomic variant 3x slower at 1 M Gaussians.  *   expected_render (nullable): the forward's render[H,W,channels] when it ran with
+ *   MGS_RASTER_EXPECTED_LAST -- v_render's last channel is then the cotangent of
+ *   channel / max(alpha, 1e-10) and the kernel's prologue converts it (and v_alphas) back to the
+ *   cotangents of the un-normalised blend: no pass over the frame in between.
+ */
 int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, const float *feats,
                           const float *opacities, const float *splats, const float *background,
                           int channels, int width, int height, int tile_w, int tile_h,
                           const int32_t *tile_offsets, const int32_t *flatten_ids,
                           const float *alphas, const int32_t *last_ids, const float *v_render,
-                          const float *v_alphas, const int32_t *pair_info,
+                          const float *v_alphas, const float *expected_render,
+                          const int32_t *pair_info,
                           uint32_t isect_capacity, float *v_means2d, float *v_means2d_abs,
                           float *v_conics, float *v_feats, float *v_opacities, void *workspace,
                           size_t *workspace_bytes, mgs_stream_t stream);

@@ -53,7 +53,7 @@ def _load() -> ctypes.CDLL:
         "mgs_transform_gaussians": ([i, p, p, p, i, i, p, p, i, p, p, p, p, p, p, p], c_int),
         "mgs_l1_loss_fwd": ([c_size_t, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_l1_loss_bwd": ([c_size_t, p, p, p, p, p], c_int),
-        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, u32, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, u32, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch

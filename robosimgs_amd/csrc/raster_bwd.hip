@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES) void raster_bwd_kerne
     float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
     float* __restrict__ v_feats, float* __restrict__ v_opacities,
     const int4* __restrict__ pair_info, float* __restrict__ records,
-    uint8_t* __restrict__ flags, uint32_t capacity) {
+    uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ expected_render) {
   __shared__ BwdEntry<CHT> queues[MGS_RASTER_BWD_WG_WAVES][kQueue];
   __shared__ float reds[MGS_RASTER_BWD_WG_WAVES][RECORDS ? 8 : 1][64];   // wave-private transpose buffer of the record reduction
   BwdEntry<CHT>* queue = queues[threadIdx.x >> 6];
@@ -149,10 +149,23 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES) void raster_bwd_kerne
     st[k].last = inside ? last_ids[p] : -1;
     float va = inside ? v_alphas[p] : 0.f;
 #pragma unroll
-    for (int c = 0; c < CHT; ++c) {
+    for (int c = 0; c < CHT; ++c)
       st[k].v_c[c] = (inside && c < channels) ? v_render[p * channels + c] : 0.f;
-      if (background && c < channels) va -= background[c] * st[k].v_c[c];
+    if (expected_render && inside) {
+      // the forward divided the last channel by max(alpha, 1e-10) ("ED"): ED = D / a, so
+      // dL/dD = v_ED / a and dL/dalpha -= v_ED ED / a (where a > 1e-10)
+      const float a = alphas[p], inv = 1.0f / fmaxf(a, 1e-10f);
+#pragma unroll
+      for (int c = 0; c < CHT; ++c)
+        if (c == channels - 1) {
+          const float v_ed = st[k].v_c[c];
+          if (a > 1e-10f) va -= v_ed * expected_render[p * channels + c] * inv;
+          st[k].v_c[c] = v_ed * inv;
+        }
     }
+#pragma unroll
+    for (int c = 0; c < CHT; ++c)
+      if (background && c < channels) va -= background[c] * st[k].v_c[c];
     st[k].tfv = st[k].T * va;
     hi = max(hi, st[k].last);
   }
@@ -438,7 +451,7 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
                      width, height, tile_w,                                                    \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities,                 \
-                     (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr, 0u)
+                     (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr, 0u, (const float*)nullptr)
 #define MGS_RB(C) if (v_means2d_abs) MGS_RB_LAUNCH(C, true); else MGS_RB_LAUNCH(C, false)
   if (channels == 1) { MGS_RB(1); }
   else if (channels == 2) { MGS_RB(2); }
@@ -460,6 +473,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                                      const int32_t* tile_offsets, const int32_t* flatten_ids,
                                      const float* alphas, const int32_t* last_ids,
                                      const float* v_render, const float* v_alphas,
+                                     const float* expected_render,
                                      const int32_t* pair_info, uint32_t isect_capacity,
                                      float* v_means2d, float* v_means2d_abs, float* v_conics,
                                      float* v_feats, float* v_opacities, void* workspace,
@@ -498,7 +512,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                      background, channels, width, height, tile_w,                              \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
-                     (float*)nullptr, info, records, flags, (uint32_t)cap);                    \
+                     (float*)nullptr, info, records, flags, (uint32_t)cap, expected_render);   \
   hipLaunchKernelGGL((reduce_records_kernel<C, A>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
                      info, records, flags, (uint32_t)cap, conics,                              \
                      reinterpret_cast<const float4*>(splats),                                  \

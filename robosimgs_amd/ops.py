@@ -195,9 +195,10 @@ def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, heig
 
 def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                           tile_h, tl: "TileLists", alphas, last_ids, v_render, v_alphas,
-                          absgrad=False, splats=None, canary_bytes=0):
+                          absgrad=False, splats=None, canary_bytes=0, expected_render=None):
     """Atomic-free, bit-reproducible raster backward (needs tl.pair_info from the binning).
     Returns freshly written (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None).
+    expected_render: the forward's frame when it ran with expected_last (the kernel undoes the divide).
     canary_bytes (tests): that many 0xA5 bytes are kept behind the workspace the library asked for
     and returned as a sixth value, so a test can see that nothing was written past the workspace."""
     n = means2d.shape[0]
@@ -212,7 +213,7 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities), ptr(splats), ptr(background),
             ch, width, height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
-            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(tl.pair_info), tl.capacity,
+            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(expected_render), ptr(tl.pair_info), tl.capacity,
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det(size query)")

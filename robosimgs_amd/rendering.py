@@ -111,13 +111,8 @@ class _RenderSH(torch.autograd.Function):
         C, n = viewmats.shape[0], means.shape[0]
         v_render = _f32c(v_render)
         v_alphas = _f32c(v_alphas).reshape(C, height, width)
-        if ctx.expected_depth:
-            # ED = D / max(alpha, 1e-10):  dL/dD = v_ED / a;  dL/dalpha += -v_ED * ED / a  (a > 1e-10)
-            a = alphas.clamp(min=1e-10)
-            v_ed = v_render[..., -1]
-            v_alphas = v_alphas - torch.where(alphas > 1e-10, v_ed * render_out[..., -1] / a,
-                                              torch.zeros_like(a))
-            v_render = torch.cat([v_render[..., :-1], (v_ed / a).unsqueeze(-1)], dim=-1)
+        # "RGB+ED": the raster backward's prologue undoes the divide by max(alpha, 1e-10) itself
+        # (expected_render=...); only a background gradient needs the converted cotangent here
         # the first camera overwrites the outputs, later ones accumulate: no zero-fill pass
         v_means = torch.empty_like(means)
         v_quats = torch.empty_like(quats)
@@ -133,7 +128,8 @@ class _RenderSH(torch.autograd.Function):
             bg = backgrounds[c] if backgrounds is not None else None
             v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_det_raw(
                 means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl, alphas[c],
-                last_ids[c], v_render[c], v_alphas[c], absgrad, splats=splats)
+                last_ids[c], v_render[c], v_alphas[c], absgrad, splats=splats,
+                expected_render=render_out[c] if ctx.expected_depth else None)
             # screen-space gradients for densification strategies (gsplat exposes them through
             # means2d.grad / means2d.absgrad; here they are published in the meta dict)
             ctx.meta_out.setdefault("means2d_grad", [None] * C)[c] = v_means2d
@@ -162,6 +158,9 @@ class _RenderSH(torch.autograd.Function):
                 m2d.absgrad = al[0].unsqueeze(0) if C == 1 else torch.stack(al)
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[7]:
+            if ctx.expected_depth:
+                v_render = torch.cat([v_render[..., :-1],
+                                      (v_render[..., -1] / alphas.clamp(min=1e-10)).unsqueeze(-1)], dim=-1)
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
         return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 15
 

@@ -128,6 +128,83 @@ def test_config5_stress_matches_cpu_port():
     print(f"\nconfigs[4] vs fp64 port: {st}, knife-edge Gaussians {info['n_edge_gaussians']}")
 
 
+def test_config3_backward_matches_fp64_oracle(config2):
+    """configs[2] at full size (1 M Gaussians, 1920x1080, forward + backward): gradients of
+    L = <w, render> + <u, alpha> against the fp64 oracle chain -- A.2 step 10 in the C++ port
+    (oracle/gs_cpu.cpp, fp64 sums, validated against autograd in tests/test_oracle_cpu.py) for the
+    blend, then torch autograd (fp64, oracle/gs_oracle_torch.py) through projection and SH colour.
+    Tolerance: per-row error scaled by the row's magnitude + 1e-3 of the tensor's largest entry stays
+    under 5e-3 on all but 1 % of the rows, cosine of the whole gradient >= 0.999 (as at test size)."""
+    from robosimgs_amd import rasterization
+    from oracle import gs_oracle_torch as OT
+    from test_gpu_backward import _compare
+    g, cam, t = config2
+    W, H, deg = 1920, 1080, 3
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    rng = np.random.default_rng(21)
+    w_img = rng.normal(size=(H, W, 3)).astype(np.float32)
+    w_a = rng.normal(size=(H, W)).astype(np.float32)
+    names = ("means", "quats", "scales", "opacities", "colors")
+    p = {k: t[k].clone().requires_grad_(True) for k in names}
+    c, a, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, K, W, H,
+                               sh_degree=deg)
+    ((c[0] * _t(w_img)).sum() + (a[0, ..., 0] * _t(w_a)).sum()).backward()
+    got = {k: p[k].grad.detach().cpu() for k in names}
+    got_m2d = meta["means2d_grad"][0].detach().cpu()
+    del c, a, meta, p
+    # oracle: blend backward in the fp64 port ...
+    vmf, Kf = np.asarray(cam.viewmat(), np.float32), np.asarray(cam.K, np.float32)
+    _, _, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vmf, Kf, W, H, deg,
+                                    margins=False, v_render=w_img, v_alpha=w_a, want_projected=True)
+    vis = info["radii"] > 0
+    _compare("v_means2d (blend)", got_m2d, info["g_means2d"], row_tol=5e-3, bad_frac=1e-2, cos_min=0.999)
+    _compare("v_opacities", got["opacities"], info["g_opacities"].reshape(-1, 1), row_tol=5e-3, bad_frac=1e-2,
+             cos_min=0.999)
+    # ... then autograd through projection + SH colour, vectorised over the 1 M Gaussians (fp64, CPU)
+    d = lambda x, grad=False: torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=grad)
+    r = {"means": d(g.means, True), "quats": d(g.quats, True), "scales": d(g.scales, True),
+         "colors": d(g.sh_coeffs[:, :(deg + 1) ** 2], True)}
+    vmt, Kt = d(vmf), d(Kf)
+    pr = OT.project(r["means"], r["quats"], r["scales"], vmt, Kt, W, H)
+    assert int((pr["radii"] > 0).sum()) == int(vis.sum())
+    campos = -vmt[:3, :3].T @ vmt[:3, 3]
+    rgb = torch.clamp(OT.spherical_harmonics(deg, r["means"] - campos, r["colors"]) + 0.5, min=0.0)
+    rgb = rgb * torch.tensor(vis, dtype=torch.float64)[:, None]
+    np.testing.assert_allclose(pr["means2d"].detach().numpy(), info["means2d"], atol=1e-6)
+    (pr["means2d"] * d(info["g_means2d"])).sum().add((pr["conics"] * d(info["g_conics"])).sum()) \
+        .add((rgb * d(info["g_feats"])).sum()).backward()
+    for k in ("means", "quats", "scales", "colors"):
+        ref = r[k].grad.numpy()
+        _compare("v_" + k, got[k], ref.reshape(ref.shape[0], -1), row_tol=5e-3, bad_frac=1e-2, cos_min=0.999)
+
+
+def test_config4_block_of_eight_ring_cameras_through_render_sharded(config2):
+    """configs[3]'s per-GPU share at its real shape: 8 consecutive cameras of the 64-camera ring at
+    1920x1080 through `render_sharded(renderer=FrameRenderer)` (world of one, no collective); two of
+    the frames are checked against the fp64 port with the zero-unexplained-pixels gate."""
+    from robosimgs_amd import FrameRenderer
+    from robosimgs_amd.distributed import render_sharded, shard_cameras
+    g, cam, t = config2
+    W, H = 1920, 1080
+    block = shard_cameras(64, 8, 3)                          # rank 3 of 8: cameras 24..31
+    assert list(block) == list(range(24, 32))
+    cams = camera_ring(len(block), W, H, thetas=[2.0 * math.pi * k / 64 for k in block])
+    vms = _t(np.stack([c.viewmat() for c in cams]))
+    Ks = _t(np.stack([c.K for c in cams]))
+    fr = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=3, sizing_camera=(cams[0].viewmat(), cams[0].K),
+                       capacity_margin=1.6)
+    colors, alphas, mine = render_sharded(t, vms, Ks, W, H, gather=False, renderer=fr, render_mode="RGB+ED")
+    assert list(mine) == list(range(8)) and colors.shape == (8, H, W, 4) and alphas.shape == (8, H, W, 1)
+    for i in (0, 5):
+        ref, ra, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                           cams[i].viewmat(), cams[i].K, W, H, 3, with_depth=True)
+        ref = ref.astype(np.float64)
+        ref[..., 3] /= np.maximum(ra, 1e-10)                  # the port returns the depth sum ("D")
+        st = O.check_frame(colors[i].cpu().numpy(), alphas[i].cpu().numpy(), ref, ra, info["margins"], O.EPS_PATH,
+                           info["edge_mask"], expected_depth=True, what=f"ring camera {block[i]}")
+        print(f"\nring camera {block[i]}: {st}")
+
+
 def test_config3_backward_directional_derivatives(config2):
     """configs[2] at full size (1 M Gaussians, 1920x1080, forward + backward): the analytic
     gradient must predict what the forward does along random parameter directions
