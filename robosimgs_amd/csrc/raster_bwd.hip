@@ -110,8 +110,11 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 #ifndef MGS_RASTER_BWD_WG_WAVES
 #define MGS_RASTER_BWD_WG_WAVES 1      // independent tiles (waves) per workgroup; 2 / 4 measured slower (564 / 554 vs 537 us)
 #endif
+#ifndef MGS_RASTER_BWD_MIN_WAVES
+#define MGS_RASTER_BWD_MIN_WAVES 1     // min waves per SIMD asked of the register allocator
+#endif
 template <int CHT, bool ABSGRAD, bool RECORDS>
-__global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES) void raster_bwd_kernel(
+__global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WAVES) void raster_bwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
@@ -174,6 +177,14 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES) void raster_bwd_kerne
   for (int d = 32; d >= 1; d >>= 1) hi = max(hi, __shfl_xor(hi, d));
   hi = min(hi, end - 1);
   if (hi < start) return;
+#ifdef MGS_RASTER_BWD_PRIO
+  {   // issue priority by the length of the walk (see raster_fwd.hip)
+    const int avg = tile_offsets[n_tiles] / n_tiles, len = hi - start + 1;
+    if (len > 2 * avg) __builtin_amdgcn_s_setprio(3);
+    else if (2 * len > 3 * avg) __builtin_amdgcn_s_setprio(2);
+    else if (len > avg) __builtin_amdgcn_s_setprio(1);
+  }
+#endif
 
   for (int q = (hi - start) / kQueue; q >= 0; --q) {
     const int b = start + q * kQueue;
