@@ -56,9 +56,11 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(
   if ((threadIdx.x & 63) == 0 && first < n) sums[first / kSum] = c;
 }
 
-// single workgroup: exclusive scan of the block sums in place; publishes n_isect / overflow
+// single workgroup: exclusive scan of the per-64 sums in place; publishes n_isect / overflow.
+// 16 consecutive sums per thread as four 16-byte loads in flight together (the kernel is one
+// latency chain: load -> wave scan -> LDS -> store), 16384 sums per trip = 1 M Gaussians.
 constexpr int kScanThreads = 1024;
-constexpr int kScanPerThread = 16;    // consecutive sums per thread: 16384 per trip, one trip at 1 M Gaussians (64 per sum)
+constexpr int kScanPerThread = 16;
 __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
     uint32_t nblk, uint32_t* __restrict__ blocksums, uint32_t capacity,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
@@ -69,11 +71,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
   for (uint32_t b0 = 0; b0 < nblk; b0 += kScanThreads * kScanPerThread) {
     const uint32_t b = b0 + threadIdx.x * kScanPerThread;
     uint32_t v[kScanPerThread], sum = 0;
+    if (b + kScanPerThread <= nblk) {          // the buffer is 256-byte aligned and b is a multiple of 16
+      const uint4* src = reinterpret_cast<const uint4*>(blocksums + b);
+      const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+      v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+      v[8] = q2.x; v[9] = q2.y; v[10] = q2.z; v[11] = q2.w; v[12] = q3.x; v[13] = q3.y; v[14] = q3.z; v[15] = q3.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) {
-      v[j] = b + j < nblk ? blocksums[b + j] : 0u;
-      sum += v[j];
+      for (int j = 0; j < kScanPerThread; ++j) v[j] = b + j < nblk ? blocksums[b + j] : 0u;
     }
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) sum += v[j];
     uint32_t incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -89,10 +97,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
     }
     __syncthreads();
     uint32_t ex = running + off + incl - sum;
+    uint32_t o[kScanPerThread];
 #pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) {
-      if (b + j < nblk) blocksums[b + j] = ex;
-      ex += v[j];
+    for (int j = 0; j < kScanPerThread; ++j) { o[j] = ex; ex += v[j]; }
+    if (b + kScanPerThread <= nblk) {
+      uint4* dst = reinterpret_cast<uint4*>(blocksums + b);
+      dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+      dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+      dst[2] = make_uint4(o[8], o[9], o[10], o[11]);
+      dst[3] = make_uint4(o[12], o[13], o[14], o[15]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kScanPerThread; ++j)
+        if (b + j < nblk) blocksums[b + j] = o[j];
     }
     wrapped |= running + tot < running;
     running += tot;

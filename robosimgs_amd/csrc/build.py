@@ -25,6 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 PER_SOURCE_FLAGS = {
     "raster_bwd.hip": os.environ.get("MGS_RASTER_BWD_FLAGS", "").split(),
     "raster_fwd.hip": os.environ.get("MGS_RASTER_FWD_FLAGS", "").split(),
+    "tile_sort.hip": os.environ.get("MGS_TILE_SORT_FLAGS", "").split(),
 }
 
 

@@ -30,7 +30,10 @@ constexpr int kTS = 256;            // threads per tile
 constexpr int kBuckets = 1024;
 constexpr int kSmall = 48;          // buckets up to this size are finished by rank counting
 constexpr int kStack = 96;          // pending heavy buckets; beyond it a bucket is rank-counted whatever its size
-constexpr int kFast = 2048;         // longest list of the LDS-resident fast path
+#ifndef MGS_TSORT_FAST
+#define MGS_TSORT_FAST 2048
+#endif
+constexpr int kFast = MGS_TSORT_FAST;   // longest list of the LDS-resident fast path (8 KiB of LDS per 1024)
 constexpr int kItems = kFast / kTS;
 constexpr uint32_t kBrute = 0x80000000u;
 
