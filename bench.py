@@ -230,6 +230,13 @@ def main():
             retire()
         if do_gather and state["fill"] > 0:            # a partial last batch still travels (whole buffer)
             ship()
+        if do_gather and world > 1 and RING % world != 0:
+            # ragged shards (64 cameras over e.g. 3 ranks): ranks with fewer frames issue empty collectives
+            # so that every rank has made the same number of gather calls when the region ends
+            nmax = torch.tensor([state["shipped"]], device=comm_dev, dtype=torch.int64)
+            dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+            while state["shipped"] < int(nmax.item()):
+                ship()
         for k in range(2):
             if pending[k] is not None:
                 pending[k].wait()

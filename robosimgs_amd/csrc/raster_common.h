@@ -74,6 +74,18 @@ __device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float a, f
   return m;
 }
 
+// The blend skips a pair whose sigma comes out negative (A.2 step 9).  For a positive definite conic
+// that can only be a rounding artefact, and only if sigma is tiny against its own terms: with
+// S = 0.5 (|a| dx^2 + |c| dy^2) + |b dx dy|, sigma >= (lambda_min / 2 lambda_max) S while fp32 evaluates
+// it to within ~6e-7 S.  A conic with lambda_min / lambda_max >= 1e-4 (det >= 1e-4 trace^2) can therefore
+// never produce sigma < 0 and the test is dead for it.  When every queued conic of a 64-entry batch is
+// such (nearly always) the batch is walked by a copy of the loop without the test: one compare and one
+// scalar AND less per 64 pairs; a batch holding a needle-like conic keeps the full test.  Results are identical.
+__device__ __forceinline__ bool sigma_sign_is_safe(float a, float b, float c) {
+  const float tr = a + c;
+  return a > 0.f && c > 0.f && fmaf(a, c, -b * b) >= 1e-4f * tr * tr;     // false for NaN
+}
+
 // full-wave sum: result valid in lane 63
 __device__ __forceinline__ float wave_reduce_to_lane63(float v) {
   int i;
