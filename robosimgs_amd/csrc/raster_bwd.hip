@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     const int4* __restrict__ pair_info, float* __restrict__ records,
     uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ expected_render) {
   __shared__ BwdEntry<CHT> queues[MGS_RASTER_BWD_WG_WAVES][kQueue];
-  __shared__ float reds[MGS_RASTER_BWD_WG_WAVES][RECORDS ? 8 : 1][64];   // wave-private transpose buffer of the record reduction
+  __shared__ float reds[MGS_RASTER_BWD_WG_WAVES][RECORDS ? 16 : 1][64];  // wave-private transpose buffer of the record reduction
   BwdEntry<CHT>* queue = queues[threadIdx.x >> 6];
   float (*red)[64] = reds[threadIdx.x >> 6];
   const int tile = blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6);
@@ -292,12 +292,43 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
           return j - CHT + channels;
         };
         int done = 0;
-        // Eight values at a time through LDS: every lane parks its partial sums lane-linear
+        // Through LDS, eight values per group: every lane parks its partial sums lane-linear
         // (red[i][lane], conflict-free), lane L then reads the eight partials red[L >> 3][8 (L & 7) ..]
         // with two ds_read_b128, adds them, and three DPP steps finish the sum over the eight lanes
         // that share a value: 10 VALU per eight values against 26 for the all-DPP butterfly (LDS
         // instructions of one wave execute in order, so the wave-private buffer needs no barrier
-        // beyond the compiler fences).
+        // beyond the compiler fences).  Up to 16 values (every case up to 8 channels) go in ONE round
+        // trip: all values are parked at once and each lane finishes two groups side by side -- the
+        // tail values used to take a DPP chain plus two ds_bpermute round trips per list entry.
+        if constexpr (NV > 8 && NV <= 16) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) red[i][lane] = vals[i];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int v1 = 8 + (int)(lane >> 3);                          // second group's value for this lane
+          const float4* s0 = reinterpret_cast<const float4*>(&red[lane >> 3][(lane & 7) * 8]);
+          const float4* s1 = reinterpret_cast<const float4*>(&red[v1 < NV ? v1 : 8][(lane & 7) * 8]);
+          const float4 a0 = s0[0], b0 = s0[1], a1 = s1[0], b1 = s1[1];
+          float t0 = ((a0.x + a0.y) + (a0.z + a0.w)) + ((b0.x + b0.y) + (b0.z + b0.w));
+          float t1 = ((a1.x + a1.y) + (a1.z + a1.w)) + ((b1.x + b1.y) + (b1.z + b1.w));
+          t0 += dpp_f(t0, kDppXor1);
+          t1 += dpp_f(t1, kDppXor1);
+          t0 += dpp_f(t0, kDppXor2);
+          t1 += dpp_f(t1, kDppXor2);
+          t0 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t0), 0x141, 0xf, 0xf, false));  // row_half_mirror
+          t1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t1), 0x141, 0xf, 0xf, false));
+          if ((lane & 7) == 0) {
+            const int p0 = rec_pos((int)(lane >> 3));
+            if (p0 >= 0) rec[p0] = t0;
+            if (v1 < NV) {
+              const int p1 = rec_pos(v1);
+              if (p1 >= 0) rec[p1] = t1;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();          // the next entry overwrites red
+          done = NV;
+        }
         while (NV - done >= 8) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) red[i][lane] = vals[done + i];
@@ -382,6 +413,8 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   for (int i = 0; i < 6; ++i) acc[i] = 0.f;
 #pragma unroll
   for (int c = 0; c < CHT; ++c) af[c] = 0.f;
+  // (loading the records unconditionally and selecting by the flag afterwards -- one round trip instead
+  //  of two -- was measured: 618 -> 676 us for the whole backward; the extra 64 MB cost more)
   // four slots per trip with predicated loads: the flag and record loads of a trip are all in
   // flight together instead of one dependent round trip per slot (summation order is unchanged)
   for (int sl = 0; sl < cnt; sl += 4) {
