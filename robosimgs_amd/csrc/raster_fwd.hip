@@ -291,6 +291,11 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
     float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last) {
   __shared__ QueueEntry<CHT> queues[4][kQueue];
+#ifdef MGS_RASTER_Q_VGPR_CLOBBER
+  // occupancy experiment: naming a high VGPR raises the kernel's register allocation (and lowers its
+  // waves per SIMD) without touching LDS, which the other frames' kernels need
+  asm volatile("" ::: MGS_RASTER_Q_VGPR_CLOBBER);
+#endif
   const int k = (int)(threadIdx.x >> 6);
   QueueEntry<CHT>* queue = queues[k];
   const int tile = blockIdx.x;
