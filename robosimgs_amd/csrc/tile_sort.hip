@@ -90,8 +90,12 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
   if (n <= kFast) {
     // ---- fast path: registers + LDS ------------------------------------------------------------
     uint32_t rk[kItems], ri[kItems];
+    // (every item loop below stops, wave-uniformly, at the first item no thread of the workgroup owns:
+    //  a 455-entry list executes two of the eight unrolled trips)
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
+      ri[it] = 0u;
+      if (it * kTS >= n) continue;
       const int idx = it * kTS + tid;
       ri[it] = idx < n ? ids_final[s + idx] : 0u;
     }
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     for (int it = 0; it < kItems; ++it) {
       const int idx = it * kTS + tid;
       rk[it] = 0u;
+      if (it * kTS >= n) continue;
       if (idx < n) {
         rk[it] = __float_as_uint(depths[ri[it]]);
         const unsigned long long c = ((unsigned long long)rk[it] << 32) | ri[it];
@@ -130,8 +135,10 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
       return (unsigned)(c >> shift) & (kBuckets - 1);
     };
 #pragma unroll
-    for (int it = 0; it < kItems; ++it)
+    for (int it = 0; it < kItems; ++it) {
+      if (it * kTS >= n) continue;
       if (it * kTS + tid < n) atomicAdd(&cnt[digit(rk[it], ri[it])], 1u);
+    }
     __syncthreads();
     uint32_t htot;
     {
@@ -164,16 +171,19 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < kItems; ++it)
+    for (int it = 0; it < kItems; ++it) {
+      if (it * kTS >= n) continue;
       if (it * kTS + tid < n) {
         const uint32_t p = atomicAdd(&cur[digit(rk[it], ri[it])], 1u);
         lk[p] = rk[it];
         li[p] = ri[it];
       }
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       const int i = it * kTS + tid;
+      if (it * kTS >= n) continue;
       if (i < n) {
         const uint32_t k = lk[i], id = li[i];
         const unsigned d = digit(k, id);
