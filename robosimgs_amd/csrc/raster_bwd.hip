@@ -113,7 +113,16 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 #ifndef MGS_RASTER_BWD_MIN_WAVES
 #define MGS_RASTER_BWD_MIN_WAVES 1     // min waves per SIMD asked of the register allocator
 #endif
-template <int CHT, bool ABSGRAD, bool RECORDS>
+// HALF (record path only; measured and NOT the default): a wave owns HALF a tile -- two 8x8 blocks side by
+// side, two pixels per lane -- and the pair's record slot is doubled (slot * 2 + half): twice the waves, each
+// half the serial work, 96 instead of 112 VGPRs, against one more wave reduction and record for the pairs
+// that reach both halves.  618 -> 724 us for the whole backward at config 2: the extra reductions and the
+// doubled slots of the reduce cost more than the finer schedule returns (what paid in the forward, where a
+// block's result needs no cross-lane sum, does not pay here).
+#ifndef MGS_RASTER_BWD_HALF
+#define MGS_RASTER_BWD_HALF 0
+#endif
+template <int CHT, bool ABSGRAD, bool RECORDS, bool HALF = false>
 __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WAVES) void raster_bwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
@@ -130,20 +139,23 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
   __shared__ float reds[MGS_RASTER_BWD_WG_WAVES][RECORDS ? 16 : 1][64];  // wave-private transpose buffer of the record reduction
   BwdEntry<CHT>* queue = queues[threadIdx.x >> 6];
   float (*red)[64] = reds[threadIdx.x >> 6];
-  const int tile = blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6);
+  static_assert(!HALF || RECORDS, "half tiles exist on the record path only");
+  constexpr int NQ = HALF ? 2 : 4;                 // 8x8 blocks per wave
+  const int unit = blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6);
+  const int tile = HALF ? unit >> 1 : unit, half = HALF ? unit & 1 : 0;
   if (tile >= n_tiles) return;
   const unsigned lane = threadIdx.x & 63u;
   const int tx = tile % tile_w, ty = tile / tile_w;
   const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   if (end <= start) return;
-  const int ix = tx * 16 + (int)(lane & 7), iy = ty * 16 + (int)(lane >> 3);
+  const int ix = tx * 16 + (int)(lane & 7), iy = ty * 16 + 8 * half + (int)(lane >> 3);
   const float px0 = (float)ix + 0.5f, py0 = (float)iy + 0.5f;
 
-  BwdPixel<CHT> st[4];
+  BwdPixel<CHT> st[NQ];
   int hi = -1;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < NQ; ++k) {
     const int x = ix + 8 * (k & 1), y = iy + 8 * (k >> 1);
     const bool inside = x < width && y < height;
     const size_t p = inside ? (size_t)y * width + x : 0;
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     // quadrants that still have a pixel with something left at or above this batch
     unsigned live = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NQ; ++k)
       if (__ballot(st[k].last >= b) != 0ull) live |= 1u << k;
     if (live == 0) continue;
 
@@ -216,7 +228,9 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         cc = conics[3 * (size_t)g + 2];
         op = opacities[g];
       }
-      qmask = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, tile_x, tile_y) & live;
+      qmask = quadrant_mask(xy.x, xy.y, ca, cb, cc, op, tile_x, tile_y);
+      if (HALF) qmask = (qmask >> (2 * half)) & 3u;       // this half's two blocks
+      qmask &= live;
     }
     const unsigned long long keep = __ballot(qmask != 0u);
     const int count = __popcll(keep);
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
       for (int c = 0; c < CHT; ++c) gg.v_f[c] = 0.f;
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NQ; ++k) {
         if (m & (1u << k))
           any |= grad_pixel<CHT, ABSGRAD>(st[k], gg, px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1),
                                           g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, g2.z, g2.w, g1.y, feat, gi);
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         // overflowed tile lists (status word set by the binning): slot bases run up to the true
         // n_isect, the workspace only to the capacity -- nothing is written past it
         if ((uint32_t)gid >= capacity) continue;
+        const size_t rslot = HALF ? 2 * (size_t)gid + half : (size_t)gid;
         // reduce-scatter butterfly: 8 values at a time, totals land in 8 lanes that store the
         // record slice with one instruction
         constexpr int NV = 6 + CHT + (ABSGRAD ? 2 : 0);
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         for (int c = 0; c < CHT; ++c) vals[6 + c] = gg.v_f[c];
         if (ABSGRAD) { vals[6 + CHT] = gg.a_x; vals[7 + CHT] = gg.a_y; }
         const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
-        float* rec = records + (size_t)gid * rs;
+        float* rec = records + rslot * rs;
         // record position of value j: channels above `channels` are padding and are dropped,
         // the absgrad pair follows the real channels
         auto rec_pos = [&](int j) {
@@ -362,7 +377,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         MGS_RS_CHUNK(2)
         MGS_RS_CHUNK(1)
 #undef MGS_RS_CHUNK
-        if (lane == 0) flags[gid] = 1;
+        if (lane == 0) flags[rslot] = 1;
       } else {
         // plain wave reduction, then one atomic per component from lane 63
         float rx = wave_reduce_to_lane63(gg.v_x), ry = wave_reduce_to_lane63(gg.v_y);
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
 }
 
 // Sum the records of each Gaussian's slots (its tile rectangle, emit order) into the outputs.
-template <int CHT, bool ABSGRAD>
+template <int CHT, bool ABSGRAD, int SLOTS = 1>      // SLOTS: record slots per (tile, Gaussian) pair (2: half tiles)
 __global__ __launch_bounds__(256) void reduce_records_kernel(
     int n, const int4* __restrict__ pair_info, const float* __restrict__ records,
     const uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ conics,
@@ -406,7 +421,9 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= n) return;
   const int4 info = pair_info[g];
-  const int cnt = (info.w & 0xffff) * ((unsigned)info.w >> 16);
+  const int npair = (info.w & 0xffff) * ((unsigned)info.w >> 16);
+  const int cnt = npair * SLOTS;
+  const size_t first = (size_t)info.x * SLOTS;
   const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
   float acc[6], af[CHT], ab[2] = {0.f, 0.f};
 #pragma unroll
@@ -421,11 +438,11 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
     bool on[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)      // slots at or past the capacity do not exist (overflowed lists)
-      on[i] = sl + i < cnt && (uint32_t)(info.x + sl + i) < capacity && flags[(size_t)info.x + sl + i] != 0;
+      on[i] = sl + i < cnt && (uint32_t)(info.x + (sl + i) / SLOTS) < capacity && flags[first + sl + i] != 0;
     float r[4][6], rf[4][CHT], ra[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float* rec = records + ((size_t)info.x + sl + i) * rs;
+      const float* rec = records + (first + sl + i) * rs;
 #pragma unroll
       for (int k = 0; k < 6; ++k) r[i][k] = on[i] ? rec[k] : 0.f;
 #pragma unroll
@@ -529,8 +546,10 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   MGS_REQUIRE(workspace_bytes, "rasterize_bwd_det: workspace_bytes is null");
   const int rs = 6 + channels + (v_means2d_abs ? 2 : 0);
   const size_t cap = isect_capacity ? isect_capacity : 1;
-  const size_t rec_bytes = align_up(cap * rs * sizeof(float), 256);
-  const size_t need = rec_bytes + align_up(cap, 256);
+  constexpr bool kHalf = MGS_RASTER_BWD_HALF != 0;
+  constexpr size_t kSlots = kHalf ? 2 : 1;
+  const size_t rec_bytes = align_up(cap * kSlots * rs * sizeof(float), 256);
+  const size_t need = rec_bytes + align_up(cap * kSlots, 256);
   if (!workspace) {
     *workspace_bytes = need;
     return MGS_OK;
@@ -547,17 +566,17 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   hipStream_t s = (hipStream_t)stream;
   float* records = static_cast<float*>(workspace);
   uint8_t* flags = static_cast<uint8_t*>(workspace) + rec_bytes;
-  hipError_t e = hipMemsetAsync(flags, 0, cap, s);
+  hipError_t e = hipMemsetAsync(flags, 0, cap * kSlots, s);
   if (e != hipSuccess) return set_error((int)e, "rasterize_bwd_det: memset: %s", hipGetErrorString(e));
   const int4* info = reinterpret_cast<const int4*>(pair_info);
 #define MGS_RD_LAUNCH(C, A)                                                                     \
-  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true>), dim3(div_up(n_tiles, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), 0, s, means2d,   \
+  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf>), dim3(div_up(n_tiles * (int)kSlots, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), 0, s, means2d,   \
                      conics, feats, opacities, reinterpret_cast<const float4*>(splats),        \
                      background, channels, width, height, tile_w,                              \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
                      (float*)nullptr, info, records, flags, (uint32_t)cap, expected_render);   \
-  hipLaunchKernelGGL((reduce_records_kernel<C, A>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
+  hipLaunchKernelGGL((reduce_records_kernel<C, A, (int)kSlots>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
                      info, records, flags, (uint32_t)cap, conics,                              \
                      reinterpret_cast<const float4*>(splats),                                  \
                      channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities)
