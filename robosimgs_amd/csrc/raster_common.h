@@ -1,6 +1,7 @@
 // raster_common.h -- pieces shared by the forward and backward tile raster kernels.
 //
-// Geometry.  One wave64 owns one 16x16 tile.  Lane l holds FOUR pixels, one in each 8x8
+// Geometry (raster_fwd_kernel, raster_bwd_kernel; raster_fwd_q_kernel gives each of the four
+// quadrants its own wave, one pixel per lane).  One wave64 owns one 16x16 tile.  Lane l holds FOUR pixels, one in each 8x8
 // quadrant k of the tile: (x, y) = (8*(k&1) + (l&7), 8*(k>>1) + (l>>3)).  A Gaussian's
 // parameters are therefore fetched once per 256 pixel evaluations, the four per-lane pixel
 // chains give the VALU independent work, and a quadrant whose 64 pixels cannot be touched

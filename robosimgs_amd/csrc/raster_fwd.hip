@@ -1,8 +1,10 @@
 // raster_fwd.hip -- per-tile depth-ordered alpha compositing, forward (A.2 step 9), gfx950.
-// Geometry, queue and culling: raster_common.h.  VALU-bound: 13 FMA-class + 7 compare/select-class
-// instructions + one v_exp per 64 pixel-Gaussian pairs against 44 bytes per tile-Gaussian pair
-// (SQ_ACTIVE_INST_VALU ~ 76 % of SIMD cycles, HBM at ~2 TB/s), so the design spends its effort on
-// evaluating fewer pairs and on cheaper evaluations, not on moving bytes.
+// Geometry, queue and culling: raster_common.h.  Vector-ALU-bound: 13 FMA-class + 7 compare/select-class
+// instructions + one v_exp per 64 pixel-Gaussian pairs = 65 cycles (2.4 / 4.1 / 8.15 cycles per class,
+// scripts/ubench/valu_issue.hip) against 44 bytes per tile-Gaussian pair, so the design spends its effort
+// on evaluating fewer pairs, on cheaper evaluations and on keeping enough waves resident, not on moving
+// bytes.  Two schedules of the same blend: raster_fwd_kernel (one wave per 16x16 tile, four pixels per lane:
+// fewest instructions) and raster_fwd_q_kernel (one wave per 8x8 block: shortest launch); DESIGN.md 4.3.
 #include <type_traits>
 
 #include "raster_common.h"

@@ -13,7 +13,8 @@
 // Grids are sized from the caller's capacity; workgroups past ceil(n / tile) exit at once.
 // Block tile: 1024 elements for small inputs (enough workgroups to fill 256 CUs), 4096 for
 // large ones (longer per-digit runs).  Byte / integer work, HBM-bound: per pass each element is
-// read twice and written once.
+// read twice and written once.  The render path sorts the (tile, Gaussian) pairs on their tile bits
+// with it (two passes at 1080p); the depth order inside a tile is tile_sort.hip's job.
 #include "mgs_common.h"
 
 namespace mgs {
