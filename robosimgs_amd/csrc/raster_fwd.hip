@@ -70,8 +70,10 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
                                             const float* feat, int idx) {
   float dx = mx - pxf, dy = my - pyf;
   float power = fmaf(dx, fmaf(B, dy, A * dx), (C * dy) * dy);   // spelled out: the backward repeats it bit for bit
-  float alpha = fminf(kAlphaMax, opac * __builtin_amdgcn_exp2f(power));
-  // SAFE: the conic cannot round sigma below zero (sigma_sign_is_safe), the first test is dead
+  // SAFE: the conic cannot round sigma below zero (sigma_sign_is_safe) and opacity <= 0.999: the sigma test is
+  // dead, exp2(power) <= 1, so opac * exp2(power) <= opac <= 0.999 and the clamp is the identity too
+  const float ov = opac * __builtin_amdgcn_exp2f(power);
+  float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
   bool valid = SAFE ? alpha >= kAlphaMin : (power <= 0.f && alpha >= kAlphaMin);
   // alpha forced to 0 where the Gaussian does not count: an open pixel (T > 1e-4 by invariant)
   // then keeps T and adds nothing, with no second mask to combine
@@ -79,7 +81,8 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
   float next_T = fmaf(-a_eff, px.T, px.T);
   bool acc = next_T > kTStop;                     // false for finished pixels (T < 0) and for the closing Gaussian
   float w = a_eff * px.T;
-  w = acc ? w : 0.f;
+  w = acc ? w : 0.f;      // (w = |T| - |T_new| -- a subtraction instead of a multiply and a select -- puts the weight
+                          //  behind the T select on the dependency chain: measured 218 -> 226 us, 3,575 -> 3,417 frames/s)
 #pragma unroll
   for (int c = 0; c < CHT; ++c) px.C[c] = fmaf(w, feat[c], px.C[c]);
   px.T = acc ? next_T : -fabsf(px.T);             // not accumulated: the pixel is (or stays) finished
@@ -185,9 +188,10 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     unsigned qmask = 0;
     if (c_ok) qmask = (cull ? quadrant_mask(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, c_op, tile_x, tile_y) : 0xfu) & live;
     const unsigned long long keep = __ballot(qmask != 0u);
-    // every queued conic of this batch is well conditioned (nearly always): the sigma >= 0 test is dead
-    // for the whole batch and the walk below runs without it (raster_common.h: sigma_sign_is_safe)
-    const bool all_safe = __ballot(qmask != 0u && !sigma_sign_is_safe(c_ca, c_cb, c_cc)) == 0ull;
+    // every queued Gaussian of this batch has a well conditioned conic and an opacity <= 0.999 (nearly
+    // always): the sigma >= 0 test and the 0.999 clamp are dead for the whole batch and the walk below runs
+    // without them (raster_common.h: sigma_sign_is_safe) -- two compare / min class instructions less per 64 pairs
+    const bool all_safe = __ballot(qmask != 0u && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kAlphaMax)) == 0ull;
     const int count = __popcll(keep);
     MGS_STAT(0, __popcll(__ballot(c_ok)));
     MGS_STAT(1, count);
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(
     }
     const unsigned long long keep = __ballot(keep_me);
     const int count = __popcll(keep);
-    const bool all_safe = __ballot(keep_me && !sigma_sign_is_safe(c_ca, c_cb, c_cc)) == 0ull;
+    const bool all_safe = __ballot(keep_me && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kAlphaMax)) == 0ull;
     if (keep_me) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
