@@ -67,6 +67,9 @@ void mgs_debug_set_raster_cull(int enabled);
  * priority by tile-list length, bit 1 = honour MGS_RASTER_LATENCY, bit 2 = force the per-block
  * kernel, bits 8.. = KiB of padding LDS (default 3).  Never changes a pixel. */
 void mgs_debug_set_raster_opts(int opts);
+/* Measurement hook (process-global): bit 0 = one-sweep (decoupled look-back) radix passes for the tile
+ * sort instead of histogram + row scan + scatter (default 0).  Same lists bit for bit. */
+void mgs_debug_set_sort_opts(int opts);
 
 /* -------------------------------------------------------------------------------------
  * Projection  (gsplat `fully_fused_projection` forward, packed=False, one camera)

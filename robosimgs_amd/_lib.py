@@ -35,6 +35,7 @@ def _load() -> ctypes.CDLL:
         "mgs_last_error_string": ([], c_char_p),
         "mgs_debug_set_raster_cull": ([i], None),
         "mgs_debug_set_raster_opts": ([i], None),
+        "mgs_debug_set_sort_opts": ([i], None),
         "mgs_projection_fwd": ([i, p, p, p, p, p, i, i, f, f, f, f, p, p, p, p, p, p], c_int),
         "mgs_projection_bwd": ([i, p, p, p, p, p, i, i, f, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_sh_fwd": ([i, i, i, p, p, p, p, p], c_int),
@@ -59,6 +60,8 @@ def _load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch
         fn.argtypes = argtypes
         fn.restype = restype
+    if os.environ.get("MGS_SORT_OPTS"):            # measurement knob: one-sweep radix passes (same lists)
+        lib.mgs_debug_set_sort_opts(int(os.environ["MGS_SORT_OPTS"], 0))
     if os.environ.get("MGS_RASTER_OPTS"):          # measurement knob (scripts/, profiles/): never changes a pixel
         lib.mgs_debug_set_raster_opts(int(os.environ["MGS_RASTER_OPTS"], 0))
     return lib
@@ -74,7 +77,7 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
-EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_debug_set_raster_cull", "mgs_debug_set_raster_opts", "mgs_projection_fwd", "mgs_projection_bwd",
+EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_debug_set_raster_cull", "mgs_debug_set_raster_opts", "mgs_debug_set_sort_opts", "mgs_projection_fwd", "mgs_projection_bwd",
            "mgs_sh_fwd", "mgs_sh_bwd", "mgs_project_color_fwd", "mgs_project_color_bwd",
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
            "mgs_rasterize_bwd_det", "mgs_composite_over", "mgs_points_project",
