@@ -223,7 +223,15 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                         "tile_width": tile_w, "tile_height": tile_h, "n_cameras": C,
                         "camera_ids": None, "gaussian_ids": None})
 
-    if sh_degree is not None and want_rgb:
+    # "D" / "ED" of an SH-coloured scene with a fixed list capacity (FrameRenderer, HIP graphs): the fused,
+    # read-back-free path renders RGB + depth and the depth channel is sliced off below
+    depth_only_via_sh = (sh_degree is not None and not want_rgb and isect_capacity is not None
+                         and colors.dim() == 3 and colors.shape[-1] == 3)
+    if depth_only_via_sh and backgrounds is not None:
+        if backgrounds.shape != (C, 1):
+            raise ValueError("backgrounds must be [C, channels]")
+        backgrounds = torch.cat([backgrounds.new_zeros(C, 3), backgrounds], dim=-1)
+    if sh_degree is not None and (want_rgb or depth_only_via_sh):
         if colors.dim() != 3 or colors.shape[0] != N or colors.shape[2] != 3:
             raise ValueError("with sh_degree set, colors must be [N,K,3]")
         if not 0 <= sh_degree <= 3 or colors.shape[1] < (sh_degree + 1) ** 2:
@@ -236,7 +244,9 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height,
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store,
-            tile_bounds == "tight", render_mode == "RGB+ED", raster_schedule == "latency")
+            tile_bounds == "tight", render_mode in ("RGB+ED", "ED"), raster_schedule == "latency")
+        if depth_only_via_sh:
+            render = render[..., 3:4]
         per_cam = store.pop("per_cam")
 
         def _stk(xs):                 # no copy for the common single-camera call
@@ -264,9 +274,8 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             # this path sizes its lists by reading the intersection count back (as the reference
             # operator does), so it can neither honour a fixed capacity nor be captured in a graph
             raise NotImplementedError(
-                "isect_capacity (read-back-free, graph-capturable frames) is only available on the "
-                "SH colour path (sh_degree given and an RGB render mode); render 'RGB+D' / 'RGB+ED' "
-                "and take the depth channel, or drop isect_capacity")
+                "isect_capacity (read-back-free, graph-capturable frames) needs the SH colour path "
+                "(sh_degree given with [N,K,3] coefficients); drop isect_capacity for per-Gaussian features")
         radii, means2d, depths, conics, comps = ops.fully_fused_projection(
             means, None, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
             radius_clip, calc_compensations=antialiased)

@@ -81,3 +81,24 @@ def test_overflow_is_per_frame_and_packed_camera_submit():
     f = r_far.fetch(tk)
     assert torch.equal(f["colors"], ok["colors"])
     r_far.release(tk)
+
+
+@pytest.mark.parametrize("mode", ["D", "ED"])
+def test_depth_only_modes_with_a_fixed_capacity_and_in_a_frame_renderer(mode):
+    """"D" / "ED" of an SH-coloured scene with isect_capacity (no read-back: capturable) go through the fused
+    path and must equal the depth channel of "RGB+D" / "RGB+ED"; FrameRenderer(render_mode=mode) captures."""
+    from robosimgs_amd import FrameRenderer, rasterization
+    g = synthetic_scene(4000, math.log(0.08), 2, 9)
+    cam = camera_ring(1, 160, 96, thetas=[1.1])[0]
+    t = g.to_torch(DEV, 2)
+    vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(DEV)[None]
+    K = torch.from_numpy(cam.K.astype(np.float32)).to(DEV)[None]
+    args = (t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K, 160, 96)
+    full, fa, _ = rasterization(*args, sh_degree=2, render_mode="RGB+" + mode, isect_capacity=200_000)
+    d, a, _ = rasterization(*args, sh_degree=2, render_mode=mode, isect_capacity=200_000)
+    assert d.shape == (1, 96, 160, 1) and torch.equal(d, full[..., 3:4]) and torch.equal(a, fa)
+    ref, _, _ = rasterization(*args, sh_degree=2, render_mode=mode)          # the operator path (reads n_isect back)
+    torch.testing.assert_close(d, ref, rtol=1e-5, atol=1e-5)
+    fr = FrameRenderer(t, 160, 96, render_mode=mode, frames_in_flight=2, isect_capacity=200_000)
+    out = fr.render(cam.viewmat(), cam.K)
+    assert torch.equal(out["colors"], d[0])
