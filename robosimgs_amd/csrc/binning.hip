@@ -2,20 +2,21 @@
 //
 // The textbook pipeline (gsplat `isect_tiles`) emits one 64-bit key (tile << 32 | depth bits)
 // per (Gaussian, tile) pair and radix-sorts all n_isect pairs on ~45 bits: six 8-bit passes
-// over 12-byte elements.  The same ordering is produced here with ~4.5x less sort traffic and
-// a third of the dependent launches of this repo's first version:
-//   1. per Gaussian: tile rectangle and tile count; exclusive scan of the counts in INDEX order
-//      (total = n_isect, kept on the device; the same scan gives the backward's record slots);
-//   2. emit (tile, gaussian) pairs in index order with a load-balanced search so that stores are
-//      lane-linear;
-//   3. stable radix sort on the tile bits only (13 bits at 1080p: a 7-bit and a 6-bit pass over
-//      8-byte pairs): every tile's list is now contiguous, in Gaussian-index order;
-//   4. first index of every tile;
-//   5. tile_sort.hip: one workgroup per tile orders its list by (depth bits, index).
-// Sorting each tile's index-ordered list by (depth, index) == the stable sort on (tile, depth)
-// with index-order ties: flatten_ids / isect_ids are bit-identical to
-// the single-key formulation.  (Round 1 sorted the N Gaussians by depth first -- twelve dependent
-// launches for 1 M keys -- and gathered their rectangles into rank order.)
+// over 12-byte elements.  The same ordering is produced here in five launches and two trips over the pairs:
+//   1. per Gaussian: tile rectangle and tile count (written by the fused projection kernel, or by
+//      tile_count_kernel for the standalone operator);
+//   2. DIRECT PATH (tile grids up to ~65 k tiles, below): a counting sort of the pairs on their tile GROUP (four
+//      consecutive tiles) with LDS-resident counters -- histogram per run of Gaussians, column scan, scatter;
+//   3. tile_sort.hip: one workgroup per tile picks its entries out of its group's segment and orders them by
+//      (depth bits, index); it also stores the tile's offset and the entries' tile ids.
+// Sorting each tile's list by the full (depth, index) composite == the stable sort on (tile, depth) with
+// index-order ties: flatten_ids / isect_ids are bit-identical to the single-key
+// formulation, whatever order step 2 delivers the entries in.
+// RADIX PATH (larger grids; mgs_debug_set_sort_opts(4) forces it): exclusive scan of the counts in index order,
+// load-balanced emit of (tile, gaussian) pairs, stable radix sort on the tile bits only (13 bits at 1080p: a
+// 7-bit and a 6-bit pass over 8-byte pairs), first index of every tile, then the same per-tile sort: ten launches,
+// 131 us at config 2 against 98 for the direct path (profiles/r2/00_experiments.md).  The index-order scan also
+// gives the backward's record slots (pair_info), so training runs it on either path.
 #include "mgs_common.h"
 #include "tile_rect.h"
 
@@ -220,6 +221,194 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
   }
 }
 
+
+// ---- direct path (tile grids up to kDirectMaxTiles tiles) --------------------------------------------------
+// The per-tile sort orders a list by the full (depth bits, index) composite, so the order in which a tile's
+// entries arrive does not matter and the radix partition by tile (emit + two histogram / scan / scatter passes
+// + tile offsets: nine launches, four trips over the pairs) can be replaced by a counting sort on the tile
+// itself whose counters live in LDS:
+//   direct_hist_kernel     each of <= 256 workgroups owns a run of consecutive Gaussians and counts their tiles in
+//                          an LDS histogram of the whole grid (LDS atomics), then stores its row of the table;
+//   direct_colscan_kernel  per tile, exclusive prefix down the table's column (64 tiles x 16 row groups per workgroup)
+//                          and the tile's total;
+//   direct_scatter_kernel  every workgroup scans the tile totals into the tile offsets (in LDS; workgroup 0 also
+//                          stores them), adds its own row = its cursors, walks its Gaussians again and drops each
+//                          pair at the cursor's next position (LDS atomic with return).
+// Device-scope atomics were measured for the same job and are no option: ~25 G atomics/s on 8160 hot counters
+// (scripts/ubench/atomic_rate.hip), i.e. 108 us per pass at config 2.
+#ifndef MGS_DIRECT_THREADS
+#define MGS_DIRECT_THREADS 512
+#endif
+// Workgroup of the histogram / scatter kernels and Gaussians per thread.  Alone the stage likes big workgroups
+// (1024 x 4: 110.7 us, 512 x 8: 113.3, 512 x 4: 118.1, 256 x 8: 125.0, 256 x 4: 137.8 -- fewer table rows, fewer
+// copies of the scatter's prologue), but a 16-wave workgroup has to wait for a quarter of a CU to drain while other
+// frames' raster waves hold the slots: with three frames in flight 1024 x 4 renders 3,281 frames/s, 512 x 8 3,669,
+// 256 x 8 3,561 (the radix partition: 3,585).
+constexpr int kDirectThreads = MGS_DIRECT_THREADS;
+#ifndef MGS_DIRECT_PER_THREAD
+#define MGS_DIRECT_PER_THREAD 8
+#endif
+constexpr int kDirectPerThread = MGS_DIRECT_PER_THREAD;   // Gaussians per thread of those kernels
+constexpr int kDirectMaxBlocks = 1024;         // table rows (more Gaussians than 4 x threads x this: longer runs per workgroup)
+constexpr int kDirectMaxTiles = 16320;         // the LDS histogram: 4 bytes per tile in 64 KiB, less the static part
+constexpr int kGroupShift = 2;                 // 2^2 consecutive tiles share a segment (1 / 2 / 4 / 8 / 16 tiles: 124 / 113 / 112 / 124 / 150 us)
+constexpr uint32_t kCoopRect = 24;             // rectangles above this many tiles are walked by the whole wave
+
+// f(tile, g) for every tile of every lane's rectangle; all 64 lanes must arrive together
+template <class F>
+__device__ __forceinline__ void for_each_tile(uint32_t pack, uint32_t cnt, uint32_t g, int tile_w, F f) {
+  const bool big = cnt > kCoopRect;
+  if (!big) {
+    const uint32_t w = pack >> 20;
+    uint32_t t = ((pack >> 10) & 1023u) * (uint32_t)tile_w + (pack & 1023u), dx = 0;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      f(t + dx, g);
+      if (++dx == w) { dx = 0; t += (uint32_t)tile_w; }
+    }
+  }
+  unsigned long long m = __ballot(big);
+  const unsigned lane = lane_id();
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const uint32_t p = __shfl(pack, src), c = __shfl(cnt, src), gs = __shfl(g, src);
+    const uint32_t w = p >> 20, x0 = p & 1023u, y0 = (p >> 10) & 1023u;
+    for (uint32_t k = lane; k < c; k += 64) {
+      const uint32_t dy = k / w, dx = k - dy * w;
+      f((y0 + dy) * (uint32_t)tile_w + x0 + dx, gs);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
+    int n, int chunk, const uint2* __restrict__ ginfo, int tile_w, int n_tiles, int shift,
+    uint32_t* __restrict__ table, int32_t* __restrict__ tiles_per_gauss) {
+  extern __shared__ uint32_t hist[];
+  n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins: groups of 2^shift consecutive tiles
+  for (int i = threadIdx.x; i < n_tiles; i += kDirectThreads) hist[i] = 0u;
+  __syncthreads();
+  const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
+  for (int base = g0; base < g1; base += kDirectThreads) {
+    const int g = base + (int)threadIdx.x;
+    uint32_t pack = kEmptyTileRect, cnt = 0;
+    if (g < g1) {
+      const uint2 info = ginfo[g];
+      pack = info.x; cnt = info.y;
+      if (tiles_per_gauss) tiles_per_gauss[g] = (int32_t)cnt;
+    }
+    for_each_tile(pack, cnt, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile >> shift], 1u); });
+  }
+  __syncthreads();
+  uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
+  for (int i = threadIdx.x; i < n_tiles; i += kDirectThreads) row[i] = hist[i];
+}
+
+// 256 threads: 16 bins (64 bytes of a row) x 16 row groups; two passes over the group's rows (sum, then rewrite as
+// the exclusive prefix), 16 loads in flight per thread
+constexpr int kColThreads = 256;
+__global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
+    int nb, int n_tiles, uint32_t* __restrict__ table, uint32_t* __restrict__ tile_count) {
+  __shared__ uint32_t part[16][16];
+  const int bl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + bl;
+  const int rpg = (nb + 15) / 16;
+  const int r0 = rg * rpg, r1 = min(nb, r0 + rpg);
+  const bool ok = t < n_tiles;
+  uint32_t sum = 0;
+  for (int r = r0; r < r1; r += 16) {
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (ok && r + j < r1) ? table[(size_t)(r + j) * n_tiles + t] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += v[j];
+  }
+  part[rg][bl] = sum;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const uint32_t s = part[g][bl];
+    if (g < rg) off += s;
+    tot += s;
+  }
+  for (int r = r0; r < r1; r += 16) {
+    uint32_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (ok && r + j < r1) ? table[(size_t)(r + j) * n_tiles + t] : 0u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (ok && r + j < r1) {
+        table[(size_t)(r + j) * n_tiles + t] = off;
+        off += v[j];
+      }
+  }
+  if (rg == 0 && ok) tile_count[t] = tot;
+}
+
+__global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
+    int n, int chunk, const uint2* __restrict__ ginfo, int tile_w, int n_tiles, int shift,
+    const uint32_t* __restrict__ table, const uint32_t* __restrict__ tile_count, uint32_t capacity,
+    uint32_t* __restrict__ flatten_ids, int32_t* __restrict__ tile_offsets,
+    uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
+  extern __shared__ uint32_t cursor[];
+  n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins (see direct_hist_kernel)
+  const uint32_t local_mask = (1u << shift) - 1u;
+  __shared__ unsigned long long wsum[kDirectThreads / 64];
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // exclusive scan of the tile totals: `per` consecutive tiles per thread (64-bit: the total may pass 2^32)
+  const int per = (n_tiles + kDirectThreads - 1) / kDirectThreads;           // <= 16
+  const int t0 = (int)threadIdx.x * per;
+  unsigned long long sum = 0;
+  for (int k = 0; k < per; ++k)
+    if (t0 + k < n_tiles) sum += tile_count[t0 + k];
+  unsigned long long incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t lo = __shfl_up((uint32_t)incl, d), hi = __shfl_up((uint32_t)(incl >> 32), d);
+    if (lane >= (unsigned)d) incl += ((unsigned long long)hi << 32) | lo;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned long long off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kDirectThreads / 64; ++w) {
+    if ((unsigned)w < wave) off += wsum[w];
+    total += wsum[w];
+  }
+  unsigned long long ex = off + incl - sum;
+  const uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
+  for (int k = 0; k < per; ++k) {
+    const int t = t0 + k;
+    if (t < n_tiles) {
+      // past the capacity nothing is stored and the lists are cut there (status says so)
+      const uint32_t at = ex < capacity ? (uint32_t)ex : capacity;
+      cursor[t] = ex < capacity ? at + row[t] : capacity;
+      if (blockIdx.x == 0) tile_offsets[t] = (int32_t)at;
+      ex += tile_count[t];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    tile_offsets[n_tiles] = (int32_t)(total < capacity ? (uint32_t)total : capacity);
+    *n_isect = total > 0xffffffffull ? 0xffffffffu : (uint32_t)total;
+    *status = total > capacity ? MGS_STATUS_ISECT_OVERFLOW : 0u;
+  }
+  __syncthreads();
+  const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
+  for (int base = g0; base < g1; base += kDirectThreads) {
+    const int g = base + (int)threadIdx.x;
+    uint32_t pack = kEmptyTileRect, cnt = 0;
+    if (g < g1) {
+      const uint2 info = ginfo[g];
+      pack = info.x; cnt = info.y;
+    }
+    for_each_tile(pack, cnt, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t gs) {
+      const uint32_t p = atomicAdd(&cursor[tile >> shift], 1u);
+      // grouped: the entry carries its tile's place in the group above the id (ids < 2^(32 - shift))
+      if (p < capacity) flatten_ids[p] = shift ? gs | ((tile & local_mask) << (32 - shift)) : gs;
+    });
+  }
+}
+
 // first sorted index of every tile; offsets[n_tiles] = n_isect.  Eight consecutive list entries per
 // thread (two 16-byte loads in flight): an eighth of the waves, each as short-lived as before --
 // with other frames' raster kernels running beside it, wave-slot time is what this kernel costs.
@@ -295,10 +484,17 @@ int bits_for(uint32_t count) {   // bits needed to hold values 0..count-1
   return b;
 }
 
+// Gaussians per workgroup of the direct path's histogram / scatter kernels, and how many workgroups that makes
+unsigned direct_chunk(unsigned n) {
+  const unsigned per_block = max(div_up(n, kDirectMaxBlocks), (unsigned)(kDirectThreads * kDirectPerThread));
+  return div_up(per_block, kDirectThreads) * kDirectThreads;
+}
+unsigned direct_blocks(unsigned n) { return div_up(n, direct_chunk(n)); }
+
 struct Workspace {
   size_t total;
-  size_t ginfo, blocksums, tile_alt, id_alt, radix, tsort;
-  Workspace(int n, uint32_t cap) {
+  size_t ginfo, blocksums, tile_alt, id_alt, radix, tsort, table, tile_count, group_offsets;
+  Workspace(int n, uint32_t cap, int n_tiles) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
     size_t nn = (size_t)(n > 0 ? n : 1), cc = cap ? cap : 1;
@@ -307,6 +503,10 @@ struct Workspace {
     tile_alt = take(cc * 4); id_alt = take(cc * 4);
     radix = take(radix_sort_temp_bytes((uint32_t)cc));
     tsort = take(tile_depth_sort_temp_bytes((uint32_t)cc));
+    const size_t nt = (size_t)(n_tiles < kDirectMaxTiles ? n_tiles : kDirectMaxTiles);   // bins: tiles or tile groups
+    table = take((size_t)direct_blocks((unsigned)nn) * nt * 4);
+    tile_count = take(nt * 4);
+    group_offsets = take((nt + 1) * 4);
     total = o;
   }
 };
@@ -329,7 +529,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   MGS_REQUIRE(tile_w <= 1023 && tile_h <= 1023, "isect_tiles: tile grid %dx%d exceeds 1023x1023", tile_w, tile_h);
   MGS_REQUIRE(workspace_bytes, "isect_tiles: workspace_bytes is null");
   MGS_REQUIRE(cam_id >= 0 && n_cams > cam_id, "isect_tiles: cam_id %d outside 0..%d", cam_id, n_cams);
-  Workspace ws(n, isect_capacity);
+  Workspace ws(n, isect_capacity, tile_w * tile_h);
   if (!workspace) {
     *workspace_bytes = ws.total;
     return MGS_OK;
@@ -349,6 +549,10 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(w + off); };
   const int n_tiles = tile_w * tile_h;
   const uint32_t cap = isect_capacity;
+  // tiles per segment of the direct path: 2^gshift (sort_opts bits 4..6 override; 0 = one tile per segment)
+  const int gshift = (sort_opts() & 8) ? (sort_opts() >> 4) & 7 : kGroupShift;
+  const bool direct = ((n_tiles + (1 << gshift) - 1) >> gshift) <= kDirectMaxTiles && !(sort_opts() & 4) &&
+                      (gshift == 0 || (unsigned)n <= (1u << (32 - gshift)));
   int rc;
 
   if (n == 0) {
@@ -366,28 +570,52 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                          opacities, (float)tile_size, tile_w, tile_h, gi, sums);
       ginfo = gi;
     }
-    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nsum, sums, cap,
-                       n_isect, status);
-    // tile sort: result must land in the caller's buffers
-    const int tile_bits = bits_for((uint32_t)n_tiles);
-    const int passes = (tile_bits + 7) / 8;
-    uint32_t* user_t = tile_ids;
-    uint32_t* user_i = reinterpret_cast<uint32_t*>(flatten_ids);
-    uint32_t *a_t = user_t, *a_i = user_i, *b_t = u32(ws.tile_alt), *b_i = u32(ws.id_alt);
-    if (passes & 1) { a_t = u32(ws.tile_alt); a_i = u32(ws.id_alt); b_t = user_t; b_i = user_i; }
-    hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_w, sums, cap, a_t,
-                       a_i, tiles_per_gauss);
-    if (pair_info)     // training only: the record slots of the backward are the same index-order scan
-      hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h, sums,
-                         reinterpret_cast<int4*>(pair_info));
-    rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
-    if (rc) return rc;
+    if (direct) {
+      if (pair_info) {   // training only: the record slots of the backward are the index-order scan of the counts
+        hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nsum, sums, cap,
+                           (uint32_t*)nullptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h, sums,
+                           reinterpret_cast<int4*>(pair_info));
+      }
+      const int chunk = (int)direct_chunk((unsigned)n);
+      const unsigned nb = direct_blocks((unsigned)n);
+      const int bins = (n_tiles + (1 << gshift) - 1) >> gshift;
+      const size_t lds = (size_t)bins * sizeof(uint32_t);
+      hipLaunchKernelGGL(direct_hist_kernel, dim3(nb), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
+                         n_tiles, gshift, u32(ws.table), tiles_per_gauss);
+      hipLaunchKernelGGL(direct_colscan_kernel, dim3(div_up((unsigned)bins, 16)), dim3(kColThreads), 0, s,
+                         (int)nb, bins, u32(ws.table), u32(ws.tile_count));
+      hipLaunchKernelGGL(direct_scatter_kernel, dim3(nb), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
+                         n_tiles, gshift, u32(ws.table), u32(ws.tile_count), cap,
+                         gshift ? u32(ws.id_alt) : reinterpret_cast<uint32_t*>(flatten_ids),
+                         gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status);
+    } else {
+      hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nsum, sums, cap,
+                         n_isect, status);
+      // tile sort: result must land in the caller's buffers
+      const int tile_bits = bits_for((uint32_t)n_tiles);
+      const int passes = (tile_bits + 7) / 8;
+      uint32_t* user_t = tile_ids;
+      uint32_t* user_i = reinterpret_cast<uint32_t*>(flatten_ids);
+      uint32_t *a_t = user_t, *a_i = user_i, *b_t = u32(ws.tile_alt), *b_i = u32(ws.id_alt);
+      if (passes & 1) { a_t = u32(ws.tile_alt); a_i = u32(ws.id_alt); b_t = user_t; b_i = user_i; }
+      hipLaunchKernelGGL(emit_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_w, sums, cap, a_t,
+                         a_i, tiles_per_gauss);
+      if (pair_info)     // training only: the record slots of the backward are the same index-order scan
+        hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h, sums,
+                           reinterpret_cast<int4*>(pair_info));
+      rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
+      if (rc) return rc;
+    }
   }
-  hipLaunchKernelGGL(tile_offsets_kernel, dim3(div_up(cap, kBlock * kOffsetsPerThread)), dim3(kBlock), 0,
-                     s, n_isect, cap, tile_ids, n_tiles, tile_offsets);
-  if (n > 0) {        // depth order inside every tile's list
+  if (!direct || n == 0)
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(div_up(cap, kBlock * kOffsetsPerThread)), dim3(kBlock), 0,
+                       s, n_isect, cap, tile_ids, n_tiles, tile_offsets);
+  if (n > 0) {        // depth order inside every tile's list (the direct path's lists get their tile ids here)
+    const bool grouped = direct && gshift > 0;
     rc = tile_depth_sort(n_tiles, tile_offsets, depths, cap, reinterpret_cast<uint32_t*>(flatten_ids),
-                         w + ws.tsort, s);
+                         direct ? tile_ids : nullptr, w + ws.tsort, s, grouped ? u32(ws.id_alt) : nullptr,
+                         grouped ? reinterpret_cast<const int32_t*>(w + ws.group_offsets) : nullptr, gshift);
     if (rc) return rc;
   }
   const unsigned gblk = div_up(cap, kBlock);

@@ -26,6 +26,7 @@ PER_SOURCE_FLAGS = {
     "raster_bwd.hip": os.environ.get("MGS_RASTER_BWD_FLAGS", "").split(),
     "raster_fwd.hip": os.environ.get("MGS_RASTER_FWD_FLAGS", "").split(),
     "tile_sort.hip": os.environ.get("MGS_TILE_SORT_FLAGS", "").split(),
+    "binning.hip": os.environ.get("MGS_BINNING_FLAGS", "").split(),
 }
 
 

@@ -407,6 +407,7 @@ int radix_sort_passes(int key_bits) { return (key_bits + 7) / 8; }
 
 static int g_sort_opts = 0;
 extern "C" void mgs_debug_set_sort_opts(int opts) { g_sort_opts = opts; }
+int sort_opts() { return g_sort_opts; }
 
 size_t radix_sort_temp_bytes(uint32_t capacity) {
   size_t nblk_cap = div_up(capacity ? capacity : 1u, Cfg<4>::kTile);   // the smaller tile bounds both

@@ -1,7 +1,7 @@
 // tile_sort.hip -- depth order INSIDE each tile's list, one workgroup per tile (gfx950).
 //
-// The binning partitions the (tile, Gaussian) pairs by tile with a stable radix sort on the tile
-// bits only, which leaves every tile's list in Gaussian-index order.  This kernel then sorts each
+// The binning partitions the (tile, Gaussian) pairs by tile (radix path) or by group of 2^shift tiles (direct
+// path, binning.hip), in no particular order inside a list.  This kernel then sorts each
 // list by (depth bits, Gaussian index) -- exactly the order of the textbook single sort on
 // (tile << 32 | depth) with index-order ties -- so the 1 M-key global
 // depth sort (12 dependent launches) and the rank gather of the first version disappear: one
@@ -69,9 +69,15 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_s
   return off + incl - v;
 }
 
+// GROUPED: the binning's direct path has dropped the pairs of every 2^shift consecutive tiles into one segment
+// of `staging` (entry = id | tile's place in the group << (32 - shift), any order).  The tile's workgroup reads
+// its group's segment (the 2^shift workgroups of a group run side by side: L2 hits), keeps its own entries and
+// counts those of the group's earlier tiles -- which is where its list starts; it stores that offset too.
+template <bool GROUPED>
 __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
-    uint32_t* ids_final, uint32_t* key0, uint32_t* id0, uint32_t* key1, uint32_t* id1) {
+    uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
+    uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out) {
   __shared__ uint32_t cnt[kBuckets];
   __shared__ uint32_t cur[kBuckets];
   __shared__ unsigned long long red_min[kTS / 64], red_max[kTS / 64];
@@ -82,9 +88,62 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
   __shared__ uint32_t lk[kFast], li[kFast];
   const int tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  const int s = offsets[tile], e = offsets[tile + 1];
-  if (e - s <= 1) return;
   const int tid = threadIdx.x;
+  int s, e, gs = 0, ge = 0;
+  uint32_t local = 0, id_mask = ~0u;
+  __shared__ uint32_t gcount[2];           // GROUPED: entries of earlier tiles of the group / of this tile
+  if (GROUPED) {
+    const int grp = tile >> shift;
+    local = (uint32_t)tile & ((1u << shift) - 1u);
+    id_mask = (1u << (32 - shift)) - 1u;
+    gs = offsets[grp]; ge = offsets[grp + 1];          // `offsets` are the groups' here
+    if (tid < 2) gcount[tid] = 0u;
+    __syncthreads();
+    uint32_t below = 0;
+    constexpr int kInFlight = 8;                        // loads in flight per thread (the trips are one latency chain)
+    for (int i0 = gs; i0 < ge; i0 += kTS * kInFlight) { // uniform trips: the wave ranks its matches with one ballot
+      uint32_t vv[kInFlight];
+#pragma unroll
+      for (int j = 0; j < kInFlight; ++j) {
+        const int i = i0 + j * kTS + tid;
+        vv[j] = i < ge ? staging[i] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < kInFlight; ++j) {
+        const int i = i0 + j * kTS + tid;
+        if (i0 + j * kTS >= ge) continue;               // uniform
+        const uint32_t v = vv[j], l = v >> (32 - shift);
+        below += (i < ge && l < local) ? 1u : 0u;
+        const bool mine = i < ge && l == local;
+        const unsigned long long m = __ballot(mine);
+        uint32_t base = 0;
+        if ((tid & 63) == 0 && m) base = atomicAdd(&gcount[1], (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (mine) {
+          const uint32_t pos = base + mask_rank(m);
+          if (pos < (uint32_t)kFast) li[pos] = v & id_mask;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+    if ((tid & 63) == 0 && below) atomicAdd(&gcount[0], below);
+    __syncthreads();
+    s = gs + (int)gcount[0];
+    e = s + (int)gcount[1];
+    if (tid == 0) {
+      offsets_out[tile] = s;
+      if (tile == n_tiles - 1) offsets_out[n_tiles] = e;
+    }
+  } else {
+    s = offsets[tile]; e = offsets[tile + 1];
+  }
+  if (tile_ids)
+    for (int i = s + tid; i < e; i += kTS) tile_ids[i] = (uint32_t)tile;
+  if (e - s <= 1) {
+    if (GROUPED && e - s == 1 && tid == 0) ids_final[s] = li[0];
+    return;
+  }
   const int n = e - s;
 
   if (n <= kFast) {
@@ -97,7 +156,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
       ri[it] = 0u;
       if (it * kTS >= n) continue;
       const int idx = it * kTS + tid;
-      ri[it] = idx < n ? ids_final[s + idx] : 0u;
+      ri[it] = idx < n ? (GROUPED ? li[idx] : ids_final[s + idx]) : 0u;
     }
     unsigned long long mn = ~0ull, mx = 0ull;
 #pragma unroll
@@ -203,11 +262,30 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     if (htot == 0) return;                          // uniform
     __syncthreads();
   } else {
-    // level 0 input: the tile's ids in index order; keys are gathered once and parked in buffer 0
-    for (int i = s + tid; i < e; i += kTS) {
-      const uint32_t id = ids_final[i];
-      key0[i] = __float_as_uint(depths[id]);
-      id0[i] = id;
+    // level 0 input: the tile's ids; keys are gathered once and parked in buffer 0
+    if (GROUPED) {          // longer than the LDS list: collect again, straight into buffer 0
+      if (tid == 0) gcount[1] = 0u;
+      __syncthreads();
+      for (int i0 = gs; i0 < ge; i0 += kTS) {
+        const int i = i0 + tid;
+        const uint32_t v = i < ge ? staging[i] : 0u;
+        const bool mine = i < ge && (v >> (32 - shift)) == local;
+        const unsigned long long m = __ballot(mine);
+        uint32_t base = 0;
+        if ((tid & 63) == 0 && m) base = atomicAdd(&gcount[1], (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (mine) {
+          const uint32_t pos = base + mask_rank(m), id = v & id_mask;
+          key0[s + pos] = __float_as_uint(depths[id]);
+          id0[s + pos] = id;
+        }
+      }
+    } else {
+      for (int i = s + tid; i < e; i += kTS) {
+        const uint32_t id = ids_final[i];
+        key0[i] = __float_as_uint(depths[id]);
+        id0[i] = id;
+      }
     }
     if (tid == 0) {
       stack_n = 1;
@@ -338,12 +416,19 @@ size_t tile_depth_sort_temp_bytes(uint32_t capacity) {
 // Sorts flatten_ids[offsets[t] .. offsets[t+1]) of every tile by (depth bits, id).  temp:
 // tile_depth_sort_temp_bytes(capacity) bytes.
 int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depths, uint32_t capacity,
-                    uint32_t* flatten_ids, void* temp, hipStream_t stream) {
+                    uint32_t* flatten_ids, uint32_t* tile_ids_fill, void* temp, hipStream_t stream,
+                    const uint32_t* staging, const int32_t* group_offsets, int group_shift) {
   if (n_tiles <= 0) return MGS_OK;
   const size_t stride = align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256) / sizeof(uint32_t);
   uint32_t* t = static_cast<uint32_t*>(temp);
-  hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, tile_offsets,
-                     depths, flatten_ids, t, t + stride, t + 2 * stride, t + 3 * stride);
+  if (staging)
+    hipLaunchKernelGGL(tile_depth_sort_kernel<true>, dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, group_offsets,
+                       depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,
+                       staging, group_shift, const_cast<int32_t*>(tile_offsets));
+  else
+    hipLaunchKernelGGL(tile_depth_sort_kernel<false>, dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, tile_offsets,
+                       depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,
+                       (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
   return check_launch("tile_depth_sort");
 }
 

@@ -24,4 +24,6 @@ for rep in range(3):
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 20)
-print(f"{os.environ.get('TAG', '')} binning (unseeded, 12 launches, back to back): {best*1e3:.1f} us  n_isect {int(tl.n_isect)}")
+import hashlib
+digest = hashlib.sha256(tl.flatten_ids[:int(tl.n_isect)].cpu().numpy().tobytes() + tl.tile_offsets.cpu().numpy().tobytes()).hexdigest()[:16]
+print(f"{os.environ.get('TAG', '')} binning (unseeded, back to back): {best*1e3:.1f} us  n_isect {int(tl.n_isect)}  lists sha256 {digest}")

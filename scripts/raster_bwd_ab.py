@@ -14,6 +14,7 @@ tw, th = -(-W // 16), -(-H // 16)
 radii, m2d, dep, con, _, feats, splats = ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, True, want_splats=True)
 tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 4_700_000, want_tiles_per_gauss=False, want_pair_info=True, conics=con, opacities=t["opacities"])
 out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats, latency=True)
+torch.manual_seed(0)
 vr = torch.rand(H, W, 4, device=dev); va = torch.rand(H, W, device=dev)
 def run():
     return ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl, out[1], out[2], vr, va, splats=splats)

@@ -449,3 +449,48 @@ def test_isect_tiles_random_sweep_bit_exact(ops, seed):
     np.testing.assert_array_equal(tl.flatten_ids[:total].cpu().numpy(), r_flat)
     np.testing.assert_array_equal(tl.tile_offsets[:-1].cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th).reshape(-1))
     assert int(tl.tile_offsets[-1]) == total
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_partition_variants_give_identical_lists(ops, seed):
+    """The binning's two ways of bringing a tile's entries together -- the counting sort on tile groups with
+    LDS counters (csrc/binning.hip direct_*_kernel, groups of 1 / 2 / 4 / 8 / 16 tiles) and the stable radix sort
+    on the tile bits -- must hand over identical lists, offsets, tile ids, counts and record slots; with too
+    small a capacity each must flag the overflow and keep every offset inside the buffers."""
+    from robosimgs_amd import _lib
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.choice([300, 4097, 20_000, 70_001]))
+    tw, th = int(rng.choice([3, 13, 30, 121])), int(rng.choice([1, 5, 18, 67]))
+    w, h = tw * 16 - int(rng.integers(0, 16)), th * 16 - int(rng.integers(0, 16))
+    means2d = np.column_stack([rng.uniform(-30, w + 30, n), rng.uniform(-30, h + 30, n)]).astype(np.float32)
+    radii = rng.choice([0, 1, 3, 8, 17, 40, 90], size=n, p=[.2, .2, .2, .2, .1, .07, .03]).astype(np.int32)
+    radii[:3] = 4000                                                        # whole-grid rectangles (walked by the wave)
+    depths = rng.uniform(0.5, 30.0, n).astype(np.float32)
+    depths[rng.integers(0, n, n // 3)] = np.float32(2.5)
+    args = (_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), tw, th)
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, tw, th, dtype=np.float32)
+    total = len(r_flat)
+    lib = _lib.lib()
+    try:
+        for opts in (4, 0x08, 0x18, 0x28, 0x38, 0x48, 0):
+            lib.mgs_debug_set_sort_opts(opts)
+            tl = ops.isect_tiles_raw(*args, total + 5, want_pair_info=True, want_isect_ids=True, want_tiles_per_gauss=True)
+            assert int(tl.n_isect.item()) == total and int(tl.status.item()) == 0, hex(opts)
+            np.testing.assert_array_equal(tl.flatten_ids[:total].cpu().numpy(), r_flat, err_msg=hex(opts))
+            np.testing.assert_array_equal(tl.isect_ids[:total].cpu().numpy(), r_ids, err_msg=hex(opts))
+            np.testing.assert_array_equal(tl.tile_ids[:total].cpu().numpy(), (r_ids >> 32).astype(np.int32), err_msg=hex(opts))
+            np.testing.assert_array_equal(tl.tiles_per_gauss.cpu().numpy(), r_tpg, err_msg=hex(opts))
+            np.testing.assert_array_equal(tl.tile_offsets[:-1].cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th).reshape(-1), err_msg=hex(opts))
+            assert int(tl.tile_offsets[-1]) == total
+            if opts == 4:
+                slots = tl.pair_info.cpu().numpy().copy()
+            else:
+                np.testing.assert_array_equal(tl.pair_info.cpu().numpy(), slots, err_msg=hex(opts))
+            # overflow: a third of the room
+            cap = max(total // 3, 1)
+            tl = ops.isect_tiles_raw(*args, cap)
+            assert int(tl.n_isect.item()) == total and int(tl.status.item()) & _lib.MGS_STATUS_ISECT_OVERFLOW, hex(opts)
+            off = tl.tile_offsets.cpu().numpy()
+            assert off.min() >= 0 and off.max() <= cap and np.all(np.diff(off) >= 0), hex(opts)
+    finally:
+        lib.mgs_debug_set_sort_opts(0)
