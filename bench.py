@@ -346,7 +346,8 @@ def main():
             def raster():
                 return ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h,
                                              tl.tile_offsets, tl.flatten_ids, out=out, track_last=False,
-                                             splats=splats, expected_last=True, latency=lat)
+                                             splats=splats, expected_last=True, latency=lat,
+                                             group_order=tl.group_order)
             for _ in range(5):
                 out = raster()
             e0.record()
@@ -405,26 +406,36 @@ def main():
             "note": "also writes the 48-byte splat records and the binning seed (n_vis * 48 + N * 8 more "
                     "bytes, not counted)"}
 
-        # binning stage (depth keys .. tile offsets) as one HIP-event interval; SURVEY.md 8(d):
-        # n_vis*20 + n_isect*12 (count + emit) + n_isect*24 (sort, ideal 1R+1W) + n_isect*8 + tiles*4
-        def binning():
+        # binning stage (rectangles .. depth-ordered lists + tile offsets) as one HIP-event interval; SURVEY.md 8(d):
+        # n_vis*20 + n_isect*12 (count + emit) + n_isect*24 (sort, ideal 1R+1W) + n_isect*8 + tiles*4.
+        # Timed the way the frame graph runs it -- seeded with the rectangles and counts the fused projection
+        # kernel wrote -- and as the standalone operator, which computes them itself first.
+        seed = proj()[-1]
+        def binning(seeded):
             return ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False,
-                                       conics=con, opacities=t["opacities"])
-        for _ in range(5):
-            binning()
-        e0.record()
-        for _ in range(reps):
-            binning()
-        e1.record()
-        torch.cuda.synchronize()
-        bin_ms = e0.elapsed_time(e1) / reps
+                                       conics=con, opacities=t["opacities"], seed=seed if seeded else None)
+        bin_times = {}
+        for seeded in (True, False):
+            for _ in range(5):
+                tl_b = binning(seeded)
+            e0.record()
+            for _ in range(reps):
+                binning(seeded)
+            e1.record()
+            torch.cuda.synchronize()
+            bin_times[seeded] = e0.elapsed_time(e1) / reps
+            assert int(tl_b.n_isect.item()) == n_isect_binned, "seeded and unseeded binning disagree"
+        bin_ms = bin_times[True]
         bin_bytes = n_vis * 20 + n_isect * 44 + tile_w * tile_h * 4
         result["roofline_binning"] = {
-            "kernels": "mgs_isect_tiles (unseeded: tile counts, scan, emit, tile radix sort, tile offsets, per-tile depth sort)", "bound": "hbm",
+            "kernels": "mgs_isect_tiles: histogram of the tile groups, column scan, scatter, per-tile depth sort "
+                       "(+ tile rectangles and counts when not seeded by the projection kernel)", "bound": "hbm",
             "achieved": round(bin_bytes / (bin_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(bin_bytes / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": bin_bytes, "stage_ms": round(bin_ms, 4),
-            "note": "eager launches back to back on one stream (the frame graph replays the same kernels)"}
+            "stage_ms_standalone_operator": round(bin_times[False], 4),
+            "note": "eager launches back to back on one stream (the frame graph replays the same kernels); "
+                    "algorithmic bytes price the classic lists (n_isect), the stage bins the tightened ones"}
 
         # ---- training-step variant (configs[2]): forward + L1 + backward ------------------
         try:

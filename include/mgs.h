@@ -150,8 +150,9 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * isect_ids[capacity] (nullable) receives those int64 keys, with `cam_id` folded in above
  * the tile bits exactly as gsplat encodes them.
  *
- * Internally: 32-bit radix sort of the Gaussians by depth, an exclusive scan of tile
- * counts in that order, a load-balanced emit, and a radix sort on the tile bits only.
+ * Internally (csrc/binning.hip, tile_sort.hip): a counting sort of the (tile, Gaussian) pairs on
+ * groups of four tiles with LDS-resident counters (histogram, column scan, scatter), then one
+ * workgroup per tile orders its list by (depth bits, Gaussian index).
  *
  * conics[N,3], opacities[N] (both nullable): when given, each Gaussian's tile rectangle is
  * tightened to the tiles holding a pixel centre it can reach with alpha >= 1/255 (bounding
@@ -168,6 +169,10 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * rectangle; the pair (g, tile (tx,ty)) owns slot slot_base + (ty - y0) * w + (tx - x0) in
  * [0, n_isect); slot bases ascend with the Gaussian index.  Consumed by
  * mgs_rasterize_bwd_det.
+ * tile_group_order[ceil(n_tiles / 4)] (nullable): launch order for the raster kernels -- the
+ * groups of four consecutive tiles {4g .. 4g+3} by falling total list length (longest first; a
+ * permutation of the group indices).  Pass it to mgs_rasterize_fwd / mgs_rasterize_bwd_det; it
+ * changes their schedule only, never a result.
  * seed_info / seed_sums (nullable, together): bin_info / bin_sums as written by
  * mgs_project_color_fwd for the same camera, tile grid and tight / classic choice; when given,
  * means2d / radii / conics / opacities are not read (and may be NULL) and seed_sums is
@@ -178,8 +183,8 @@ int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const flo
                     int tile_h, int cam_id, int n_cams,
                     uint32_t isect_capacity, int32_t *tiles_per_gauss, uint32_t *n_isect,
                     uint32_t *tile_ids, int32_t *flatten_ids, int64_t *isect_ids,
-                    int32_t *tile_offsets, int32_t *pair_info, uint32_t *status,
-                    const uint32_t *seed_info, uint32_t *seed_sums,
+                    int32_t *tile_offsets, int32_t *pair_info, int32_t *tile_group_order,
+                    uint32_t *status, const uint32_t *seed_info, uint32_t *seed_sums,
                     void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
 
 /* gsplat `isect_offset_encode`: first sorted index per (cam, tile) from sorted int64 keys.
@@ -200,12 +205,15 @@ int mgs_isect_offset_encode(uint32_t n_isect, const int64_t *isect_ids, int n_ca
  *   given, means2d / conics / feats / opacities are not read (and may be NULL).
  *   flags: MGS_RASTER_EXPECTED_LAST divides the last channel (after the background term) by
  *   max(alpha, 1e-10) in the epilogue -- the "ED" / "RGB+ED" render modes
- *   without a second pass over the frame.
+ *   without a second pass over the frame.  MGS_RASTER_LATENCY: one wave per 8x8 block instead of
+ *   one per tile (same pixels, shorter launch when the GPU is not shared with other frames).
+ *   tile_group_order (nullable): from mgs_isect_tiles; tiles are then started longest lists first.
  * ----------------------------------------------------------------------------------- */
 int mgs_rasterize_fwd(int n, const float *means2d, const float *conics, const float *feats,
                       const float *opacities, const float *splats, const float *background,
                       int channels, int width, int height, int tile_w, int tile_h,
-                      const int32_t *tile_offsets, const int32_t *flatten_ids, int flags,
+                      const int32_t *tile_offsets, const int32_t *flatten_ids,
+                      const int32_t *tile_group_order, int flags,
                       float *render, float *alphas, int32_t *last_ids, mgs_stream_t stream);
 
 /*   v_render[H,W,channels], v_alphas[H,W] incoming; v_means2d[N,2] v_conics[N,3]
@@ -230,6 +238,7 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
  *   MGS_RASTER_EXPECTED_LAST -- v_render's last channel is then the cotangent of
  *   channel / max(alpha, 1e-10) and the kernel's prologue converts it (and v_alphas) back to the
  *   cotangents of the un-normalised blend: no pass over the frame in between.
+ *   tile_group_order (nullable): from mgs_isect_tiles; when NULL the call computes the order itself.
  */
 int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, const float *feats,
                           const float *opacities, const float *splats, const float *background,
@@ -237,7 +246,7 @@ int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, cons
                           const int32_t *tile_offsets, const int32_t *flatten_ids,
                           const float *alphas, const int32_t *last_ids, const float *v_render,
                           const float *v_alphas, const float *expected_render,
-                          const int32_t *pair_info,
+                          const int32_t *pair_info, const int32_t *tile_group_order,
                           uint32_t isect_capacity, float *v_means2d, float *v_means2d_abs,
                           float *v_conics, float *v_feats, float *v_opacities, void *workspace,
                           size_t *workspace_bytes, mgs_stream_t stream);

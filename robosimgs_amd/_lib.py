@@ -42,9 +42,9 @@ def _load() -> ctypes.CDLL:
         "mgs_sh_bwd": ([i, i, i, p, p, p, p, p, p, p], c_int),
         "mgs_project_color_fwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, f, f, f, p, p, p, p, p, i, p, p, i, p, p, p], c_int),
         "mgs_project_color_bwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, i, p], c_int),
-        "mgs_isect_tiles": ([i, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_isect_tiles": ([i, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
-        "mgs_rasterize_fwd": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, i, p, p, p, p], c_int),
+        "mgs_rasterize_fwd": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, i, p, p, p, p], c_int),
         "mgs_rasterize_bwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_composite_over": ([i, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_points_project": ([i, p, p, p, p, p, p], c_int),
@@ -54,7 +54,7 @@ def _load() -> ctypes.CDLL:
         "mgs_transform_gaussians": ([i, p, p, p, i, i, p, p, i, p, p, p, p, p, p, p], c_int),
         "mgs_l1_loss_fwd": ([c_size_t, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_l1_loss_bwd": ([c_size_t, p, p, p, p, p], c_int),
-        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, u32, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, u32, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch

@@ -19,6 +19,7 @@
 // gives the backward's record slots (pair_info), so training runs it on either path.
 #include "mgs_common.h"
 #include "tile_rect.h"
+#include "tile_order.h"
 
 namespace mgs {
 namespace {
@@ -250,7 +251,7 @@ constexpr int kDirectThreads = MGS_DIRECT_THREADS;
 #endif
 constexpr int kDirectPerThread = MGS_DIRECT_PER_THREAD;   // Gaussians per thread of those kernels
 constexpr int kDirectMaxBlocks = 1024;         // table rows (more Gaussians than 4 x threads x this: longer runs per workgroup)
-constexpr int kDirectMaxTiles = 16320;         // the LDS histogram: 4 bytes per tile in 64 KiB, less the static part
+constexpr int kDirectMaxTiles = 15000;         // the LDS histogram: 4 bytes per bin in 64 KiB, less the static part
 constexpr int kGroupShift = 2;                 // 2^2 consecutive tiles share a segment (1 / 2 / 4 / 8 / 16 tiles: 124 / 113 / 112 / 124 / 150 us)
 constexpr uint32_t kCoopRect = 24;             // rectangles above this many tiles are walked by the whole wave
 
@@ -349,9 +350,15 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     int n, int chunk, const uint2* __restrict__ ginfo, int tile_w, int n_tiles, int shift,
     const uint32_t* __restrict__ table, const uint32_t* __restrict__ tile_count, uint32_t capacity,
     uint32_t* __restrict__ flatten_ids, int32_t* __restrict__ tile_offsets,
-    uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
+    uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status, int32_t* __restrict__ group_order) {
   extern __shared__ uint32_t cursor[];
   n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins (see direct_hist_kernel)
+  if (group_order && blockIdx.x == gridDim.x - 1) {
+    // one workgroup more than the scatter needs: the launch order of the raster kernels (tile_order.h) from the
+    // bin totals -- bins are groups of four tiles here (shift == 2) -- beside the scatter, at no cost in time
+    order_groups_by_total<kDirectThreads>(n_tiles, [&](int g) { return tile_count[g]; }, group_order);
+    return;
+  }
   const uint32_t local_mask = (1u << shift) - 1u;
   __shared__ unsigned long long wsum[kDirectThreads / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -478,6 +485,13 @@ __global__ __launch_bounds__(kBlock) void offset_encode_kernel(
     for (int k = cur + 1; k < total; ++k) offsets[k] = (int32_t)n;
 }
 
+__global__ __launch_bounds__(1024) void tile_group_order_kernel(int n_tiles, const int32_t* __restrict__ tile_offsets,
+                                                                int32_t* __restrict__ order) {
+  order_groups_by_total<1024>((n_tiles + 3) / 4, [&](int g) {
+    return (uint32_t)(tile_offsets[min(4 * g + 4, n_tiles)] - tile_offsets[4 * g]);
+  }, order);
+}
+
 int bits_for(uint32_t count) {   // bits needed to hold values 0..count-1
   int b = 0;
   while (count > 1 && (1ull << b) < count) ++b;
@@ -514,6 +528,13 @@ struct Workspace {
 }  // namespace
 }  // namespace mgs
 
+namespace mgs {
+int launch_tile_group_order(int n_tiles, const int32_t* tile_offsets, int32_t* order, hipStream_t stream) {
+  hipLaunchKernelGGL(tile_group_order_kernel, dim3(1), dim3(1024), 0, stream, n_tiles, tile_offsets, order);
+  return check_launch("tile_group_order");
+}
+}  // namespace mgs
+
 using namespace mgs;
 
 extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii,
@@ -522,7 +543,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                                int cam_id, int n_cams, uint32_t isect_capacity,
                                int32_t* tiles_per_gauss, uint32_t* n_isect, uint32_t* tile_ids,
                                int32_t* flatten_ids, int64_t* isect_ids, int32_t* tile_offsets,
-                               int32_t* pair_info, uint32_t* status, const uint32_t* seed_info,
+                               int32_t* pair_info, int32_t* tile_group_order, uint32_t* status,
+                               const uint32_t* seed_info,
                                uint32_t* seed_sums, void* workspace,
                                size_t* workspace_bytes, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "isect_tiles: bad sizes");
@@ -554,6 +576,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   const bool direct = ((n_tiles + (1 << gshift) - 1) >> gshift) <= kDirectMaxTiles && !(sort_opts() & 4) &&
                       (gshift == 0 || (unsigned)n <= (1u << (32 - gshift)));
   int rc;
+  bool order_done = false;
 
   if (n == 0) {
     (void)hipMemsetAsync(n_isect, 0, 4, s);
@@ -585,10 +608,13 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                          n_tiles, gshift, u32(ws.table), tiles_per_gauss);
       hipLaunchKernelGGL(direct_colscan_kernel, dim3(div_up((unsigned)bins, 16)), dim3(kColThreads), 0, s,
                          (int)nb, bins, u32(ws.table), u32(ws.tile_count));
-      hipLaunchKernelGGL(direct_scatter_kernel, dim3(nb), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
+      const bool order_in_scatter = tile_group_order && gshift == 2;
+      order_done = order_in_scatter;
+      hipLaunchKernelGGL(direct_scatter_kernel, dim3(nb + (order_in_scatter ? 1 : 0)), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
                          n_tiles, gshift, u32(ws.table), u32(ws.tile_count), cap,
                          gshift ? u32(ws.id_alt) : reinterpret_cast<uint32_t*>(flatten_ids),
-                         gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status);
+                         gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status,
+                         order_in_scatter ? tile_group_order : nullptr);
     } else {
       hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nsum, sums, cap,
                          n_isect, status);
@@ -616,6 +642,10 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     rc = tile_depth_sort(n_tiles, tile_offsets, depths, cap, reinterpret_cast<uint32_t*>(flatten_ids),
                          direct ? tile_ids : nullptr, w + ws.tsort, s, grouped ? u32(ws.id_alt) : nullptr,
                          grouped ? reinterpret_cast<const int32_t*>(w + ws.group_offsets) : nullptr, gshift);
+    if (rc) return rc;
+  }
+  if (tile_group_order && !order_done) {
+    rc = launch_tile_group_order(n_tiles, tile_offsets, tile_group_order, s);
     if (rc) return rc;
   }
   const unsigned gblk = div_up(cap, kBlock);

@@ -13,6 +13,7 @@
 //     lane 63, one hardware float atomic per component.  Scattered device atomics sustain only
 //     ~25-30 G/s on MI355X, which made this variant 1.38 ms against 0.78 ms for the records.
 #include "raster_common.h"
+#include "tile_order.h"
 
 namespace mgs {
 namespace {
@@ -154,9 +155,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
   static_assert(!HALF || RECORDS, "half tiles exist on the record path only");
   constexpr int NQ = HALF ? 2 : 4;                 // 8x8 blocks per wave
   const int unit = blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6);
-  if ((HALF ? unit >> 1 : unit) >= n_tiles) return;
-  // tile_order: the tiles by falling list length (tile_order_kernel), so that the longest walks start first
-  const int tile = HALF ? unit >> 1 : (tile_order ? tile_order[unit] : unit), half = HALF ? unit & 1 : 0;
+  // tile_order: groups of four tiles by falling list length (tile_order.h), so that the longest walks start first
+  const int tile = HALF ? (unit >> 1 < n_tiles ? unit >> 1 : -1) : tile_of_unit(unit, n_tiles, tile_order);
+  const int half = HALF ? unit & 1 : 0;
+  if (tile < 0) return;
   const unsigned lane = threadIdx.x & 63u;
   const int tx = tile % tile_w, ty = tile / tile_w;
   const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
@@ -462,49 +464,6 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
   }
 }
 
-// Launch order of the tiles: by falling list length (1024 length classes, counting sort in one workgroup).  A tile
-// is one wave's serial job and the hardware starts workgroups in index order; with the long lists first the
-// short ones fill the end of the launch instead of a long one starting last (longest-processing-time-first).
-// The order inside a class is whatever the LDS atomics give -- it changes the schedule, never a result.
-constexpr int kOrderBins = 1024;
-__global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int32_t* __restrict__ tile_offsets,
-                                                          int32_t* __restrict__ order) {
-  __shared__ int hist[kOrderBins];
-  __shared__ int wave_tot[16];
-  __shared__ int max_len;
-  const int t = threadIdx.x;
-  hist[t] = 0;
-  if (t == 0) max_len = 1;
-  __syncthreads();
-  int m = 1;
-  for (int i = t; i < n_tiles; i += 1024) m = max(m, tile_offsets[i + 1] - tile_offsets[i]);
-  atomicMax(&max_len, m);
-  __syncthreads();
-  const float scale = (float)(kOrderBins - 1) / (float)max_len;
-  auto bin_of = [&](int i) {
-    const int len = tile_offsets[i + 1] - tile_offsets[i];
-    return kOrderBins - 1 - min(kOrderBins - 1, (int)((float)len * scale));     // longest first
-  };
-  for (int i = t; i < n_tiles; i += 1024) atomicAdd(&hist[bin_of(i)], 1);
-  __syncthreads();
-  // exclusive scan of the 1024 class counts: within each wave by shifts, then over the 16 wave totals
-  const int mine = hist[t];
-  int incl = mine;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(incl, d);
-    if ((t & 63) >= d) incl += up;
-  }
-  if ((t & 63) == 63) wave_tot[t >> 6] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < (t >> 6); ++w) base += wave_tot[w];
-  __syncthreads();
-  hist[t] = base + incl - mine;
-  __syncthreads();
-  for (int i = t; i < n_tiles; i += 1024) order[atomicAdd(&hist[bin_of(i)], 1)] = i;
-}
-
 // Sum the records of each Gaussian's slots (its tile rectangle, emit order) into the outputs.
 template <int CHT, bool ABSGRAD, int SLOTS = 1>      // SLOTS: record slots per (tile, Gaussian) pair (2: half tiles)
 __global__ __launch_bounds__(256) void reduce_records_kernel(
@@ -631,7 +590,8 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                                      const float* alphas, const int32_t* last_ids,
                                      const float* v_render, const float* v_alphas,
                                      const float* expected_render,
-                                     const int32_t* pair_info, uint32_t isect_capacity,
+                                     const int32_t* pair_info, const int32_t* tile_group_order,
+                                     uint32_t isect_capacity,
                                      float* v_means2d, float* v_means2d_abs, float* v_conics,
                                      float* v_feats, float* v_opacities, void* workspace,
                                      size_t* workspace_bytes, mgs_stream_t stream) {
@@ -666,13 +626,19 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   hipError_t e = hipMemsetAsync(flags, 0, cap * kSlots, s);
   if (e != hipSuccess) return set_error((int)e, "rasterize_bwd_det: memset: %s", hipGetErrorString(e));
   const int4* info = reinterpret_cast<const int4*>(pair_info);
-  int32_t* order = nullptr;
+  const int32_t* order = nullptr;
   if (!kHalf && MGS_RASTER_BWD_ORDER) {
-    order = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_offsets, order);
+    order = tile_group_order;
+    if (!order) {       // the caller's lists came without one (mgs_isect_tiles writes it): compute it here
+      int32_t* mine = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes);
+      const int rc = launch_tile_group_order(n_tiles, tile_offsets, mine, s);
+      if (rc) return rc;
+      order = mine;
+    }
   }
+  const int n_units = order ? (n_tiles + 3) / 4 * 4 : n_tiles * (int)kSlots;
 #define MGS_RD_LAUNCH(C, A)                                                                     \
-  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf>), dim3(div_up(n_tiles * (int)kSlots, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), 0, s, means2d,   \
+  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf>), dim3(div_up(n_units, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), 0, s, means2d,   \
                      conics, feats, opacities, reinterpret_cast<const float4*>(splats),        \
                      background, channels, width, height, tile_w,                              \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \

@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "raster_common.h"
+#include "tile_order.h"
 
 #ifndef MGS_RASTER_WAVES
 // min waves per SIMD asked of the register allocator; 8 / 6 / 5 spill and lose (profiles/r1/05)
@@ -96,12 +97,13 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
-    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last, int opts) {
+    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last, int opts,
+    const int32_t* __restrict__ group_order) {
   constexpr int kWgWaves = TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES;
   __shared__ QueueEntry<CHT> queues[kWgWaves][kQueue + 1];
   QueueEntry<CHT>* queue = queues[threadIdx.x >> 6];
-  const int tile = blockIdx.x * kWgWaves + (int)(threadIdx.x >> 6);
-  if (tile >= n_tiles) return;
+  const int tile = tile_of_unit(blockIdx.x * kWgWaves + (int)(threadIdx.x >> 6), n_tiles, group_order);   // tile_order.h
+  if (tile < 0) return;
   const unsigned lane = threadIdx.x & 63u;
   const int tx = tile % tile_w, ty = tile / tile_w;
   const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
-    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last) {
+    float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last,
+    const int32_t* __restrict__ group_order) {
   __shared__ QueueEntry<CHT> queues[4][kQueue];
 #ifdef MGS_RASTER_Q_VGPR_CLOBBER
   // occupancy experiment: naming a high VGPR raises the kernel's register allocation (and lowers its
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(
 #endif
   const int k = (int)(threadIdx.x >> 6);
   QueueEntry<CHT>* queue = queues[k];
-  const int tile = blockIdx.x;
+  const int tile = tile_of_unit(blockIdx.x, n_tiles, group_order);      // tile_order.h
+  if (tile < 0) return;
   const unsigned lane = threadIdx.x & 63u;
   const int tx = tile % tile_w, ty = tile / tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
@@ -458,6 +462,7 @@ extern "C" void mgs_debug_set_raster_cull(int enabled) { g_raster_cull = enabled
 //   bit 0: issue priority by tile-list length in the one-wave-per-tile kernel (default on)
 //   bit 1: honour MGS_RASTER_LATENCY (one wave per 8x8 block, raster_fwd_q_kernel, <= 4 channels); default on
 //   bit 2: use that kernel whatever the flags say
+//   bit 3: ignore tile_group_order (index-order launch); bit 4: ignore it in the one-wave-per-tile inference kernel only
 //   bits 8..: KiB of unused dynamic LDS per workgroup of that kernel (caps its occupancy: experiments)
 static int g_raster_opts = 3;
 extern "C" void mgs_debug_set_raster_opts(int opts) { g_raster_opts = opts; }
@@ -476,8 +481,8 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
                                  const float* feats, const float* opacities, const float* splats,
                                  const float* background, int channels, int width, int height,
                                  int tile_w, int tile_h, const int32_t* tile_offsets,
-                                 const int32_t* flatten_ids, int flags, float* render,
-                                 float* alphas, int32_t* last_ids, mgs_stream_t stream) {
+                                 const int32_t* flatten_ids, const int32_t* tile_group_order, int flags,
+                                 float* render, float* alphas, int32_t* last_ids, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_fwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
@@ -488,18 +493,21 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
   const bool per_block = (g_raster_opts & 4) || ((g_raster_opts & 2) && (flags & MGS_RASTER_LATENCY));
+  if (g_raster_opts & 8) tile_group_order = nullptr;
+  if ((g_raster_opts & 16) && !per_block && !last_ids) tile_group_order = nullptr;
+  const int n_units = tile_group_order ? (n_tiles + 3) / 4 * 4 : n_tiles;       // tile slots of the launch
 #define MGS_RF_LAUNCH_T(C, T)                                                                  \
-  hipLaunchKernelGGL((raster_fwd_kernel<C, T>), dim3(div_up(n_tiles, (T) ? 1 : MGS_RASTER_WG_WAVES)),   \
+  hipLaunchKernelGGL((raster_fwd_kernel<C, T>), dim3(div_up(n_units, (T) ? 1 : MGS_RASTER_WG_WAVES)),   \
                      dim3(64 * ((T) ? 1 : MGS_RASTER_WG_WAVES)), 0, s, means2d, conics,           \
                      feats, opacities, reinterpret_cast<const float4*>(splats), background,     \
                      channels, width, height, tile_w, n_tiles,                                 \
                      tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull,            \
-                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, g_raster_opts)
+                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, g_raster_opts, tile_group_order)
 #define MGS_RQ_LAUNCH_T(C, T)                                                                  \
-  hipLaunchKernelGGL((raster_fwd_q_kernel<C, T>), dim3(n_tiles), dim3(256), (size_t)(g_raster_opts >> 8) * 1024, s, means2d, conics, feats,  \
+  hipLaunchKernelGGL((raster_fwd_q_kernel<C, T>), dim3(n_units), dim3(256), (size_t)(g_raster_opts >> 8) * 1024, s, means2d, conics, feats,  \
                      opacities, reinterpret_cast<const float4*>(splats), background, channels, width,      \
                      height, tile_w, n_tiles, tile_offsets, flatten_ids, render, alphas, last_ids,         \
-                     g_raster_cull, (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0)
+                     g_raster_cull, (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, tile_group_order)
 #define MGS_RF_LAUNCH(C) do {                                                                      \
     if (per_block && (C) <= 4) { if (last_ids) MGS_RQ_LAUNCH_T(C, true); else MGS_RQ_LAUNCH_T(C, false); } \
     else if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)

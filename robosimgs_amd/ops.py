@@ -89,7 +89,7 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
 class TileLists:
     """Depth-ordered per-tile lists of one camera (device resident, capacity sized)."""
     __slots__ = ("n_isect", "tile_ids", "flatten_ids", "tile_offsets", "tiles_per_gauss",
-                 "isect_ids", "status", "capacity", "pair_info")
+                 "isect_ids", "status", "capacity", "pair_info", "group_order")
 
 
 _workspaces: dict = {}
@@ -128,12 +128,14 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
                            if want_tiles_per_gauss else None)
     out.isect_ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_isect_ids else None
     out.pair_info = torch.empty(n, 4, dtype=torch.int32, device=dev) if want_pair_info else None
+    # launch order of the raster kernels' tiles (groups of four, longest lists first): a schedule, not a result
+    out.group_order = torch.empty((tile_w * tile_h + 3) // 4, dtype=torch.int32, device=dev)
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), TILE_SIZE,
             tile_w, tile_h, cam_id, n_cams,
             capacity, ptr(out.tiles_per_gauss), ptr(out.n_isect), ptr(out.tile_ids),
             ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.pair_info),
-            ptr(out.status), ptr(seed[0]) if seed else None, ptr(seed[1]) if seed else None]
+            ptr(out.group_order), ptr(out.status), ptr(seed[0]) if seed else None, ptr(seed[1]) if seed else None]
     check(L.mgs_isect_tiles(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_isect_tiles(size query)")
     ws = _workspace(nbytes.value, dev)
@@ -145,12 +147,13 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                       tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None,
-                      expected_last=False, latency=False):
+                      expected_last=False, latency=False, group_order=None):
     """out = (render, alphas, last_ids|None) to write into existing buffers.  track_last=False (or
     last_ids None) is the inference variant: no last_ids, one select less per pair.
     expected_last: the last channel leaves divided by max(alpha, 1e-10) ("ED" modes).
     latency: MGS_RASTER_LATENCY -- one wave per 8x8 block; faster when the launch has the GPU to itself
-    (a single frame, a training step), slower in total work when several frames are in flight."""
+    (a single frame, a training step), slower in total work when several frames are in flight.
+    group_order: TileLists.group_order -- the tiles are then started longest lists first."""
     n = means2d.shape[0]
     ch = feats.shape[-1]
     dev = means2d.device
@@ -163,7 +166,8 @@ def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, heig
         render, alphas, last_ids = out
     check(_lib.lib().mgs_rasterize_fwd(n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities),
                                        ptr(splats), ptr(background), ch, width, height, tile_w, tile_h,
-                                       ptr(tile_offsets), ptr(flatten_ids), int(bool(expected_last)) | (2 if latency else 0),
+                                       ptr(tile_offsets), ptr(flatten_ids), ptr(group_order),
+                                       int(bool(expected_last)) | (2 if latency else 0),
                                        ptr(render), ptr(alphas), ptr(last_ids), stream_handle()),
           "mgs_rasterize_fwd")
     return render, alphas, last_ids
@@ -213,7 +217,8 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities), ptr(splats), ptr(background),
             ch, width, height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
-            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(expected_render), ptr(tl.pair_info), tl.capacity,
+            ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(expected_render), ptr(tl.pair_info),
+            ptr(getattr(tl, "group_order", None)), tl.capacity,
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det(size query)")

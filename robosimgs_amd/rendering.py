@@ -86,7 +86,8 @@ class _RenderSH(torch.autograd.Function):
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
                                   out=(render[c], alphas[c], last_ids[c] if training else None),
-                                  splats=splats, expected_last=expected_depth, latency=latency)
+                                  splats=splats, expected_last=expected_depth, latency=latency,
+                                  group_order=tl.group_order)
             per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl, splats))
         ctx.per_cam = per_cam
         # "RGB+ED": the kernel's epilogue divided the depth channel by max(alpha, 1e-10); the

@@ -494,3 +494,38 @@ def test_partition_variants_give_identical_lists(ops, seed):
             assert off.min() >= 0 and off.max() <= cap and np.all(np.diff(off) >= 0), hex(opts)
     finally:
         lib.mgs_debug_set_sort_opts(0)
+
+
+@pytest.mark.parametrize("w,h", [(200, 120), (96, 80), (1000, 40)])
+def test_tile_group_order_is_a_schedule_not_a_result(ops, w, h):
+    """mgs_isect_tiles' tile_group_order: a permutation of the groups of four tiles, longest total list first
+    (1024 length classes), identical in meaning on the direct and the radix partition; the raster kernels
+    produce the same bits with it, without it, and on either schedule (also where the tile count is no multiple
+    of four)."""
+    from robosimgs_amd import _lib
+    g, cam = _scene(6000, 0.1, 1, w, h)
+    lib = _lib.lib()
+    try:
+        frames = []
+        for opts in (0, 4):
+            lib.mgs_debug_set_sort_opts(opts)
+            t, radii, means2d, depths, conics, feats, tl, tw, th = _raster_inputs(ops, g, cam, w, h, 1)
+            n_groups = (tw * th + 3) // 4
+            order = tl.group_order.cpu().numpy()
+            assert sorted(order.tolist()) == list(range(n_groups))
+            off = tl.tile_offsets.cpu().numpy().astype(np.int64)
+            totals = np.array([off[min(4 * k + 4, tw * th)] - off[4 * k] for k in range(n_groups)])
+            cls = np.minimum(1023, (totals[order].astype(np.float32) * np.float32(1023.0 / max(totals.max(), 1))).astype(np.int64))
+            assert np.all(np.diff(cls) <= 0), "length classes must fall along the order"
+            for go in (None, tl.group_order):
+                for lat in (False, True):
+                    for track in (False, True):
+                        frames.append(ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, w, h, tw, th,
+                                                            tl.tile_offsets, tl.flatten_ids, track_last=track,
+                                                            latency=lat, group_order=go))
+        for f in frames[1:]:
+            assert torch.equal(f[0], frames[0][0]) and torch.equal(f[1], frames[0][1])
+            if f[2] is not None:
+                assert torch.equal(f[2], frames[1][2])
+    finally:
+        lib.mgs_debug_set_sort_opts(0)
