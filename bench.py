@@ -11,7 +11,12 @@ libmgs.so, replayed as one HIP graph with the scene resident in HBM.
 N > 1 (configs[3]; launched by torch.distributed.run, one process per GPU over RCCL): a step is one
 pass over the 64-camera novel-view ring theta_k = 2 pi k / 64; rank r renders the contiguous block
 shard_cameras(64, N, r) through its FrameRenderer and rank 0 gathers all 64 finished frames (fp32
-RGB + depth + alpha by default, `--gather-dtype u8` for the 8-bit images a dataset writer stores).
+RGB + depth + alpha, 20 bytes per pixel, is the payload `value` is measured with; the same run then times
+the ring again with the 8-bit RGB images a dataset writer stores and reports that rate beside it as
+config.gather_other_payload -- `--gather-dtype u8` swaps the two, `--one-payload` skips the second).
+The fp32 payload is 41.5 MB per frame: at 8 ranks rank 0 takes 7/8 of every frame over its seven xGMI
+links, which bounds the whole job near 350 GB/s / 41.5 MB = 8-9 k frames/s whatever the renderers do; the
+8-bit payload (6.2 MB per frame) is bounded at ~55 k frames/s and shows the renderers' own scaling.
 Total work is fixed as N grows: scaling is "strong"; value = frames all ranks rendered / time.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
@@ -78,6 +83,7 @@ def parse():
     ap.add_argument("--debug-single-device-gloo", action="store_true")
     # debugging aid: run the N > 1 leg (camera ring + gather) in a world of one
     ap.add_argument("--force-gather", action="store_true")
+    ap.add_argument("--one-payload", action="store_true", help="N > 1: time only --gather-dtype, not the other payload too")
     return ap.parse_args()
 
 
@@ -166,105 +172,121 @@ def main():
 
     do_gather = use_dist and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
-    g_u8 = a.gather_dtype == "u8"
-    g_dtype = torch.uint8 if g_u8 else torch.float32
-    g_ch = 3 if g_u8 else 5                            # u8: RGB; fp32: RGB, expected depth, alpha
     # Frames leave in batches of `gather_batch` through a double-buffered staging area: the frame is
     # converted (u8) or copied (fp32) into its place in the batch, the slot is released at once, and
     # every gather_batch-th frame one collective ships the whole batch -- a per-frame collective
     # costs ~80 us of launch / stream hand-over each, a quarter of a frame time.
     GB = max(1, min(a.gather_batch, max(1, math.ceil(RING / world)))) if ring else 1
-    batch_shape = (GB, H, W, g_ch)
-    staging = [torch.empty(batch_shape, device=dev, dtype=g_dtype) for _ in range(2)] if do_gather else None
-    host_staging = ([torch.empty(batch_shape, device="cpu", dtype=g_dtype) for _ in range(2)]
-                    if do_gather and debug_gloo else None)          # gloo debugging mode only
-    gather_bufs = None
-    if do_gather and rank == 0:
-        gather_bufs = [[torch.empty(batch_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
-                       for _ in range(2)]
-    pending = [None, None]
-    state = {"cur": 0, "fill": 0, "shipped": 0}
-    tickets = []
 
-    def ship():
-        """One collective for the frames staged so far (stream-ordered after their conversion)."""
-        cur = state["cur"]
-        src = staging[cur]
-        if debug_gloo:
-            host_staging[cur].copy_(src)                           # synchronous host copy
-            src = host_staging[cur]
-        pending[cur] = dist.gather(src, gather_bufs[cur] if rank == 0 else None, dst=0, async_op=True)
-        state["cur"], state["fill"] = cur ^ 1, 0
-        state["shipped"] += 1
+    def time_frames(g_u8):
+        """Warm-up, then regions of K steps until min_seconds are timed; the gathered payload is fp32 RGB +
+        expected depth + alpha (g_u8 False) or the 8-bit RGB image (g_u8 True).  Returns (regions, collectives)."""
+        g_dtype = torch.uint8 if g_u8 else torch.float32
+        g_ch = 3 if g_u8 else 5                            # u8: RGB; fp32: RGB, expected depth, alpha
+        batch_shape = (GB, H, W, g_ch)
+        staging = [torch.empty(batch_shape, device=dev, dtype=g_dtype) for _ in range(2)] if do_gather else None
+        host_staging = ([torch.empty(batch_shape, device="cpu", dtype=g_dtype) for _ in range(2)]
+                        if do_gather and debug_gloo else None)          # gloo debugging mode only
+        gather_bufs = None
+        if do_gather and rank == 0:
+            gather_bufs = [[torch.empty(batch_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
+                           for _ in range(2)]
+        pending = [None, None]
+        state = {"cur": 0, "fill": 0, "shipped": 0}
+        tickets = []
 
-    def retire():
-        """Fetch the oldest frame; with N > 1 stage it for the (asynchronous) RCCL gather."""
-        tk = tickets.pop(0)
-        f = fr.fetch(tk, check=False)
-        if do_gather:
-            cur, j = state["cur"], state["fill"]
-            if j == 0 and pending[cur] is not None:    # the collective that last read this staging buffer
-                pending[cur].wait()                    # (NCCL: the current STREAM waits, not the host)
-                pending[cur] = None
-            if g_u8:                                   # quantise on the device, inside the timed region
-                frame_to_u8(f["colors"], f["alphas"], out=staging[cur][j].view(-1, 3))
-            else:                                      # RGB + depth | alpha, straight from the slot's buffers
-                staging[cur][j][..., :4].copy_(f["colors"], non_blocking=True)
-                staging[cur][j][..., 4:].copy_(f["alphas"], non_blocking=True)
-            state["fill"] = j + 1
-            if state["fill"] == GB:
+        def ship():
+            """One collective for the frames staged so far (stream-ordered after their conversion)."""
+            cur = state["cur"]
+            src = staging[cur]
+            if debug_gloo:
+                host_staging[cur].copy_(src)                           # synchronous host copy
+                src = host_staging[cur]
+            pending[cur] = dist.gather(src, gather_bufs[cur] if rank == 0 else None, dst=0, async_op=True)
+            state["cur"], state["fill"] = cur ^ 1, 0
+            state["shipped"] += 1
+
+        def retire():
+            """Fetch the oldest frame; with N > 1 stage it for the (asynchronous) RCCL gather."""
+            tk = tickets.pop(0)
+            f = fr.fetch(tk, check=False)
+            if do_gather:
+                cur, j = state["cur"], state["fill"]
+                if j == 0 and pending[cur] is not None:    # the collective that last read this staging buffer
+                    pending[cur].wait()                    # (NCCL: the current STREAM waits, not the host)
+                    pending[cur] = None
+                if g_u8:                                   # quantise on the device, inside the timed region
+                    frame_to_u8(f["colors"], f["alphas"], out=staging[cur][j].view(-1, 3))
+                else:                                      # RGB + depth | alpha, straight from the slot's buffers
+                    staging[cur][j][..., :4].copy_(f["colors"], non_blocking=True)
+                    staging[cur][j][..., 4:].copy_(f["alphas"], non_blocking=True)
+                state["fill"] = j + 1
+                if state["fill"] == GB:
+                    ship()
+            fr.release(tk)
+
+        def submit(cam_dev):
+            if len(tickets) == n_fl:
+                retire()
+            tickets.append(fr.submit(cam_dev))
+
+        def step():
+            for cd in cam_devs:
+                submit(cd)
+
+        def drain():
+            while tickets:
+                retire()
+            if do_gather and state["fill"] > 0:            # a partial last batch still travels (whole buffer)
                 ship()
-        fr.release(tk)
+            if do_gather and world > 1 and RING % world != 0:
+                # ragged shards (64 cameras over e.g. 3 ranks): ranks with fewer frames issue empty collectives
+                # so that every rank has made the same number of gather calls when the region ends
+                nmax = torch.tensor([state["shipped"]], device=comm_dev, dtype=torch.int64)
+                dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+                while state["shipped"] < int(nmax.item()):
+                    ship()
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
 
-    def submit(cam_dev):
-        if len(tickets) == n_fl:
-            retire()
-        tickets.append(fr.submit(cam_dev))
+        def region(k_steps):
+            barrier_sync(use_dist)
+            t0 = time.perf_counter()
+            for _ in range(k_steps):
+                step()
+            drain()
+            barrier_sync(use_dist)
+            dt = time.perf_counter() - t0
+            if use_dist:                                   # MAX over ranks; every rank sees the same number
+                tt = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt
 
-    def step():
-        for cd in cam_devs:
-            submit(cd)
-
-    def drain():
-        while tickets:
-            retire()
-        if do_gather and state["fill"] > 0:            # a partial last batch still travels (whole buffer)
-            ship()
-        if do_gather and world > 1 and RING % world != 0:
-            # ragged shards (64 cameras over e.g. 3 ranks): ranks with fewer frames issue empty collectives
-            # so that every rank has made the same number of gather calls when the region ends
-            nmax = torch.tensor([state["shipped"]], device=comm_dev, dtype=torch.int64)
-            dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
-            while state["shipped"] < int(nmax.item()):
-                ship()
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-
-    def region(k_steps):
-        barrier_sync(use_dist)
-        t0 = time.perf_counter()
-        for _ in range(k_steps):
+        for _ in range(a.warmup):
             step()
         drain()
-        barrier_sync(use_dist)
-        dt = time.perf_counter() - t0
-        if use_dist:                                   # MAX over ranks; every rank sees the same number
-            tt = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
+        regs = []
+        while True:                                        # identical trip count on every rank (dt is all-reduced)
+            regs.append(region(a.steps))
+            if sum(regs) >= a.min_seconds or len(regs) >= 400:
+                break
+        if do_gather and rank == 0:
+            # the collective really delivered every rank's frame (all cameras see the scene)
+            for r_ in range(world):
+                assert float(gather_bufs[0][r_][0].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
+        return regs, state["shipped"]
 
-    for _ in range(a.warmup):
-        step()
-    drain()
-    regions = []
-    while True:                                        # identical trip count on every rank (dt is all-reduced)
-        regions.append(region(a.steps))
-        if sum(regions) >= a.min_seconds or len(regions) >= 400:
-            break
+    g_u8 = a.gather_dtype == "u8"
+    regions, n_collectives = time_frames(g_u8)
     elapsed = float(np.median(regions))
+    # the other payload, timed the same way in the same run (N > 1 only): both are reported
+    other = None
+    if do_gather and not a.one_payload:
+        o_regions, _ = time_frames(not g_u8)
+        other = float(np.median(o_regions))
     # single-frame latency (one slot, nothing else in flight), for reference
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -275,10 +297,6 @@ def main():
         torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / 20 * 1e3
     outs = [(None, None, s["meta"]) for s in fr._slots]
-    if do_gather and rank == 0:
-        # the collective really delivered every rank's frame (all cameras see the scene)
-        for r_ in range(world):
-            assert float(gather_bufs[0][r_][0].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
     status = max(int(o[2]["isect_status"].max().item()) for o in outs)
     assert status == 0, "tile-intersection capacity overflow inside the timed region"
     total_frames = (RING if ring else 1) * a.steps     # all ranks together, per region
@@ -314,7 +332,11 @@ def main():
                    "gather": ((("8-bit RGB images (frame_to_u8 on the device, inside the timed region)" if g_u8
                                 else "fp32 RGB + expected depth + alpha (20 B per pixel)")
                                + f" to rank 0 (RCCL), {GB} frames per collective, "
-                                 f"{state['shipped']} collectives issued") if do_gather else "none"),
+                                 f"{n_collectives} collectives issued") if do_gather else "none"),
+                   "gather_other_payload": ({"payload": ("fp32 RGB + expected depth + alpha (20 B per pixel)" if g_u8 else
+                                                         "8-bit RGB images (frame_to_u8 on the device, inside the timed region)"),
+                                             "frames_per_s": round(total_frames / other, 2),
+                                             "ms_per_step": round(other / a.steps * 1e3, 4)} if other else None),
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
                              "frames in flight on separate HIP streams",
                    "frames_in_flight": n_fl, "single_frame_latency_ms": round(latency_ms, 4),
