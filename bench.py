@@ -15,8 +15,10 @@ RGB + depth + alpha, 20 bytes per pixel, is the payload `value` is measured with
 the ring again with the 8-bit RGB images a dataset writer stores and reports that rate beside it as
 config.gather_other_payload -- `--gather-dtype u8` swaps the two, `--one-payload` skips the second).
 The fp32 payload is 41.5 MB per frame: at 8 ranks rank 0 takes 7/8 of every frame over its seven xGMI
-links, which bounds the whole job near 350 GB/s / 41.5 MB = 8-9 k frames/s whatever the renderers do; the
-8-bit payload (6.2 MB per frame) is bounded at ~55 k frames/s and shows the renderers' own scaling.
+links, which bounds the whole job at (rank 0's inbound xGMI rate) / 41.5 MB -- 8-9 k frames/s if RCCL's
+point-to-point gather sustains ~50 GB/s per link (not measured: no multi-GPU box in this round) -- whatever
+the renderers do; the 8-bit payload (6.2 MB per frame) moves the same bound to ~55 k frames/s and shows the
+renderers' own scaling.
 Total work is fixed as N grows: scaling is "strong"; value = frames all ranks rendered / time.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
