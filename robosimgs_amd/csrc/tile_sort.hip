@@ -33,8 +33,9 @@ constexpr int kStack = 96;          // pending heavy buckets; beyond it a bucket
 #ifndef MGS_TSORT_FAST
 #define MGS_TSORT_FAST 2048
 #endif
-constexpr int kFast = MGS_TSORT_FAST;   // longest list of the LDS-resident fast path (8 KiB of LDS per 1024)
-constexpr int kItems = kFast / kTS;
+constexpr int kFastLong = MGS_TSORT_FAST;   // longest list of the LDS-resident fast path (8 KiB of LDS per 1024) ...
+constexpr int kFastShort = 1024;            // ... and where the capacity says lists are short on average: 17 instead of
+                                            // 25 KiB of LDS per workgroup = 8 instead of 6 workgroups per CU
 constexpr uint32_t kBrute = 0x80000000u;
 
 __device__ __forceinline__ bool comp_less(uint32_t ka, uint32_t ia, uint32_t kb, uint32_t ib) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_s
 // of `staging` (entry = id | tile's place in the group << (32 - shift), any order).  The tile's workgroup reads
 // its group's segment (the 2^shift workgroups of a group run side by side: L2 hits), keeps its own entries and
 // counts those of the group's earlier tiles -- which is where its list starts; it stores that offset too.
-template <bool GROUPED>
+template <bool GROUPED, int kFast>
 __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
     uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
   __shared__ int stack_lo[kStack], stack_hi[kStack];
   __shared__ uint8_t stack_src[kStack];
   __shared__ int stack_n;
+  constexpr int kItems = kFast / kTS;
   __shared__ uint32_t lk[kFast], li[kFast];
   const int tile = blockIdx.x;
   if (tile >= n_tiles) return;
@@ -421,14 +423,20 @@ int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depth
   if (n_tiles <= 0) return MGS_OK;
   const size_t stride = align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256) / sizeof(uint32_t);
   uint32_t* t = static_cast<uint32_t*>(temp);
-  if (staging)
-    hipLaunchKernelGGL(tile_depth_sort_kernel<true>, dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, group_offsets,
-                       depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,
-                       staging, group_shift, const_cast<int32_t*>(tile_offsets));
-  else
-    hipLaunchKernelGGL(tile_depth_sort_kernel<false>, dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, tile_offsets,
-                       depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,
-                       (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
+  // average list length the capacity allows: short lists -> the fast path with the smaller LDS list
+  const bool short_lists = (size_t)capacity <= (size_t)n_tiles * 640;
+#define MGS_TS_LAUNCH(G, F, OFFS, STG, SH, OUT)                                                              \
+  hipLaunchKernelGGL((tile_depth_sort_kernel<G, F>), dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, OFFS,   \
+                     depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,    \
+                     STG, SH, OUT)
+  if (staging) {
+    if (short_lists) MGS_TS_LAUNCH(true, kFastShort, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
+    else MGS_TS_LAUNCH(true, kFastLong, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
+  } else {
+    if (short_lists) MGS_TS_LAUNCH(false, kFastShort, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
+    else MGS_TS_LAUNCH(false, kFastLong, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
+  }
+#undef MGS_TS_LAUNCH
   return check_launch("tile_depth_sort");
 }
 
