@@ -529,3 +529,24 @@ def test_tile_group_order_is_a_schedule_not_a_result(ops, w, h):
                 assert torch.equal(f[2], frames[1][2])
     finally:
         lib.mgs_debug_set_sort_opts(0)
+
+
+@pytest.mark.parametrize("tw,th", [(1023, 58), (1023, 59), (1000, 131)])
+def test_binning_at_the_edge_of_the_lds_histogram(ops, tw, th):
+    """Tile grids around the largest the direct partition takes (15,000 groups of four tiles: a 60 KB LDS
+    histogram) and beyond it (radix partition): lists equal the stable-sort formulation bit for bit."""
+    rng = np.random.default_rng(tw + th)
+    n = 5000
+    w, h = tw * 16, th * 16
+    means2d = np.column_stack([rng.uniform(0, w, n), rng.uniform(0, h, n)]).astype(np.float32)
+    radii = rng.choice([0, 2, 9, 30, 200], size=n).astype(np.int32)
+    depths = rng.uniform(0.5, 30.0, n).astype(np.float32)
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, tw, th, dtype=np.float32)
+    total = len(r_flat)
+    tl = ops.isect_tiles_raw(_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), tw, th, total + 1, want_isect_ids=True)
+    assert int(tl.n_isect.item()) == total and int(tl.status.item()) == 0
+    np.testing.assert_array_equal(tl.flatten_ids[:total].cpu().numpy(), r_flat)
+    np.testing.assert_array_equal(tl.isect_ids[:total].cpu().numpy(), r_ids)
+    np.testing.assert_array_equal(tl.tile_offsets[:-1].cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th).reshape(-1))
+    order = tl.group_order.cpu().numpy()
+    assert sorted(order.tolist()) == list(range((tw * th + 3) // 4))
