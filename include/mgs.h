@@ -239,6 +239,7 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
  *   channel / max(alpha, 1e-10) and the kernel's prologue converts it (and v_alphas) back to the
  *   cotangents of the un-normalised blend: no pass over the frame in between.
  *   tile_group_order (nullable): from mgs_isect_tiles; when NULL the call computes the order itself.
+ *   v_alphas (nullable here): NULL = the loss does not depend on the alpha output (no zero frame needed).
  */
 int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, const float *feats,
                           const float *opacities, const float *splats, const float *background,

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     st[k].T = inside ? 1.0f - alphas[p] : 1.f;           // starts at the pixel's final transmittance
     st[k].bv = 0.f;
     st[k].last = inside ? last_ids[p] : -1;
-    float va = inside ? v_alphas[p] : 0.f;
+    float va = (inside && v_alphas) ? v_alphas[p] : 0.f;      // v_alphas == nullptr: no loss term on alpha
 #pragma unroll
     for (int c = 0; c < CHT; ++c)
       st[k].v_c[c] = (inside && c < channels) ? v_render[p * channels + c] : 0.f;
@@ -617,7 +617,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   if (n == 0) return MGS_OK;
   MGS_REQUIRE(!splats || channels <= 4, "rasterize_bwd_det: packed splats carry at most 4 channels");
   MGS_REQUIRE((splats || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
-                  alphas && last_ids && v_render && v_alphas && pair_info && v_means2d && v_conics &&
+                  alphas && last_ids && v_render && pair_info && v_means2d && v_conics &&
                   v_feats && v_opacities, "rasterize_bwd_det: null pointer");
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;

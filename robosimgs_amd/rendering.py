@@ -94,6 +94,8 @@ class _RenderSH(torch.autograd.Function):
         # backward undoes that with the saved frame (an OUTPUT: it must go through
         # save_for_backward -- parked on ctx it forms a reference cycle that crashes HIP graph capture)
         ctx.expected_depth = bool(expected_depth)
+        ctx.channels = ch
+        ctx.set_materialize_grads(False)       # an unused output's cotangent arrives as None, not as a zero frame
         ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks,
                               backgrounds, alphas, last_ids,
                               render if (expected_depth and training) else None)
@@ -110,8 +112,11 @@ class _RenderSH(torch.autograd.Function):
         (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
          absgrad) = ctx.cfg
         C, n = viewmats.shape[0], means.shape[0]
+        # set_materialize_grads(False): an output the loss does not use arrives as None instead of a zero frame
+        if v_render is None:
+            v_render = torch.zeros(C, height, width, ctx.channels, dtype=torch.float32, device=means.device)
         v_render = _f32c(v_render)
-        v_alphas = _f32c(v_alphas).reshape(C, height, width)
+        v_alphas = _f32c(v_alphas).reshape(C, height, width) if v_alphas is not None else None
         # "RGB+ED": the raster backward's prologue undoes the divide by max(alpha, 1e-10) itself
         # (expected_render=...); only a background gradient needs the converted cotangent here
         # the first camera overwrites the outputs, later ones accumulate: no zero-fill pass
@@ -129,7 +134,7 @@ class _RenderSH(torch.autograd.Function):
             bg = backgrounds[c] if backgrounds is not None else None
             v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_det_raw(
                 means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl, alphas[c],
-                last_ids[c], v_render[c], v_alphas[c], absgrad, splats=splats,
+                last_ids[c], v_render[c], v_alphas[c] if v_alphas is not None else None, absgrad, splats=splats,
                 expected_render=render_out[c] if ctx.expected_depth else None)
             # screen-space gradients for densification strategies (gsplat exposes them through
             # means2d.grad / means2d.absgrad; here they are published in the meta dict)

@@ -404,3 +404,29 @@ def test_deterministic_backward_with_overflowed_lists_stays_inside_its_workspace
                                         last, v_r, v_a, splats=splats, canary_bytes=1 << 20)
         torch.cuda.synchronize()
         assert bool((out[5] == 0xA5).all()), f"capacity {cap}: the backward wrote past its workspace"
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGB+ED"])
+def test_unused_outputs_need_no_zero_cotangent(mode):
+    """A loss on the colours alone (or on alpha alone) reaches the backward with None for the other output
+    (set_materialize_grads(False)): no zero frame is allocated, filled and read.  Gradients must equal bit for bit
+    those of the same loss with the unused output added at weight zero."""
+    from robosimgs_amd import rasterization
+    g, cam = _scene(3000, 0.15, 2, 96, 64)
+    t = g.to_torch(DEV, 2)
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    names = ("means", "quats", "scales", "opacities", "colors")
+    w_c = torch.rand(1, 64, 96, 4 if "D" in mode else 3, device=DEV)
+    w_a = torch.rand(1, 64, 96, 1, device=DEV)
+
+    def grads(loss_of):
+        p = {k: t[k].detach().clone().requires_grad_(True) for k in names}
+        c, a, _ = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, K, 96, 64,
+                                sh_degree=2, render_mode=mode)
+        loss_of(c, a).backward()
+        return [p[k].grad for k in names]
+
+    for only, both in ((lambda c, a: (c * w_c).sum(), lambda c, a: (c * w_c).sum() + (a * 0.0).sum()),
+                       (lambda c, a: (a * w_a).sum(), lambda c, a: (a * w_a).sum() + (c * 0.0).sum())):
+        for x, y in zip(grads(only), grads(both)):
+            assert torch.equal(x, y)
