@@ -223,18 +223,22 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
 }
 
 
-// ---- direct path (tile grids up to kDirectMaxTiles tiles) --------------------------------------------------
+// ---- direct path (up to kDirectMaxTiles bins) ---------------------------------------------------------------
 // The per-tile sort orders a list by the full (depth bits, index) composite, so the order in which a tile's
 // entries arrive does not matter and the radix partition by tile (emit + two histogram / scan / scatter passes
-// + tile offsets: nine launches, four trips over the pairs) can be replaced by a counting sort on the tile
-// itself whose counters live in LDS:
-//   direct_hist_kernel     each of <= 256 workgroups owns a run of consecutive Gaussians and counts their tiles in
-//                          an LDS histogram of the whole grid (LDS atomics), then stores its row of the table;
-//   direct_colscan_kernel  per tile, exclusive prefix down the table's column (64 tiles x 16 row groups per workgroup)
-//                          and the tile's total;
-//   direct_scatter_kernel  every workgroup scans the tile totals into the tile offsets (in LDS; workgroup 0 also
-//                          stores them), adds its own row = its cursors, walks its Gaussians again and drops each
-//                          pair at the cursor's next position (LDS atomic with return).
+// + tile offsets: nine launches, four trips over the pairs) can be replaced by a counting sort whose counters
+// live in LDS.  A bin is a group of 2^shift consecutive tiles (four by default, kGroupShift):
+//   direct_hist_kernel     each of <= kDirectMaxBlocks workgroups owns a run of consecutive Gaussians and counts
+//                          their tiles into an LDS histogram over all bins (LDS atomics), then stores its row of
+//                          the [workgroup][bin] table;
+//   direct_colscan_kernel  per bin, exclusive prefix down the table's column (16 bins x 16 row groups per
+//                          workgroup) and the bin's total;
+//   direct_scatter_kernel  every workgroup scans the bin totals into the bin offsets (in LDS; workgroup 0 also
+//                          stores them, with n_isect and the overflow status), adds its own row = its cursors,
+//                          walks its Gaussians again and drops each pair at the cursor's next position (LDS
+//                          atomic with return) as id | tile's place in the group << (32 - shift); one more
+//                          workgroup computes the raster kernels' launch order (tile_order.h) meanwhile.
+// tile_sort.hip then lets every tile pick its entries out of its group's segment.
 // Device-scope atomics were measured for the same job and are no option: ~25 G atomics/s on 8160 hot counters
 // (scripts/ubench/atomic_rate.hip), i.e. 108 us per pass at config 2.
 #ifndef MGS_DIRECT_THREADS
@@ -250,7 +254,7 @@ constexpr int kDirectThreads = MGS_DIRECT_THREADS;
 #define MGS_DIRECT_PER_THREAD 8
 #endif
 constexpr int kDirectPerThread = MGS_DIRECT_PER_THREAD;   // Gaussians per thread of those kernels
-constexpr int kDirectMaxBlocks = 1024;         // table rows (more Gaussians than 4 x threads x this: longer runs per workgroup)
+constexpr int kDirectMaxBlocks = 1024;         // table rows (beyond threads x per-thread x this many Gaussians: longer runs per workgroup)
 constexpr int kDirectMaxTiles = 15000;         // the LDS histogram: 4 bytes per bin in 64 KiB, less the static part
 constexpr int kGroupShift = 2;                 // 2^2 consecutive tiles share a segment (1 / 2 / 4 / 8 / 16 tiles: 124 / 113 / 112 / 124 / 150 us)
 constexpr uint32_t kCoopRect = 24;             // rectangles above this many tiles are walked by the whole wave
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
   __shared__ unsigned long long wsum[kDirectThreads / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // exclusive scan of the tile totals: `per` consecutive tiles per thread (64-bit: the total may pass 2^32)
-  const int per = (n_tiles + kDirectThreads - 1) / kDirectThreads;           // <= 16
+  const int per = (n_tiles + kDirectThreads - 1) / kDirectThreads;
   const int t0 = (int)threadIdx.x * per;
   unsigned long long sum = 0;
   for (int k = 0; k < per; ++k)
