@@ -12,7 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "projection.hip", "sort.hip", "binning.hip", "tile_sort.hip", "raster_fwd.hip",
            "raster_bwd.hip", "backward.hip", "composite.hip", "points.hip", "loss.hip", "transform.hip"]
-HEADERS = ["mgs_common.h", "mgs_math.h", "raster_common.h", "sh_staging.h", "../../include/mgs.h"]
+HEADERS = ["mgs_common.h", "mgs_math.h", "raster_common.h", "sh_staging.h", "tile_rect.h", "tile_order.h",
+           "../../include/mgs.h"]
 LIB = os.path.join(HERE, "libmgs.so")
 OBJ_DIR = os.path.join(HERE, "build")
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 adds/multiplies into v_pk_*_f32, which on
@@ -47,10 +48,42 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
+def _code_only(text: str) -> str:
+    """C / C++ source with comments removed and runs of whitespace collapsed (string and character
+    literals are kept as they are): two sources that differ in comments or layout only give the same text."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                   # literal: copy to the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def current_stamp() -> str:
-    """Hash of the sources, headers and flags libmgs.so is built from (bench.py keys measured PMC
-    traffic to it, so a number taken on another build is never printed)."""
-    return _stamp()
+    """Hash of the CODE libmgs.so is built from -- sources and headers without comments and layout, plus the
+    flags (bench.py keys measured PMC traffic to it, so a number taken on another build is never printed,
+    while an edit of a comment does not orphan the measurement)."""
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_SOURCE_FLAGS.items()))).encode())
+    for f in SOURCES + HEADERS:
+        p = os.path.join(HERE, f)
+        if os.path.exists(p):
+            with open(p, "r", encoding="utf-8", errors="replace") as fh:
+                h.update(_code_only(fh.read()).encode())
+    return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
