@@ -404,8 +404,10 @@ def main():
                                                   "frac": round(achieved_walked / HBM_PEAK_GBS, 4),
                                                   "note": "n_isect_binned * 44 + n_px * 20 + tiles * 8: the "
                                                           "tightened lists the kernel walks, no last_ids store"},
-                              "note": "VALU-bound kernel (DESIGN.md 4.3); the HBM fraction is reported as "
-                                      "the contract asks"}
+                              "valu": pmc_valu("raster_fwd_q_kernel<4, false>" if timed_latency else "raster_fwd_kernel<4, false>",
+                                               (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3)),
+                              "note": "VALU-bound kernel (DESIGN.md 4.3): `valu` says how close it runs to the issue rate "
+                                      "of its own instruction mix; the HBM fraction is reported as the contract asks"}
 
         # the second-largest forward kernel is HBM-bound: projection + SH colour (SURVEY.md 8(d):
         # N*236 + n_vis*48 algorithmic bytes), timed the same way
@@ -495,6 +497,37 @@ def pmc_traffic(kernel_key, standard_workload):
         return int(k["traffic_bytes"]), k.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
     except Exception as e:
         return None, f"no PMC record ({type(e).__name__})"
+
+
+# Issue cost of the blend's instruction mix, SIMD-cycles per wave64 vector instruction: 13 fma-class at 2.4, 7
+# compare / select-class at 4.1 and one v_exp at 8.15 = 65 cycles per 21 (scripts/ubench/valu_issue.hip)
+VALU_ISSUE_FLOOR = 65.0 / 21.0
+
+
+def pmc_valu(kernel_name, standard_workload):
+    """What bounds the raster for real: vector instructions per launch and SIMD-cycles per instruction from the
+    same PMC record (SQ_INSTS_VALU; GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 x 1024 SIMDs), against the issue
+    cost of the blend's instruction mix.  Printed under the same build-stamp rule as `traffic`."""
+    if not standard_workload:
+        return None
+    try:
+        with open(PMC_FILE) as f:
+            rec = json.load(f)
+        from robosimgs_amd.csrc import build as hip_build
+        if rec.get("stamp") != hip_build.current_stamp():
+            return None
+        row = next(v for k, v in rec["raw"].items() if kernel_name in k and k.startswith("raster_inf"))
+        insts, gui = float(row["SQ_INSTS_VALU"]), float(row["GRBM_GUI_ACTIVE"])
+        cyc = gui / 8.0 * 1024.0 / insts
+        return {"bound": "valu-issue", "instructions_per_launch": int(insts),
+                "simd_cycles_per_instruction": round(cyc, 2),
+                "issue_floor_cycles_per_instruction": round(VALU_ISSUE_FLOOR, 2),
+                "frac_of_issue_bound": round(VALU_ISSUE_FLOOR / cyc, 3),
+                "source": "rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE in the run that took `traffic` "
+                          "(profiles/pmc_traffic.json, profiles/r2/06_pmc_counters.md); floor: "
+                          "scripts/ubench/valu_issue.hip"}
+    except Exception:
+        return None
 
 
 def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
