@@ -27,11 +27,11 @@ print("n_isect", int(tl.n_isect))
 vr = torch.rand(H, W, CH, device=dev); va = torch.rand(H, W, device=dev)
 for _ in range(reps):
     if stage == "raster":
-        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out, splats=splats)
+        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out, splats=splats, group_order=tl.group_order)
     elif stage == "raster_inf":          # the inference variant (no last_ids): the kernel bench.py times
-        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=(out[0], out[1], None), track_last=False, splats=splats, expected_last=CH == 4)
+        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=(out[0], out[1], None), track_last=False, splats=splats, expected_last=CH == 4, group_order=tl.group_order)
     elif stage == "raster_inf_q":        # the same, one wave per 8x8 block (MGS_RASTER_LATENCY)
-        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=(out[0], out[1], None), track_last=False, splats=splats, expected_last=CH == 4, latency=True)
+        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=(out[0], out[1], None), track_last=False, splats=splats, expected_last=CH == 4, latency=True, group_order=tl.group_order)
     elif stage == "raster_bwd":
         ops.rasterize_bwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out[1], out[2], vr, va)
     elif stage == "raster_bwd_det":
