@@ -523,6 +523,8 @@ def pmc_valu(kernel_name, standard_workload):
                 "simd_cycles_per_instruction": round(cyc, 2),
                 "issue_floor_cycles_per_instruction": round(VALU_ISSUE_FLOOR, 2),
                 "frac_of_issue_bound": round(VALU_ISSUE_FLOOR / cyc, 3),
+                "note": "the floor is the blend loop's mix; fetch, cull and queue instructions are mostly of the cheaper "
+                        "class, so a kernel at the bound can read slightly above 1",
                 "source": "rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE in the run that took `traffic` "
                           "(profiles/pmc_traffic.json, profiles/r2/06_pmc_counters.md); floor: "
                           "scripts/ubench/valu_issue.hip"}
