@@ -8,7 +8,8 @@ synthetic scene at 1920x1080 in the mode the north star describes -- RGB + expec
 (`render_mode="RGB+ED"`): projection+SH, tile binning, tile raster, all through the C ABI of
 libmgs.so, replayed as one HIP graph with the scene resident in HBM.
 
-N > 1 (configs[3]; launched by torch.distributed.run, one process per GPU over RCCL): a step is one
+N > 1 (configs[3]; one process per GPU over RCCL -- started by torch.distributed.run as the driver does, or by
+bench.py itself when it is called as plain `python bench.py --gpus N` without WORLD_SIZE in the environment): a step is one
 pass over the 64-camera novel-view ring theta_k = 2 pi k / 64; rank r renders the contiguous block
 shard_cameras(64, N, r) through its FrameRenderer and rank 0 gathers all 64 finished frames (fp32
 RGB + depth + alpha, 20 bytes per pixel, is the payload `value` is measured with; the same run then times
@@ -89,6 +90,37 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n, debug_gloo):
+    """Re-run this command under torch.distributed.run with n ranks on this node; returns the exit code."""
+    import socket
+    import subprocess
+    if not debug_gloo:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node has {have} "
+                  "(one rank per GPU; --debug-single-device-gloo shares cuda:0 for control-flow debugging only)",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as sk:                          # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")               # (also keeps torchrun from printing its OMP notice)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in r.stdout.splitlines():                      # anything else the ranks printed goes to stderr
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if r.returncode == 0 and len(lines) == 1:
+        print(lines[0], flush=True)
+        return 0
+    print(f"bench.py: the {n}-rank run ended with exit code {r.returncode} and {len(lines)} result line(s)", file=sys.stderr)
+    return r.returncode or 1
+
+
 def barrier_sync(use_dist):
     torch.cuda.synchronize()
     if use_dist:
@@ -101,8 +133,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, what the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` does) and pass
+        # rank 0's JSON line through as the only line on stdout
+        raise SystemExit(self_launch(a.gpus, a.debug_single_device_gloo))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the number of ranks")
     debug_gloo = a.debug_single_device_gloo
     if debug_gloo:
         local_rank = 0
