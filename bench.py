@@ -451,7 +451,7 @@ def main():
         def proj():
             return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg,
                                              t["colors"], vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0, False,
-                                             True, want_splats=True, bin_seed="tight")
+                                             True, want_splats=True, bin_seed="tight", lean=True)
         for _ in range(5):
             proj()
         e0.record()
@@ -466,8 +466,9 @@ def main():
             "achieved": round(proj_bytes / (proj_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(proj_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": proj_bytes, "kernel_ms": round(proj_ms, 4),
-            "note": "also writes the 48-byte splat records and the binning seed (n_vis * 48 + N * 8 more "
-                    "bytes, not counted)"}
+            "note": "the inference-frame form the timed frames run: writes depths, the 48-byte splat records and the "
+                    "binning seed (n_vis * 48 + N * 8 more bytes, not counted); radii / means2d / conics / feats are "
+                    "NULL (nobody reads them in such a frame)"}
 
         # binning stage (rectangles .. depth-ordered lists + tile offsets) as one HIP-event interval; SURVEY.md 8(d):
         # n_vis*20 + n_isect*12 (count + emit) + n_isect*24 (sort, ideal 1R+1W) + n_isect*8 + tiles*4.
@@ -476,7 +477,8 @@ def main():
         seed = proj()[-1]
         def binning(seeded):
             return ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False,
-                                       conics=con, opacities=t["opacities"], seed=seed if seeded else None)
+                                       conics=con, opacities=t["opacities"], seed=seed if seeded else None,
+                                       want_tile_ids=not seeded)
         bin_times = {}
         for seeded in (True, False):
             for _ in range(5):

@@ -36,7 +36,10 @@
 extern "C" {
 #endif
 
-#define MGS_VERSION 100 /* 0.1.0 */
+/* Bumped whenever a parameter list changes: a caller built against another header must not load this
+ * library (robosimgs_amd/_lib.py asserts mgs_version() == the MGS_VERSION it was written for).
+ * 100 round 1; 200 round 2 (seed / splats / tile_group_order arguments); 300 round 3. */
+#define MGS_VERSION 300
 
 #define MGS_OK 0
 #define MGS_ERR_INVALID_ARGUMENT (-1)
@@ -130,6 +133,9 @@ int mgs_sh_bwd(int n, int degree, int coeff_stride, const float *dirs, const flo
  * rectangle (bin_tight != 0: tightened to the tiles it can reach with alpha >= 1/255, see
  * mgs_isect_tiles) and the count sum of every 64 consecutive Gaussians.  Handed to
  * mgs_isect_tiles as seed_info / seed_sums they save the binning a pass and a launch.
+ * radii / means2d / conics / feats may each be NULL when BOTH splats and bin_info are given (an
+ * inference frame: the raster gathers from splats, the seeded binning reads bin_info and depths;
+ * 36 of 84 MB of stores per 1 M Gaussians fall away).  depths is always written.
  * ----------------------------------------------------------------------------------- */
 int mgs_project_color_fwd(int n, const float *means, const float *quats, const float *scales,
                           const float *opacities, int sh_degree, int coeff_stride,
@@ -174,9 +180,11 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * permutation of the group indices).  Pass it to mgs_rasterize_fwd / mgs_rasterize_bwd_det; it
  * changes their schedule only, never a result.
  * seed_info / seed_sums (nullable, together): bin_info / bin_sums as written by
- * mgs_project_color_fwd for the same camera, tile grid and tight / classic choice; when given,
- * means2d / radii / conics / opacities are not read (and may be NULL) and seed_sums is
- * overwritten (scanned in place).
+ * mgs_project_color_fwd for the same camera, tile grid and tight / classic choice (the choice is the
+ * seed's: conics / opacities are ignored then); when given, tile_size must be MGS_TILE_SIZE,
+ * means2d / radii / conics / opacities are not read (and may be NULL) and seed_sums -- 16-byte aligned --
+ * is overwritten (scanned in place).
+ * tile_ids (nullable): an inference frame does not need it; NULL saves the store.
  * ----------------------------------------------------------------------------------- */
 int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const float *depths,
                     const float *conics, const float *opacities, int tile_size, int tile_w,

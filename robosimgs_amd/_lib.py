@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgs.so")
 
 MGS_STATUS_ISECT_OVERFLOW = 1
+MGS_VERSION = 300          # include/mgs.h this binding was written against (parameter lists change with it)
 
 
 class MgsError(RuntimeError):
@@ -29,6 +30,11 @@ def _load() -> ctypes.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no "
             "CPU or PyTorch fallback for the render path.")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.mgs_version.restype = c_int
+    have = lib.mgs_version()
+    if have != MGS_VERSION:      # shifted parameter lists would end in a GPU fault, not in an error
+        raise MgsError(f"{LIB_PATH} reports ABI version {have}, this binding was written for {MGS_VERSION} "
+                       "(include/mgs.h): rebuild the library (`python robosimgs_amd/csrc/build.py --force`)")
     p, i, f, u32 = c_void_p, c_int, c_float, c_uint32
     sig = {
         "mgs_version": ([], c_int),

@@ -511,7 +511,7 @@ unsigned direct_blocks(unsigned n) { return div_up(n, direct_chunk(n)); }
 
 struct Workspace {
   size_t total;
-  size_t ginfo, blocksums, tile_alt, id_alt, radix, tsort, table, tile_count, group_offsets;
+  size_t ginfo, blocksums, tile_alt, tile_priv, id_alt, radix, tsort, table, tile_count, group_offsets;
   Workspace(int n, uint32_t cap, int n_tiles) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
@@ -519,6 +519,7 @@ struct Workspace {
     ginfo = take(nn * 8);
     blocksums = take((size_t)div_up((unsigned)nn, kSum) * 4);
     tile_alt = take(cc * 4); id_alt = take(cc * 4);
+    tile_priv = take(cc * 4);          // stands in for the caller's tile_ids when that is null
     radix = take(radix_sort_temp_bytes((uint32_t)cc));
     tsort = take(tile_depth_sort_temp_bytes((uint32_t)cc));
     const size_t nt = (size_t)(n_tiles < kDirectMaxTiles ? n_tiles : kDirectMaxTiles);   // bins: tiles or tile groups
@@ -568,11 +569,19 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
               "isect_tiles: tight tile bounds need both conics and opacities");
   MGS_REQUIRE(n == 0 || (seed_info == nullptr) == (seed_sums == nullptr),
               "isect_tiles: seed_info and seed_sums come together (mgs_project_color_fwd writes both)");
-  MGS_REQUIRE((n == 0 || ((seed_info || (means2d && radii)) && depths)) && n_isect && tile_ids && flatten_ids &&
+  MGS_REQUIRE((n == 0 || ((seed_info || (means2d && radii)) && depths)) && n_isect && flatten_ids &&
                   tile_offsets && status, "isect_tiles: null pointer");
+  // the seed is what mgs_project_color_fwd computed: rectangles at MGS_TILE_SIZE; its per-64 sums are scanned
+  // in place with 16-byte accesses
+  MGS_REQUIRE(!seed_info || tile_size == MGS_TILE_SIZE, "isect_tiles: a seed is for tile_size %d, got %d", MGS_TILE_SIZE, tile_size);
+  MGS_REQUIRE(!seed_sums || (reinterpret_cast<uintptr_t>(seed_sums) & 15u) == 0, "isect_tiles: seed_sums must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   char* w = static_cast<char*>(workspace);
   auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(w + off); };
+  // tile_ids is optional: an inference frame never reads it.  The direct path then skips the store (15 MB at
+  // 3.7 M pairs); the radix path and the isect_ids output keep a private copy in the workspace.
+  const bool want_tile_ids = tile_ids != nullptr;
+  if (!tile_ids) tile_ids = u32(ws.tile_priv);
   const int n_tiles = tile_w * tile_h;
   const uint32_t cap = isect_capacity;
   // tiles per segment of the direct path: 2^gshift (sort_opts bits 4..6 override; 0 = one tile per segment)
@@ -644,7 +653,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   if (n > 0) {        // depth order inside every tile's list (the direct path's lists get their tile ids here)
     const bool grouped = direct && gshift > 0;
     rc = tile_depth_sort(n_tiles, tile_offsets, depths, cap, reinterpret_cast<uint32_t*>(flatten_ids),
-                         direct ? tile_ids : nullptr, w + ws.tsort, s, grouped ? u32(ws.id_alt) : nullptr,
+                         direct && (want_tile_ids || isect_ids) ? tile_ids : nullptr, w + ws.tsort, s, grouped ? u32(ws.id_alt) : nullptr,
                          grouped ? reinterpret_cast<const int32_t*>(w + ws.group_offsets) : nullptr, gshift);
     if (rc) return rc;
   }

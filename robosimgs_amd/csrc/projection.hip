@@ -156,12 +156,16 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     float4 qq = reinterpret_cast<const float4*>(quats)[g];
     q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
     p = project_gaussian(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
-    radii[g] = p.radius;
-    reinterpret_cast<float2*>(means2d)[g] = make_float2(p.mean2d[0], p.mean2d[1]);
+    // radii / means2d / conics (and feats below) are null in an inference frame: the raster reads the packed
+    // records, the seeded binning reads bin_info + depths -- 36 MB of stores per 1 M Gaussians nobody would read
+    if (radii) radii[g] = p.radius;
+    if (means2d) reinterpret_cast<float2*>(means2d)[g] = make_float2(p.mean2d[0], p.mean2d[1]);
     depths[g] = p.depth;
-    conics[3 * (size_t)g + 0] = p.conic[0];
-    conics[3 * (size_t)g + 1] = p.conic[1];
-    conics[3 * (size_t)g + 2] = p.conic[2];
+    if (conics) {
+      conics[3 * (size_t)g + 0] = p.conic[0];
+      conics[3 * (size_t)g + 1] = p.conic[1];
+      conics[3 * (size_t)g + 2] = p.conic[2];
+    }
     if (opac_out) opac_out[g] = opacities[g] * p.compensation;
   }
   bool active = p.radius > 0;
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     splats[3 * (size_t)g + 1] = make_float4(p.conic[2], op, rgb[0], rgb[1]);
     splats[3 * (size_t)g + 2] = make_float4(rgb[2], feat_stride == 4 ? p.depth : 0.f, 0.f, 0.f);
   }
+  if (!feats) return;
   if (feat_stride == 4) {
     reinterpret_cast<float4*>(feats)[g] = make_float4(rgb[0], rgb[1], rgb[2], p.depth);
   } else {
@@ -276,8 +281,11 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
   MGS_REQUIRE(coeff_stride >= (sh_degree + 1) * (sh_degree + 1), "project_color_fwd: coeff_stride too small");
   MGS_REQUIRE(feat_stride == 3 || feat_stride == 4, "project_color_fwd: feat_stride must be 3 or 4");
   if (n == 0) return MGS_OK;
-  MGS_REQUIRE(means && quats && scales && sh_coeffs && viewmat && K && radii && means2d &&
-                  depths && conics && feats, "project_color_fwd: null pointer");
+  MGS_REQUIRE(means && quats && scales && sh_coeffs && viewmat && K && depths, "project_color_fwd: null pointer");
+  // the per-Gaussian arrays may be dropped only when their consumers have a substitute: the raster reads
+  // `splats`, the binning is seeded with `bin_info`
+  MGS_REQUIRE((radii && means2d && conics && feats) || (splats && bin_info),
+              "project_color_fwd: radii / means2d / conics / feats may be NULL only when splats and bin_info are given");
   MGS_REQUIRE(!opac_out || opacities, "project_color_fwd: opac_out needs opacities");
   MGS_REQUIRE(!splats || opacities, "project_color_fwd: splats needs opacities");
   MGS_REQUIRE((bin_info == nullptr) == (bin_sums == nullptr), "project_color_fwd: bin_info and bin_sums come together");

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     // its five waves advances at a fifth of the SIMD's rate, so the longest lists -- started no earlier
     // than the others -- set the kernel's duration.  Waves with long lists get priority and finish at
     // their own issue limit; short ones fill the gaps.
-    const int avg = tile_offsets[n_tiles] / n_tiles, len = end - start;
+    const int avg = (tile_offsets[n_tiles] - tile_offsets[0]) / n_tiles, len = end - start;   // this camera's own total
     if (len > 2 * avg) __builtin_amdgcn_s_setprio(3);
     else if (2 * len > 3 * avg) __builtin_amdgcn_s_setprio(2);
     else if (len > avg) __builtin_amdgcn_s_setprio(1);

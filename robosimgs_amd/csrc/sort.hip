@@ -355,8 +355,12 @@ __global__ __launch_bounds__(kThreads) void onesweep_scatter_kernel(
           w = __hip_atomic_load(status + (size_t)(i - u) * kRadix + threadIdx.x, __ATOMIC_RELAXED,
                                 __HIP_MEMORY_SCOPE_AGENT);
         }
+        // a predecessor that never published (2^22 polls: the block was not scheduled, which cannot happen
+        // for tickets taken in dispatch order) must not turn into a silently wrong prefix: abort the launch,
+        // the next synchronisation reports it
+        if ((w >> 30) == 0u) __builtin_trap();
         excl += w & kCountMask;
-        if ((w >> 30) != 1u) done = true;          // INCLUSIVE (or the front of the array, or a timed-out poll)
+        if ((w >> 30) != 1u) done = true;          // INCLUSIVE (or the front of the array)
       }
       i -= 8;
       if (i < 0) done = true;

@@ -54,19 +54,25 @@ def projection_fwd_raw(means, quats, scales, viewmat, K, width, height, eps2d, n
 
 def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmat, K,
                           width, height, eps2d, near_plane, far_plane, radius_clip,
-                          antialiased, with_depth, want_splats=False, bin_seed=None):
+                          antialiased, with_depth, want_splats=False, bin_seed=None, lean=False):
     """Returns (radii, means2d, depths, conics, opac_aa|None, feats) and, with want_splats, a 7th
     item: the packed [N,12] records the raster kernels gather from.  bin_seed = "tight" | "classic":
-    an 8th item (seed_info [N,2] i32, seed_sums [ceil(N/64)] i32) for isect_tiles_raw(seed=...)."""
+    an 8th item (seed_info [N,2] i32, seed_sums [ceil(N/64)] i32) for isect_tiles_raw(seed=...).
+    lean (needs want_splats and bin_seed): radii / means2d / conics / feats are not written and come back
+    as None -- an inference frame, whose raster reads the records and whose binning reads the seed."""
     n = means.shape[0]
     dev = means.device
-    radii = torch.empty(n, dtype=torch.int32, device=dev)
-    means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
-    depths = torch.empty(n, dtype=torch.float32, device=dev)
-    conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
-    opac = torch.empty(n, dtype=torch.float32, device=dev) if antialiased else None
+    if lean and not (want_splats and bin_seed is not None):
+        raise ValueError("lean=True needs want_splats=True and a bin_seed")
     stride = 4 if with_depth else 3
-    feats = torch.empty(n, stride, dtype=torch.float32, device=dev)
+    radii = means2d = conics = feats = None
+    if not lean:
+        radii = torch.empty(n, dtype=torch.int32, device=dev)
+        means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        feats = torch.empty(n, stride, dtype=torch.float32, device=dev)
+    depths = torch.empty(n, dtype=torch.float32, device=dev)
+    opac = torch.empty(n, dtype=torch.float32, device=dev) if antialiased else None
     splats = torch.empty(n, 12, dtype=torch.float32, device=dev) if want_splats else None
     seed = None
     if bin_seed is not None and n > 0:
@@ -109,19 +115,20 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_id=0, n_cams=1,
                     want_isect_ids=False, want_tiles_per_gauss=True,
-                    want_pair_info=False, conics=None, opacities=None, seed=None) -> TileLists:
+                    want_pair_info=False, conics=None, opacities=None, seed=None,
+                    want_tile_ids=True) -> TileLists:
     """conics + opacities given: tile rectangles tightened to the tiles a Gaussian can reach with
     alpha >= 1/255 (shorter lists, bit-identical render); None: gsplat's classic rectangles.
     seed = (seed_info, seed_sums) from project_color_fwd_raw(bin_seed=...): the rectangles come from
-    there (means2d / radii / conics / opacities are then not read; seed_sums is consumed)."""
-    n = means2d.shape[0]
-    dev = means2d.device
+    there (means2d / radii / conics / opacities are then not read and may be None; seed_sums is consumed)."""
+    n = depths.shape[0]
+    dev = depths.device
     L = _lib.lib()
     out = TileLists()
     out.capacity = int(capacity)
     out.n_isect = torch.empty(1, dtype=torch.int32, device=dev)
     out.status = torch.empty(1, dtype=torch.int32, device=dev)       # written by every call
-    out.tile_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
+    out.tile_ids = torch.empty(capacity, dtype=torch.int32, device=dev) if want_tile_ids else None
     out.flatten_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
     out.tile_offsets = torch.empty(tile_w * tile_h + 1, dtype=torch.int32, device=dev)
     out.tiles_per_gauss = (torch.empty(n, dtype=torch.int32, device=dev)
@@ -147,16 +154,18 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                       tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None,
-                      expected_last=False, latency=False, group_order=None):
-    """out = (render, alphas, last_ids|None) to write into existing buffers.  track_last=False (or
+                      expected_last=False, latency=False, group_order=None, channels=None):
+    """out = (render, alphas, last_ids|None) to write into existing buffers.  With `splats` (<= 4 channels)
+    means2d / conics / feats / opacities are not read and may be None; give `channels` then.  track_last=False (or
     last_ids None) is the inference variant: no last_ids, one select less per pair.
     expected_last: the last channel leaves divided by max(alpha, 1e-10) ("ED" modes).
     latency: MGS_RASTER_LATENCY -- one wave per 8x8 block; faster when the launch has the GPU to itself
     (a single frame, a training step), slower in total work when several frames are in flight.
     group_order: TileLists.group_order -- the tiles are then started longest lists first."""
-    n = means2d.shape[0]
-    ch = feats.shape[-1]
-    dev = means2d.device
+    src = means2d if means2d is not None else splats
+    n = src.shape[0]
+    ch = int(channels) if channels is not None else feats.shape[-1]
+    dev = src.device
     if out is None:
         render = torch.empty(height, width, ch, dtype=torch.float32, device=dev)
         alphas = torch.empty(height, width, dtype=torch.float32, device=dev)

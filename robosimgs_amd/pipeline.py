@@ -1,7 +1,7 @@
 """FrameRenderer: steady-state novel-view rendering of a static scene at HIP-graph speed.
 
 A data-generation loop renders thousands of frames of ONE scene from changing cameras.  The
-frame is a fixed sequence of ~25 kernels whose sizes do not depend on the camera once the
+frame is a fixed sequence of six kernels whose sizes do not depend on the camera once the
 tile-list capacity is fixed, so it is captured once per in-flight slot as a HIP graph whose
 camera (viewmat, K) lives in device buffers that are overwritten before each replay.  Several
 slots, each on its own stream, keep independent frames in flight: the latency-bound binning
@@ -55,6 +55,8 @@ class FrameRenderer:
         self.kw = dict(raster_kw)
         # several frames in flight: total work matters, not one launch's duration (rendering.py)
         self.kw.setdefault("raster_schedule", "throughput" if int(frames_in_flight) > 1 else "latency")
+        # the slots' frames keep no per-Gaussian arrays nobody reads (rendering.py: lean_meta)
+        self.kw.setdefault("lean_meta", True)
         self.bg = background
         if isect_capacity is None:
             if sizing_camera is None:

@@ -33,9 +33,11 @@ class _Meta(dict):
         if key not in ("flatten_ids", "isect_ids") or "tile_lists" not in self:
             raise KeyError(key)
         lists = self["tile_lists"]
+        if lists and lists[0].tile_ids is None:
+            raise KeyError(f"{key}: this frame was rendered with lean_meta=True and keeps no tile ids")
         n_tiles = self["tile_width"] * self["tile_height"]
         tile_bits = int(n_tiles).bit_length()             # floor(log2(n_tiles)) + 1
-        N = self["radii"].shape[1]
+        N = self["depths"].shape[1]
         counts = [int(c) for c in self["n_isects"].tolist()]
         flat, keys = [], []
         for c, (tl, n) in enumerate(zip(lists, counts)):
@@ -55,7 +57,7 @@ class _RenderSH(torch.autograd.Function):
     def forward(ctx, means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds,
                 width, height, sh_degree, eps2d, near_plane, far_plane, radius_clip,
                 antialiased, with_depth, isect_capacity, absgrad, meta_out, tight, expected_depth,
-                latency):
+                latency, lean):
         C = viewmats.shape[0]
         dev = means.device
         tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
@@ -66,20 +68,24 @@ class _RenderSH(torch.autograd.Function):
         training = any(ctx.needs_input_grad[:6]) or ctx.needs_input_grad[7]
         last_ids = (torch.empty(C, height, width, dtype=torch.int32, device=dev) if training
                     else None)
+        # lean: an inference frame with a fixed list capacity keeps only what its own kernels read -- the packed
+        # records, the binning seed and the depths; radii / means2d / conics / feats / tiles_per_gauss are neither
+        # written nor returned (36 + 4 MB of stores per 1 M Gaussians)
+        lean = bool(lean) and not training and isect_capacity is not None
         per_cam = []
         for c in range(C):
             # the projection kernel also seeds the binning (tile rectangle + count per Gaussian)
             radii, means2d, depths, conics, opac_aa, feats, splats, seed = ops.project_color_fwd_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats[c], Ks[c], width,
                 height, eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth,
-                want_splats=True, bin_seed="tight" if tight else "classic")
+                want_splats=True, bin_seed="tight" if tight else "classic", lean=lean)
             opac = opac_aa if antialiased else opacities
             cap = isect_capacity
             if cap is None:
                 cap = max(1, ops._upper_bound_isects(radii, tile_w, tile_h))
             tl = ops.isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, cap, c, C,
-                                     want_isect_ids=False, want_tiles_per_gauss=True,
-                                     want_pair_info=training,
+                                     want_isect_ids=False, want_tiles_per_gauss=not lean,
+                                     want_pair_info=training, want_tile_ids=not lean,
                                      conics=conics if tight else None,
                                      opacities=opac if tight else None, seed=seed)
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
@@ -87,7 +93,7 @@ class _RenderSH(torch.autograd.Function):
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
                                   out=(render[c], alphas[c], last_ids[c] if training else None),
                                   splats=splats, expected_last=expected_depth, latency=latency,
-                                  group_order=tl.group_order)
+                                  group_order=tl.group_order, channels=ch)
             per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl, splats))
         ctx.per_cam = per_cam
         # "RGB+ED": the kernel's epilogue divided the depth channel by max(alpha, 1e-10); the
@@ -168,7 +174,7 @@ class _RenderSH(torch.autograd.Function):
                 v_render = torch.cat([v_render[..., :-1],
                                       (v_render[..., -1] / alphas.clamp(min=1e-10)).unsqueeze(-1)], dim=-1)
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 15
+        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 16
 
 
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
@@ -180,8 +186,13 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                   rasterize_mode: str = "classic", channel_chunk: int = 32,
                   isect_capacity: Optional[int] = None,
                   tile_bounds: str = "tight",
-                  raster_schedule: str = "latency") -> Tuple[Tensor, Tensor, Dict]:
+                  raster_schedule: str = "latency",
+                  lean_meta: bool = False) -> Tuple[Tensor, Tensor, Dict]:
     """Render N Gaussians from C cameras.
+
+    lean_meta (SH path, isect_capacity given, no gradients): the frame keeps only what its own kernels read;
+    meta then lacks radii / means2d / conics / tiles_per_gauss (depths, n_isects, isect_status and tile_lists
+    stay) and the projection kernel skips 40 MB of stores per 1 M Gaussians.  FrameRenderer's default.
 
     raster_schedule (SH path): "latency" runs the tile raster with one wave per 8x8 block (the launch
     has the GPU to itself: a single frame, a training step; -19 % kernel time), "throughput" with
@@ -250,7 +261,8 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height,
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store,
-            tile_bounds == "tight", render_mode in ("RGB+ED", "ED"), raster_schedule == "latency")
+            tile_bounds == "tight", render_mode in ("RGB+ED", "ED"), raster_schedule == "latency",
+            bool(lean_meta))
         if depth_only_via_sh:
             render = render[..., 3:4]
         per_cam = store.pop("per_cam")
@@ -260,19 +272,21 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
 
         def _cat(xs):
             return xs[0] if len(xs) == 1 else torch.cat(xs)
+        if per_cam[0][0] is not None:        # (a lean frame has none of these)
+            meta.update(
+                radii=_stk([p[0] for p in per_cam]),
+                means2d=_stk([p[1] for p in per_cam]),
+                conics=_stk([p[3] for p in per_cam]),
+                tiles_per_gauss=_stk([p[6].tiles_per_gauss for p in per_cam]))
         meta.update(
-            radii=_stk([p[0] for p in per_cam]),
-            means2d=_stk([p[1] for p in per_cam]),
             depths=_stk([p[2] for p in per_cam]),
-            conics=_stk([p[3] for p in per_cam]),
             opacities=(_stk([p[4] for p in per_cam]) if antialiased
                        else opacities.unsqueeze(0).expand(C, N)),
-            tiles_per_gauss=_stk([p[6].tiles_per_gauss for p in per_cam]),
             n_isects=_cat([p[6].n_isect for p in per_cam]),
             isect_status=_cat([p[6].status for p in per_cam]),
             isect_offsets=_stk([p[6].tile_offsets[:-1].view(tile_h, tile_w) for p in per_cam]),
             tile_lists=[p[6] for p in per_cam])
-        if torch.is_grad_enabled() and render.requires_grad:
+        if torch.is_grad_enabled() and render.requires_grad and "means2d" in meta:
             meta["means2d"] = meta["means2d"].detach().requires_grad_(True)   # see _RenderSH.backward
     else:
         # feature path: colours are given per Gaussian (or evaluated from SH for "D"/"ED")

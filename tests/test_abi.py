@@ -29,7 +29,9 @@ def test_header_symbols_are_exported_and_bound():
     for name, nargs in decl.items():
         fn = getattr(L, name)
         assert len(fn.argtypes) == nargs, f"{name}: header has {nargs} parameters, ctypes table {len(fn.argtypes)}"
-    assert L.mgs_version() == 100
+    header = open(HEADER).read()
+    declared = int(re.search(r"#define\s+MGS_VERSION\s+(\d+)", header).group(1))
+    assert L.mgs_version() == declared == _lib.MGS_VERSION      # header, library and binding agree
     assert isinstance(L.mgs_last_error_string(), bytes)
 
 

@@ -45,7 +45,7 @@ def ops():
 def test_single_hip_runtime_loaded(ops):
     """libmgs.so must bind to the HIP runtime torch loaded (one libamdhip64 in the process)."""
     from robosimgs_amd import _lib
-    assert _lib.lib().mgs_version() == 100
+    assert _lib.lib().mgs_version() == _lib.MGS_VERSION
     torch.zeros(1, device=DEV)
     with open("/proc/self/maps") as f:
         libs = {line.split()[-1] for line in f if "libamdhip64" in line}

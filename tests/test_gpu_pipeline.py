@@ -102,3 +102,46 @@ def test_depth_only_modes_with_a_fixed_capacity_and_in_a_frame_renderer(mode):
     fr = FrameRenderer(t, 160, 96, render_mode=mode, frames_in_flight=2, isect_capacity=200_000)
     out = fr.render(cam.viewmat(), cam.K)
     assert torch.equal(out["colors"], d[0])
+
+
+def test_lean_frames_drop_the_unread_arrays_and_keep_every_bit():
+    """FrameRenderer's slots (lean_meta=True) pass NULL for radii / means2d / conics / feats / tiles_per_gauss /
+    tile_ids at the C ABI: the image must be the one the full call gives, bit for bit, in every mode."""
+    from robosimgs_amd import rasterization
+    g = synthetic_scene(60_000, math.log(0.04), 3, 4)
+    cam = camera_ring(3, 400, 304)[1]
+    t = g.to_torch(DEV, 3)
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    for mode in ("RGB", "RGB+ED", "RGB+D", "ED"):
+        for aa in ("classic", "antialiased"):
+            kw = dict(sh_degree=3, render_mode=mode, rasterize_mode=aa, isect_capacity=2_000_000)
+            with torch.no_grad():
+                c0, a0, m0 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K,
+                                           400, 304, **kw)
+                c1, a1, m1 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K,
+                                           400, 304, lean_meta=True, **kw)
+            assert torch.equal(c0, c1) and torch.equal(a0, a1), (mode, aa)
+            assert "radii" in m0 and "radii" not in m1 and "means2d" not in m1 and "tiles_per_gauss" not in m1
+            assert int(m1["n_isects"][0]) == int(m0["n_isects"][0]) > 0 and int(m1["isect_status"][0]) == 0
+            assert torch.equal(m0["depths"], m1["depths"])
+            assert m1["tile_lists"][0].tile_ids is None
+            with pytest.raises(KeyError):
+                m1["isect_ids"]
+    # gradients asked for: lean is ignored, the full set of arrays is back
+    p = {k: t[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+    c2, a2, m2 = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, K, 400, 304,
+                               sh_degree=3, render_mode="RGB+ED", isect_capacity=2_000_000, lean_meta=True)
+    assert "radii" in m2
+    c2.sum().backward()
+    assert p["means"].grad is not None
+
+
+def test_projection_refuses_null_outputs_without_their_substitutes():
+    from robosimgs_amd import _lib
+    L = _lib.lib()
+    z = torch.zeros(64, device=DEV)
+    # radii NULL but no splats / bin_info: an argument error, not a fault
+    rc = L.mgs_project_color_fwd(4, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, 1, z.data_ptr(),
+                                 z.data_ptr(), z.data_ptr(), 16, 16, 0.3, 0.01, 1e10, 0.0, None, None, z.data_ptr(),
+                                 None, None, 3, None, None, 0, None, None, None)
+    assert rc == -1 and b"may be NULL only" in L.mgs_last_error_string()
