@@ -565,7 +565,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     return set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "isect_tiles: workspace %zu < %zu bytes",
                      *workspace_bytes, ws.total);
   MGS_REQUIRE(isect_capacity > 0, "isect_tiles: zero capacity");
-  MGS_REQUIRE((conics == nullptr) == (opacities == nullptr),
+  MGS_REQUIRE(seed_info || (conics == nullptr) == (opacities == nullptr),
               "isect_tiles: tight tile bounds need both conics and opacities");
   MGS_REQUIRE(n == 0 || (seed_info == nullptr) == (seed_sums == nullptr),
               "isect_tiles: seed_info and seed_sums come together (mgs_project_color_fwd writes both)");
