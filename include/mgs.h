@@ -305,6 +305,20 @@ int mgs_composite_over(int n_px, const float *bg_rgb, const float *bg_alpha,
 int mgs_frame_to_u8(int n_px, const float *rgb, int rgb_stride, const float *alpha,
                     const float *background, uint8_t *out, mgs_stream_t stream);
 
+/* Dataset frame in the layout the reference's readers open (the OUTPUT side of the path):
+ *   rgba[H,W,4] u8 (nullable): RGB as mgs_frame_to_u8, A = alpha > 0 ? max(1, round(255 alpha)) : 0 -- the
+ *     RGBA image load_images (/root/reference/Articulation/utils/nerf2physic_utils.py:84-101) opens; its
+ *     mask `A > 0` is exactly `alpha > 0`;
+ *   distance[H,W] f32, or f64 when distance_f64 != 0 (nullable): the RAY DISTANCE z * ||K^-1 (x, y, 1)||
+ *     through INTEGER pixel coordinates, z = the last channel of colors (the "ED" depth of an RGB+ED frame;
+ *     color_stride >= 4) -- what load_depths (:104-118) opens and distance_to_depth (:135-146) turns back
+ *     into z.  Computed in fp64 and rounded once; with the f64 output the reader recovers z to the last
+ *     fp32 bit, with f32 (what `ns-render` stores) to one ulp.
+ *   Kinv_host: HOST pointer to the 9 doubles of K^-1 (row-major), read during the call. */
+int mgs_frame_to_dataset(int width, int height, const float *colors, int color_stride,
+                         const float *alpha, const float *background, const double *Kinv_host,
+                         uint8_t *rgba, void *distance, int distance_f64, mgs_stream_t stream);
+
 /* -------------------------------------------------------------------------------------
  * Point-cloud z-buffer helpers: the reference's
  * Articulation/utils/point_utils.py, one entry point per function.

@@ -29,6 +29,9 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
     if name in ("composite_over", "frame_to_u8"):
         from . import compositing
         return getattr(compositing, name)
+    if name in ("frame_to_dataset", "DatasetWriter", "read_dataset_frame", "unnormalize_points"):
+        from . import dataset
+        return getattr(dataset, name)
     if name == "transform_gaussians":
         from . import transform
         return transform.transform_gaussians

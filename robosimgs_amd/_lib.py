@@ -57,6 +57,7 @@ def _load() -> ctypes.CDLL:
         "mgs_points_depth_map": ([i, p, i, p, i, i, i, i, f, f, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_points_sample_mask": ([i, p, i, p, i, i, f, p, p, f, p, p], c_int),
         "mgs_frame_to_u8": ([i, p, i, p, p, p, p], c_int),
+        "mgs_frame_to_dataset": ([i, i, p, i, p, p, p, p, p, i, p], c_int),
         "mgs_transform_gaussians": ([i, p, p, p, i, i, p, p, i, p, p, p, p, p, p, p], c_int),
         "mgs_l1_loss_fwd": ([c_size_t, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_l1_loss_bwd": ([c_size_t, p, p, p, p, p], c_int),
@@ -88,7 +89,7 @@ EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_debug_set_raster_cull", 
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
            "mgs_rasterize_bwd_det", "mgs_composite_over", "mgs_points_project",
            "mgs_points_depth_map", "mgs_points_sample_mask", "mgs_l1_loss_fwd", "mgs_l1_loss_bwd",
-           "mgs_transform_gaussians", "mgs_frame_to_u8"]
+           "mgs_transform_gaussians", "mgs_frame_to_u8", "mgs_frame_to_dataset"]
 
 
 def check(rc: int, what: str) -> None:

@@ -121,3 +121,65 @@ extern "C" int mgs_frame_to_u8(int n_px, const float* rgb, int rgb_stride, const
                      rgb_stride, alpha, background, out, quads ? 1 : 0);
   return check_launch("frame_to_u8");
 }
+
+
+// ---- dataset frames in the layout the reference's readers expect ------------------------------------
+// /root/reference/Articulation/utils/nerf2physic_utils.py: load_images (:84-101) opens RGBA images and takes
+// alpha > 0 as the object mask; load_depths (:104-118) opens [H,W,1] .npy.gz RAY DISTANCES and converts them
+// with distance_to_depth (:135-146), whose rays go through INTEGER pixel coordinates (np.arange, no + 0.5):
+//     distance = z * || K^-1 (x, y, 1) ||.
+// One pass over the frame: 20 B read, 4 + 4 (or 8) B written per pixel.
+namespace mgs {
+namespace {
+struct KInv { double m[9]; };
+
+template <typename DistT>
+__global__ __launch_bounds__(256) void frame_to_dataset_kernel(int width, int height, const float* __restrict__ colors,
+                                                               int stride, const float* __restrict__ alpha,
+                                                               const float* __restrict__ background, KInv ki,
+                                                               uint32_t* __restrict__ rgba, DistT* __restrict__ dist) {
+#pragma clang fp contract(off)      // the test-side NumPy restatement has no fused multiply-add (see oracle/dataset_np.py)
+  const float b0 = background ? background[0] : 0.f, b1 = background ? background[1] : 0.f,
+              b2 = background ? background[2] : 0.f;
+  const int n_px = width * height;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < n_px; p += gridDim.x * 256) {
+    const float* c = colors + (size_t)p * stride;
+    const float a = alpha[p], w = 1.f - a;
+    if (rgba) {
+      // alpha > 0 must survive the quantisation: the reader's mask is A > 0
+      const uint32_t A = a > 0.f ? max(1u, quant8(a)) : 0u;
+      rgba[p] = quant8(c[0] + w * b0) | quant8(c[1] + w * b1) << 8 | quant8(c[2] + w * b2) << 16 | A << 24;
+    }
+    if (dist) {
+      const double x = (double)(p % width), y = (double)(p / width);
+      const double rx = (x * ki.m[0] + y * ki.m[1]) + ki.m[2], ry = (x * ki.m[3] + y * ki.m[4]) + ki.m[5],
+                   rz = (x * ki.m[6] + y * ki.m[7]) + ki.m[8];
+      const double norm = sqrt((rx * rx + ry * ry) + rz * rz);
+      dist[p] = (DistT)((double)c[stride - 1] * norm);          // one rounding (fp32 output) or none (fp64)
+    }
+  }
+}
+}  // namespace
+}  // namespace mgs
+
+extern "C" int mgs_frame_to_dataset(int width, int height, const float* colors, int color_stride,
+                                    const float* alpha, const float* background, const double* Kinv_host,
+                                    uint8_t* rgba, void* distance, int distance_f64, mgs_stream_t stream) {
+  MGS_REQUIRE(width > 0 && height > 0 && color_stride >= 3, "frame_to_dataset: bad sizes");
+  MGS_REQUIRE(colors && alpha && (rgba || distance), "frame_to_dataset: null pointer");
+  MGS_REQUIRE(!distance || (Kinv_host && color_stride >= 4),
+              "frame_to_dataset: the distance map needs K^-1 and a depth channel (the last of >= 4)");
+  MGS_REQUIRE(((uintptr_t)rgba & 3) == 0, "frame_to_dataset: rgba must be 4-byte aligned");
+  KInv ki;
+  for (int i = 0; i < 9; ++i) ki.m[i] = Kinv_host ? Kinv_host[i] : 0.0;
+  unsigned grid = div_up((unsigned)(width * height), 256u);
+  if (grid > 4096u) grid = 4096u;
+  hipStream_t s = (hipStream_t)stream;
+  if (distance_f64)
+    hipLaunchKernelGGL(frame_to_dataset_kernel<double>, dim3(grid), dim3(256), 0, s, width, height, colors, color_stride,
+                       alpha, background, ki, reinterpret_cast<uint32_t*>(rgba), static_cast<double*>(distance));
+  else
+    hipLaunchKernelGGL(frame_to_dataset_kernel<float>, dim3(grid), dim3(256), 0, s, width, height, colors, color_stride,
+                       alpha, background, ki, reinterpret_cast<uint32_t*>(rgba), static_cast<float*>(distance));
+  return check_launch("frame_to_dataset");
+}

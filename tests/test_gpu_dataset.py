@@ -1,0 +1,67 @@
+"""mgs_frame_to_dataset on the MI355X against the arrays the reference's readers were given
+(tests/golden/dataset_reference.npz), and the whole output path on a rendered frame."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from robosimgs_amd import camera as C
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "dataset_reference.npz"))
+
+
+@pytest.mark.parametrize("i", range(int(G["n_frames"])))
+def test_kernel_writes_the_arrays_the_reference_read(i, tmp_path):
+    from robosimgs_amd.dataset import DatasetWriter, frame_to_dataset
+    colors = torch.from_numpy(G[f"colors_{i}"]).to(DEV)
+    alpha = torch.from_numpy(G[f"alpha_{i}"]).to(DEV)
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        rgba, dist = frame_to_dataset(colors, alpha[..., None], G[f"K_{i}"], background=G["background"].tolist(),
+                                      distance_dtype=dt)
+        assert rgba.dtype == torch.uint8 and dist.dtype == dt and dist.shape == (*alpha.shape, 1)
+        assert np.array_equal(rgba.cpu().numpy(), G[f"rgba_{i}"])                         # bit for bit
+        assert np.array_equal(dist.cpu().numpy(), G[f"distance_{tag}_{i}"])               # bit for bit
+        img, dep = DatasetWriter(str(tmp_path / tag)).write(i, rgba, dist)
+        assert open(img, "rb").read() == G[f"png_bytes_{i}"].tobytes()                    # the very files
+        assert open(dep, "rb").read() == G[f"npygz_bytes_{tag}_{i}"].tobytes()            # the reference opened
+    rgba_only, none = frame_to_dataset(colors[..., :3].contiguous(), alpha)              # RGB frame: image only
+    assert none is None and np.array_equal(rgba_only.cpu().numpy()[..., 3], G[f"rgba_{i}"][..., 3])
+    with pytest.raises(ValueError):
+        frame_to_dataset(colors[..., :3].contiguous(), alpha, G[f"K_{i}"])
+
+
+def test_rendered_frame_through_the_writer_and_back(tmp_path):
+    """Render -> mgs_frame_to_dataset -> files -> this repo's distance_to_depth (reference-pinned in
+    test_camera_golden.py): the z-depth that comes back is the renderer's ED channel to the last bit, the
+    stored mask is alpha > 0."""
+    from robosimgs_amd import camera_ring, rasterization, synthetic_scene
+    from robosimgs_amd.dataset import DatasetWriter, frame_to_dataset, read_dataset_frame
+    g = synthetic_scene(30_000, math.log(0.05), 3, 5)
+    cams = camera_ring(3, 320, 208)
+    t = g.to_torch(DEV, 3)
+    wr = DatasetWriter(str(tmp_path))
+    for i, cam in enumerate(cams):
+        vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(DEV)[None]
+        K = torch.from_numpy(cam.K.astype(np.float32)).to(DEV)[None]
+        with torch.no_grad():
+            colors, alphas, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K,
+                                              320, 208, sh_degree=3, render_mode="RGB+ED")
+        rgba, dist = frame_to_dataset(colors[0], alphas[0], cam.K, distance_dtype=torch.float64)
+        img, dep = wr.write(i, rgba, dist)
+        back_rgba, back_dist = read_dataset_frame(img, dep)
+        a = alphas[0, ..., 0].cpu().numpy()
+        assert 0.05 < (a > 0).mean() < 1.0
+        assert np.array_equal(back_rgba[..., 3] > 0, a > 0)
+        z = C.distance_to_depth(back_dist, cam.K).astype(np.float32)
+        assert np.array_equal(z, colors[0, ..., 3].cpu().numpy())
+        rgba32, dist32 = frame_to_dataset(colors[0], alphas[0], cam.K)                   # fp32 files: one ulp
+        z32 = C.distance_to_depth(dist32[..., 0].cpu().numpy().astype(np.float64), cam.K)
+        ed = colors[0, ..., 3].cpu().numpy()
+        assert np.all(np.abs(z32 - ed.astype(np.float64)) <= np.spacing(np.abs(ed)))
+    assert sorted(os.listdir(wr.image_dir)) == [f"frame_{i:05d}.png" for i in range(3)]
+    assert sorted(os.listdir(wr.depth_dir)) == [f"frame_{i:05d}.npy.gz" for i in range(3)]
