@@ -152,6 +152,19 @@ struct Extras {            // optional outputs of the double build (all may be n
   float* margins = nullptr;        // [4,H,W]  alpha / T / sigma / depth-order margins (inf where nothing was decided)
   uint8_t* edge_mask = nullptr;    // [H,W]
   long long* n_edge = nullptr;     // Gaussians with an uncertain tile rectangle
+  // flip weight [H,W] (needs margins): sum of what every decision within flip_eps = {alpha, T, sigma, depth}
+  // of flipping is worth, as a blend weight (multiply by the feature range for a colour bound):
+  //   alpha / sigma toggle of a Gaussian   alpha T        T threshold (stop here or go on)   T
+  //   depth-order swap of two neighbours   alpha_i alpha_j T      uncertain tile membership   alpha
+  // A toggle also moves every later T by the factor (1 - alpha): later T thresholds are tested against
+  // eps_T + (sum of the toggled alphas so far).
+  float* flip_weight = nullptr;
+  const float* flip_eps = nullptr;
+  // touched [N] (needs margins, edge_mask and flip_eps): 1 for every Gaussian that reaches alpha >= 0.5/255 at
+  // some could-flip pixel (a margin below flip_eps, or an edge pixel).  A flip at a pixel changes T and the
+  // colour behind for every Gaussian blended there: only these rows of the gradient may differ from the
+  // oracle's by more than rounding.
+  uint8_t* touched = nullptr;
   // backward of the blend (A.2 step 10), fp64 accumulation
   const float* v_render = nullptr; // [H,W,ch]
   const float* v_alpha = nullptr;  // [H,W]
@@ -286,6 +299,11 @@ long long render_impl(int n, const float* means, const float* quats, const float
   const size_t n_px = (size_t)width * height;
   const float inf = std::numeric_limits<float>::infinity();
   if (want_margins) std::fill(ex.margins, ex.margins + 4 * n_px, inf);
+  const bool want_fw = want_margins && ex.flip_weight != nullptr && ex.flip_eps != nullptr;
+  std::vector<float> t_at_min;         // T at the pair that came closest to the T threshold (for the edge pixels)
+  if (want_fw) { std::fill(ex.flip_weight, ex.flip_weight + n_px, 0.f); t_at_min.assign(n_px, 0.f); }
+  const double fe_a = want_fw ? ex.flip_eps[0] : 0, fe_t = want_fw ? ex.flip_eps[1] : 0,
+               fe_s = want_fw ? ex.flip_eps[2] : 0, fe_z = want_fw ? ex.flip_eps[3] : 0;
   std::vector<long long> last_idx;     // backward: list position of the last blended Gaussian, -1 if none
   std::vector<double> t_final;         // backward: final transmittance in full precision
   if (want_bwd) { last_idx.assign(n_px, -1); t_final.assign(n_px, 1.0); }
@@ -299,6 +317,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
         F Tr = 1, C[4] = {0, 0, 0, 0};
         const F fx = px + F(0.5), fy = py + F(0.5);
         F m_a = inf, m_t = inf, m_s = inf, m_z = inf, z_prev = -1;
+        double fw = 0, loose = 0, wt_prev = 0, t_min = 0;
         long long last = -1;
         for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
           const int g = ids[perm[i]];
@@ -309,18 +328,33 @@ long long render_impl(int n, const float* means, const float* quats, const float
           F alpha = std::min(F(0.999), s.opac * std::exp(-sigma));
           F nT = Tr * (1 - alpha);
           if (want_margins) {
-            m_a = std::min(m_a, std::abs(alpha * 255 - 1));
+            const F ma = std::abs(alpha * 255 - 1);
+            m_a = std::min(m_a, ma);
+            bool toggle = want_fw && (double)ma < fe_a;
             if (alpha >= F(0.5 / 255.0)) {
-              m_t = std::min(m_t, std::abs(nT / F(1e-4) - 1));
+              const F mt = std::abs(nT / F(1e-4) - 1);
               F S = F(0.5) * (std::abs(s.ca) * dx * dx + std::abs(s.cc) * dy * dy) + std::abs(s.cb * dx * dy);
-              if (S > 0) m_s = std::min(m_s, std::abs(sigma) / S);
+              if (S > 0) {
+                const F ms = std::abs(sigma) / S;
+                m_s = std::min(m_s, ms);
+                if (want_fw && (double)ms < fe_s) toggle = true;
+              }
+              if (toggle) { fw += (double)(alpha * Tr); loose += (double)alpha; toggle = false; }
+              if (mt < m_t) { m_t = mt; t_min = (double)Tr; }
+              if (want_fw && (double)mt < fe_t + loose) fw += (double)Tr;
             }
+            if (toggle) { fw += (double)(alpha * Tr); loose += (double)alpha; }
           }
           if (sigma < 0) continue;
           if (alpha < F(1.0 / 255.0)) continue;
           if (want_margins) {      // consecutive contributors whose depths are within rounding of a tie may swap
-            if (z_prev > 0) m_z = std::min(m_z, (s.depth - z_prev) / s.depth);
+            if (z_prev > 0) {
+              const F mz = (s.depth - z_prev) / s.depth;
+              m_z = std::min(m_z, mz);
+              if (want_fw && (double)mz < fe_z) fw += wt_prev * (double)alpha;
+            }
             z_prev = s.depth;
+            wt_prev = (double)(alpha * Tr);
           }
           if (nT <= F(1e-4)) break;
           F wgt = alpha * Tr;
@@ -337,6 +371,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
           ex.margins[n_px + p] = (float)m_t;
           ex.margins[2 * n_px + p] = (float)m_s;
           ex.margins[3 * n_px + p] = (float)m_z;
+          if (want_fw) { ex.flip_weight[p] = (float)fw; t_at_min[p] = (float)t_min; }
         }
         if (want_bwd) { last_idx[p] = last; t_final[p] = (double)Tr; }
       }
@@ -357,11 +392,41 @@ long long render_impl(int n, const float* means, const float* quats, const float
               F dx = s.mx - (px + F(0.5)), dy = s.my - (py + F(0.5));
               F sigma = F(0.5) * (s.ca * dx * dx + s.cc * dy * dy) + s.cb * dx * dy;
               F alpha = std::min(F(0.999), s.opac * std::exp(-sigma));
-              if (alpha >= F((1.0 - 1e-3) / 255.0)) ex.edge_mask[(size_t)py * width + px] = 1;
+              if (alpha >= F((1.0 - 1e-3) / 255.0)) {
+                const size_t p = (size_t)py * width + px;
+                ex.edge_mask[p] = 1;
+                if (want_fw) {     // the Gaussian may or may not be in this tile's list: worth alpha (T <= 1), and the
+                                   // pixel's closest T threshold moves by the factor (1 - alpha)
+                  ex.flip_weight[p] += (float)alpha;
+                  if ((double)ex.margins[n_px + p] < fe_t + (double)alpha) ex.flip_weight[p] += t_at_min[p];
+                }
+              }
             }
         }
     }
     if (ex.n_edge) *ex.n_edge = n_edge;
+  }
+  if (want_margins && want_edges && ex.touched && ex.flip_eps) {
+    std::memset(ex.touched, 0, (size_t)n);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long t = 0; t < (long long)tw * th; ++t) {
+      const int tx = (int)(t % tw), ty = (int)(t / tw);
+      for (int py = ty * T; py < std::min((ty + 1) * T, height); ++py)
+        for (int px = tx * T; px < std::min((tx + 1) * T, width); ++px) {
+          const size_t p = (size_t)py * width + px;
+          const bool could_flip = ex.edge_mask[p] || ex.margins[p] < ex.flip_eps[0] || ex.margins[n_px + p] < ex.flip_eps[1] ||
+                                  ex.margins[2 * n_px + p] < ex.flip_eps[2] || ex.margins[3 * n_px + p] < ex.flip_eps[3];
+          if (!could_flip) continue;
+          const F fx = px + F(0.5), fy = py + F(0.5);
+          for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
+            const int g = ids[perm[i]];
+            const Splat<F>& s = sp[g];
+            F dx = s.mx - fx, dy = s.my - fy;
+            F sigma = F(0.5) * (s.ca * dx * dx + s.cc * dy * dy) + s.cb * dx * dy;
+            if (s.opac * std::exp(-sigma) >= F(0.5 / 255.0)) ex.touched[g] = 1;     // (benign race: all writers store 1)
+          }
+        }
+    }
   }
 
   // A.2 step 10: backward of the blend, Gaussian-outer per tile, fp64 sums
@@ -465,7 +530,7 @@ extern "C" long long gs_cpu_render(int n, const float* means, const float* quats
 }
 
 // The same frame in fp64 (inputs are the fp32 arrays the GPU gets).  Optional outputs (null to skip):
-// margins [4,H,W] + edge_mask [H,W] + n_edge; blend backward given v_render [H,W,ch] / v_alpha [H,W]
+// margins [4,H,W] + edge_mask [H,W] + n_edge (+ flip_weight [H,W] for the thresholds flip_eps[4], see Extras); blend backward given v_render [H,W,ch] / v_alpha [H,W]
 // into g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opac [N]; the projected quantities
 // o_means2d / o_conics / o_feats / o_radii.
 extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* quats,
@@ -478,9 +543,12 @@ extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* q
                                        uint8_t* edge_mask, long long* n_edge, const float* v_render,
                                        const float* v_alpha, double* g_means2d, double* g_conics,
                                        double* g_feats, double* g_opac, double* o_means2d,
-                                       double* o_conics, double* o_feats, int32_t* o_radii) {
+                                       double* o_conics, double* o_feats, int32_t* o_radii,
+                                       float* flip_weight, const float* flip_eps, uint8_t* touched) {
   Extras ex;
+  ex.touched = touched;
   ex.margins = margins; ex.edge_mask = edge_mask; ex.n_edge = n_edge;
+  ex.flip_weight = flip_weight; ex.flip_eps = flip_eps;
   ex.v_render = v_render; ex.v_alpha = v_alpha;
   ex.g_means2d = g_means2d; ex.g_conics = g_conics; ex.g_feats = g_feats; ex.g_opac = g_opac;
   ex.o_means2d = o_means2d; ex.o_conics = o_conics; ex.o_feats = o_feats; ex.o_radii = o_radii;

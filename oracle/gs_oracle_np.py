@@ -265,7 +265,8 @@ def isect_offsets(isect_ids, n_cams, tile_w, tile_h):
 # A.2 step 9: forward blend (literal sequential loop; small cases only)
 # --------------------------------------------------------------------------------------
 def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, height,
-              tile_size=16, background=None, dtype=np.float64, exp=None, margins=False, depths=None):
+              tile_size=16, background=None, dtype=np.float64, exp=None, margins=False, depths=None,
+              flip_eps=None):
     """Per-tile front-to-back alpha compositing for ONE camera.
 
     colors [N,D]; offsets [th,tw] int32 (first sorted index per tile); the range of
@@ -287,7 +288,15 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
                                round by an fp32 projection (needs `depths`; inf without)
     An implementation whose arithmetic differs from this one by a relative eps can take a different
     branch only at a pixel whose margin is below ~eps; everywhere else it must agree to within the
-    propagated rounding error."""
+    propagated rounding error.
+
+    flip_eps (an EPS_* dict, with margins=True) adds stats["flip_weight"] [H,W] and stats["t_at_min"] [H,W]:
+    what the decisions within flip_eps of flipping are WORTH at that pixel, as a blend weight --
+      alpha / sigma toggle of a Gaussian  alpha T       T threshold (stop at this Gaussian or go on)  T
+      depth-order swap of two neighbours  alpha_i alpha_j T
+    (a toggle also moves every later T by the factor 1 - alpha, so later T thresholds are tested against
+    eps_T + the toggled alphas so far).  A pixel that differs from this blend because such a decision went
+    the other way can be off by at most that weight times the feature range: `check_frame` enforces it."""
     if exp is None:
         exp = np.exp
     mu = np.asarray(means2d, dtype=dtype)
@@ -302,6 +311,11 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
     alpha_img = np.zeros((height, width), dtype=dtype)
     last = np.zeros((height, width), dtype=np.int32)
     marg = np.full((4, height, width), np.inf) if margins else None
+    want_fw = margins and flip_eps is not None
+    fw_img = np.zeros((height, width)) if want_fw else None
+    tmin_img = np.zeros((height, width)) if want_fw else None
+    fe_a, fe_t, fe_s, fe_z = ((flip_eps["alpha"], flip_eps["T"], flip_eps["sigma"], flip_eps.get("depth", 0.0))
+                              if want_fw else (0, 0, 0, 0))
     zs = np.asarray(depths, dtype=np.float64) if depths is not None else None
     n_eval = 0
     n_contrib = 0
@@ -322,6 +336,7 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
             cur_last = np.zeros(px.shape, dtype=np.int32)
             tm = np.full((4,) + px.shape, np.inf) if margins else None
             z_prev = np.full(px.shape, -1.0)
+            fw, loose, wt_prev, t_min = (np.zeros(px.shape) for _ in range(4))
             for i in range(s, e):
                 if done.all():
                     break
@@ -343,12 +358,22 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
                     with np.errstate(divide="ignore", invalid="ignore"):
                         m_s = np.where(S > 0, np.abs(sigma) / S, np.inf)
                     could_count = a >= dtype(0.5 * ALPHA_MIN)     # a sigma flip only matters if alpha would count
+                    if want_fw:
+                        toggle = live & ((m_a < fe_a) | (could_count & (m_s < fe_s)))
+                        fw += np.where(toggle, a * T, 0)
+                        loose += np.where(toggle, a, 0)
+                        closer = live & could_count & (m_t < tm[1])
+                        t_min = np.where(closer, T, t_min)
+                        fw += np.where(live & could_count & (m_t < fe_t + loose), T, 0)
                     tm[0] = np.where(live, np.minimum(tm[0], m_a), tm[0])
                     tm[1] = np.where(live & (a >= dtype(0.5 * ALPHA_MIN)), np.minimum(tm[1], m_t), tm[1])
                     tm[2] = np.where(live & could_count, np.minimum(tm[2], m_s), tm[2])
                     if zs is not None:
                         m_z = np.where(z_prev > 0, (zs[g] - z_prev) / zs[g], np.inf)
                         tm[3] = np.where(ok, np.minimum(tm[3], m_z), tm[3])
+                        if want_fw:
+                            fw += np.where(ok & (m_z < fe_z), wt_prev * a, 0)
+                            wt_prev = np.where(ok, a * T, wt_prev)
                         z_prev = np.where(ok, zs[g], z_prev)
                 stop = ok & (Tn <= dtype(T_STOP))
                 done |= stop
@@ -365,9 +390,14 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
             last[y_lo:y_hi, x_lo:x_hi] = cur_last
             if margins:
                 marg[:, y_lo:y_hi, x_lo:x_hi] = tm
+            if want_fw:
+                fw_img[y_lo:y_hi, x_lo:x_hi] = fw
+                tmin_img[y_lo:y_hi, x_lo:x_hi] = t_min
     stats = {"pair_evals": n_eval, "contribs": n_contrib}
     if margins:
         stats["margins"] = marg
+    if want_fw:
+        stats["flip_weight"], stats["t_at_min"] = fw_img, tmin_img
     return img, alpha_img, last, stats
 
 
@@ -401,13 +431,23 @@ def explained_pixels(margins, eps, edge_mask=None):
     return m
 
 
+FLIP_SLACK = 1.5      # on the flip weight: the fp32 implementation's own alpha / T differ from these by ~eps
+
+
 def check_frame(got, got_alpha, ref, ref_alpha, margins, eps, edge_mask=None, tol=1e-4,
-                expected_depth=False, max_explained=0.03, what="frame"):
+                expected_depth=False, max_explained=0.03, what="frame", flip_weight=None, feat_max=None,
+                require_flip_bound=False):
     """THE forward parity gate.  got / ref [H,W,D], alphas [H,W].  Asserts
       * every pixel whose colour, depth-sum or alpha differs by more than `tol` (1e-4 abs, the
         north-star tolerance) is a pixel where the fp64 blend took a decision within `eps` of
         flipping (explained_pixels) -- ZERO unexplained pixels;
       * such could-flip pixels are at most `max_explained` of the image (the gate is not vacuous).
+      * with flip_weight [H,W] (rasterize(flip_eps=eps) / cpu_ref.render_f64(flip_eps=eps); for whole-path
+        frames already including the edge pixels' share) and feat_max [D] (largest |feature| per channel over
+        the visible Gaussians): a could-flip pixel may be off by at most what the near-flip decisions are worth,
+            |d colour_c| <= tol + FLIP_SLACK * flip_weight * 2 feat_max_c,   |d alpha| <= tol + FLIP_SLACK * flip_weight
+        (toggling a Gaussian changes the pixel by alpha T (c - colour behind it)) -- an error larger than that
+        at a could-flip pixel is as much a failure as an error at any other pixel.
     expected_depth: the last channel is depth-sum / alpha ("ED"): ED = D / alpha, so
     |dED| <= tol (1 + |ED|) / alpha is the same 1e-4 bound on D and alpha propagated through the divide.
     Returns a dict of statistics (for printing)."""
@@ -431,17 +471,35 @@ def check_frame(got, got_alpha, ref, ref_alpha, margins, eps, edge_mask=None, to
         f"{what}: {stats['unexplained']} pixels differ from the oracle by more than {tol:g} without any "
         f"threshold within eps of flipping (first at {tuple(np.argwhere(unexplained)[0])}); {stats}")
     assert stats["could_flip_frac"] <= max_explained, f"{what}: gate is vacuous: {stats}"
+    assert flip_weight is not None or not require_flip_bound, f"{what}: no flip weight given"
+    if flip_weight is not None:
+        fw = FLIP_SLACK * np.asarray(flip_weight, dtype=np.float64)
+        fm = np.asarray(feat_max, dtype=np.float64).reshape(-1)[:got.shape[-1]]
+        lim_f = lim + fw[..., None] * 2.0 * fm[None, None, :]
+        if expected_depth:      # d(D / alpha) <= (dD + |ED| d alpha) / alpha
+            lim_f[..., -1] = (tol * (1.0 + np.abs(ref[..., -1])) + fw * (2.0 * fm[-1] + np.abs(ref[..., -1]))) \
+                / np.maximum(np.minimum(ra, ga), 1e-10)
+        over = ex & ((d > lim_f).any(-1) | (np.abs(ga - ra) > tol + fw))
+        ratio = np.where(ex[..., None], d / lim_f, 0.0)
+        stats.update(flip_over_bound=int(over.sum()), max_flip_err_over_bound=float(ratio.max()),
+                     max_err_at_flip_pixels=float(np.where(ex[..., None], d[..., :3], 0.0).max()),
+                     max_flip_weight=float(np.where(ex, fw / FLIP_SLACK, 0.0).max()))
+        assert stats["flip_over_bound"] == 0, (
+            f"{what}: {stats['flip_over_bound']} could-flip pixels are off by more than their near-flip decisions "
+            f"are worth (first at {tuple(np.argwhere(over)[0])}: |d| = {d[tuple(np.argwhere(over)[0])]}, bound "
+            f"{lim_f[tuple(np.argwhere(over)[0])]}); {stats}")
     return stats
 
 
 def gaussian_edge_mask(p, opacities, width, height, tile_size=16, eps_radius=3e-5, d_mu=1e-3,
-                       eps_alpha=1e-3, near_plane=0.01, far_plane=1e10):
+                       eps_alpha=1e-3, near_plane=0.01, far_plane=1e10, return_weight=False):
     """bool [H,W]: pixels that a Gaussian reaches with alpha >= (1 - eps_alpha)/255 inside a tile
     whose membership in that Gaussian's tile rectangle depends on a knife edge of A.2 steps 2-5/7:
     3 sqrt(lambda) within eps_radius (relative) of an integer (the ceil), mean2d +- radius within
     d_mu pixels of a tile boundary or of the screen-cull limits, depth within 1e-5 relative of the
     near / far plane.  `p` is the dict `project` returned ("lam" included)."""
     mask = np.zeros((height, width), dtype=bool)
+    weight = np.zeros((height, width))           # sum of the alphas of the uncertain Gaussians reaching the pixel
     tw, th = -(-width // tile_size), -(-height // tile_size)
     v = 3.0 * np.sqrt(p["lam"])
     z, mu = p["z"], p["mu"]
@@ -481,6 +539,9 @@ def gaussian_edge_mask(p, opacities, width, height, tile_size=16, eps_radius=3e-
                 a = np.minimum(ALPHA_MAX, opa[g] * np.exp(-sig))
                 hit = a >= (1.0 - eps_alpha) * ALPHA_MIN
                 mask[ty * tile_size:ty * tile_size + len(ys), tx * tile_size:tx * tile_size + len(xs)] |= hit
+                weight[ty * tile_size:ty * tile_size + len(ys), tx * tile_size:tx * tile_size + len(xs)] += np.where(hit, a, 0.0)
+    if return_weight:
+        return mask, int(unsure.sum()), weight
     return mask, int(unsure.sum())
 
 
@@ -490,11 +551,12 @@ def gaussian_edge_mask(p, opacities, width, height, tile_size=16, eps_radius=3e-
 def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, height,
            sh_degree=None, tile_size=16, render_mode="RGB", eps2d=0.3,
            near_plane=0.01, far_plane=1e10, radius_clip=0.0, background=None,
-           rasterize_mode="classic", dtype=np.float64, margins=False):
+           rasterize_mode="classic", dtype=np.float64, margins=False, flip_eps=None):
     """Full single-camera frame following SURVEY.md A.1/A.2.  Inputs are post-activation
     (scales = exp(log_s), opacities = sigmoid(logit)).  Returns (colors[H,W,D],
     alpha[H,W,1], meta).  margins=True adds meta["margins"] (see `rasterize`) and
-    meta["edge_mask"] / meta["n_edge_gaussians"] (see `gaussian_edge_mask`)."""
+    meta["edge_mask"] / meta["n_edge_gaussians"] (see `gaussian_edge_mask`); flip_eps (an EPS_* dict) also
+    meta["flip_weight"] [H,W] (edge pixels included) and meta["feat_max"] [D] for `check_frame`."""
     tile_w = -(-width // tile_size)
     tile_h = -(-height // tile_size)
     p = project(means, quats, scales, viewmat, K, width, height, eps2d, near_plane,
@@ -525,15 +587,24 @@ def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, hei
         bg = np.asarray(background, dtype=dtype)
     img, alpha, last, stats = rasterize(p["means2d"], p["conics"], feats, opac,
                                         flatten_ids, offs, width, height, tile_size,
-                                        bg, dtype, margins=margins, depths=p["depths"] if margins else None)
+                                        bg, dtype, margins=margins, depths=p["depths"] if margins else None,
+                                        flip_eps=flip_eps if margins else None)
     if render_mode in ("ED", "RGB+ED"):
         img = img.copy()
         img[..., -1] = img[..., -1] / np.maximum(alpha, dtype(1e-10))
     meta = dict(p)
     if margins:
-        em, n_edge = gaussian_edge_mask(p, opac, width, height, tile_size,
-                                        near_plane=near_plane, far_plane=far_plane)
+        em, n_edge, ew = gaussian_edge_mask(p, opac, width, height, tile_size,
+                                            near_plane=near_plane, far_plane=far_plane, return_weight=True)
         meta.update(edge_mask=em, n_edge_gaussians=n_edge)
+        if flip_eps is not None:
+            # an uncertain tile membership is worth the Gaussian's alpha (T <= 1) and moves the pixel's closest
+            # T threshold by the factor (1 - alpha)
+            fw = stats.pop("flip_weight") + ew
+            fw = fw + np.where(em & (stats["margins"][1] < flip_eps["T"] + ew), stats.pop("t_at_min"), 0.0)
+            vis = p["radii"] > 0
+            meta.update(flip_weight=fw, feat_max=(np.abs(feats[vis]).max(axis=0) if vis.any()
+                                                  else np.zeros(feats.shape[1])))
     meta.update(tiles_per_gauss=tpg, isect_ids=isect_ids, flatten_ids=flatten_ids,
                 isect_offsets=offs, last_ids=last, colors=rgb, opacities=opac,
                 tile_width=tile_w, tile_height=tile_h, n_isect=len(flatten_ids),

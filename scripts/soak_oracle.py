@@ -24,10 +24,11 @@ for seed in range(N):
     c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], _t(cam.viewmat())[None], _t(cam.K)[None],
                                W, H, sh_degree=deg, render_mode=mode, rasterize_mode=rm_, raster_schedule=sched)
     ref, ra, rm = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, f32(cam.viewmat()), f32(cam.K), W, H, sh_degree=deg,
-                           render_mode=mode, rasterize_mode=rm_, margins=True)
+                           render_mode=mode, rasterize_mode=rm_, margins=True, flip_eps=O.EPS_PATH)
     try:
         st = O.check_frame(c[0].cpu().numpy(), a[0].cpu().numpy(), ref, ra, rm["margins"], O.EPS_PATH, rm["edge_mask"],
-                           expected_depth="E" in mode, max_explained=1.0, what=f"seed {seed}")
+                           expected_depth="E" in mode, max_explained=1.0, what=f"seed {seed}",
+                           flip_weight=rm["flip_weight"], feat_max=rm["feat_max"], require_flip_bound=True)
     except AssertionError as e:
         failures.append(str(e)[:300]); continue
     over += st["over_tol"]; worst_nonflip = max(worst_nonflip, st["max_err_over_tol_nonflip"]); worst_flag = max(worst_flag, st["could_flip_frac"])

@@ -43,14 +43,15 @@ def test_ply_and_json_to_pixels(tmp_path):
         # transforms.json) against the fp64 oracle on those very inputs: the zero-unexplained-pixels gate
         lc = loaded[i]
         ref, ra, rm = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, f32(lc.viewmat()), f32(lc.K),
-                               160, 96, sh_degree=2, render_mode="RGB+ED", margins=True)
+                               160, 96, sh_degree=2, render_mode="RGB+ED", margins=True, flip_eps=O.EPS_PATH)
         rgb_ref = np.clip(ref[..., :3] + (1 - ra) * 0.1, 0, 1)
         got = np.concatenate([out["rgb"][i].cpu().numpy(), out["depth"][i].cpu().numpy()], -1)
         want = np.concatenate([rgb_ref, np.where(ra > 0, ref[..., 3:], ref[..., 3].max())], -1)
         lit = ra[..., 0] > 0                    # splatfacto's post-processing replaces depth where alpha == 0
         got[~lit, 3] = want[~lit, 3]
         O.check_frame(got, out["alpha"][i].cpu().numpy(), want, ra, rm["margins"], O.EPS_PATH, rm["edge_mask"],
-                      expected_depth=True, what=f"loaded scene, camera {i}")
+                      expected_depth=True, what=f"loaded scene, camera {i}", flip_weight=rm["flip_weight"],
+                      feat_max=np.maximum(rm["feat_max"], [0.1, 0.1, 0.1, 0.0]), require_flip_bound=True)
         # (2) the export / import round trip (positions, orientations AND the SH colour field rotated there and
         # back, fp32 on disk) reproduces the ORIGINAL scene's image to the precision of that round trip
         ref0, ra0, _ = O.render(world.means, world.quats, world.scales, world.opacities, world.sh_coeffs,

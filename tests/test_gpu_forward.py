@@ -199,9 +199,11 @@ def test_rasterize_matches_oracle(ops, n, mu, w, h, deg):
         means2d.cpu().numpy(), conics.cpu().numpy(), feats.cpu().numpy(),
         t["opacities"].cpu().numpy(), tl.flatten_ids[:n_isect].cpu().numpy(),
         tl.tile_offsets[:-1].cpu().numpy().reshape(th, tw), w, h, 16,
-        background=bg.cpu().numpy(), margins=True)
+        background=bg.cpu().numpy(), margins=True, flip_eps=O.EPS_STAGE)
     st = O.check_frame(render.cpu().numpy(), alphas.cpu().numpy(), ref_img, ref_alpha, stats["margins"],
-                       O.EPS_STAGE, what=f"blend stage n={n}")
+                       O.EPS_STAGE, what=f"blend stage n={n}", flip_weight=stats["flip_weight"],
+                       feat_max=np.maximum(feats.abs().amax(0).cpu().numpy(), bg.abs().cpu().numpy()),
+                       require_flip_bound=True)
     print(f"\nblend stage n={n} {w}x{h}: {st}")
     same_last = (last.cpu().numpy() == ref_last).mean()
     assert same_last >= 0.999, f"last_ids agree on {same_last:.5f} of pixels"
@@ -219,7 +221,7 @@ def test_rasterization_end_to_end(mode):
                                          256, 256, sh_degree=0, render_mode=mode, tile_bounds="classic")
     ref, ref_alpha, rmeta = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
                                      _f32(cam.viewmat()), _f32(cam.K), 256, 256, sh_degree=0,
-                                     render_mode=mode, margins=True)
+                                     render_mode=mode, margins=True, flip_eps=O.EPS_PATH)
     assert colors.shape == (1,) + ref.shape
     assert int(meta["radii"].gt(0).sum()) == rmeta["n_vis"] == 9849
     if "n_isects" in meta:
@@ -227,7 +229,8 @@ def test_rasterization_end_to_end(mode):
     # whole path vs whole fp64 oracle (fed the fp32-rounded camera the GPU gets): zero pixels over
     # 1e-4 that no threshold / knife edge within O.EPS_PATH explains
     st = O.check_frame(colors[0].cpu().numpy(), alphas[0].cpu().numpy(), ref, ref_alpha, rmeta["margins"],
-                       O.EPS_PATH, rmeta["edge_mask"], expected_depth="E" in mode, what=f"configs[0] {mode}")
+                       O.EPS_PATH, rmeta["edge_mask"], expected_depth="E" in mode, what=f"configs[0] {mode}",
+                       flip_weight=rmeta["flip_weight"], feat_max=rmeta["feat_max"], require_flip_bound=True)
     print(f"\nconfigs[0] {mode}: {st}")
     # default (tight) tile bounds: shorter lists, the same image bit for bit
     c2, a2, meta2 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
@@ -252,9 +255,11 @@ def test_rasterization_multi_camera_and_capacity():
     check_isect_status(meta)
     for c, cam in enumerate(cams):
         ref, ref_alpha, rm = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
-                                      _f32(cam.viewmat()), _f32(cam.K), 160, 96, sh_degree=2, margins=True)
+                                      _f32(cam.viewmat()), _f32(cam.K), 160, 96, sh_degree=2, margins=True,
+                                      flip_eps=O.EPS_PATH)
         O.check_frame(colors[c].cpu().numpy(), alphas[c].cpu().numpy(), ref, ref_alpha, rm["margins"],
-                      O.EPS_PATH, rm["edge_mask"], what=f"camera {c}")
+                      O.EPS_PATH, rm["edge_mask"], what=f"camera {c}", flip_weight=rm["flip_weight"],
+                      feat_max=rm["feat_max"], require_flip_bound=True)
     _, _, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"],
                                vm, Ks, 160, 96, sh_degree=2, isect_capacity=100)
     with pytest.raises(_lib.MgsError):

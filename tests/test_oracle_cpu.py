@@ -21,16 +21,20 @@ def test_config0_counts_and_image():
                                       cam.viewmat(), cam.K, 256, 256, 0, n_threads=4)
     vm, K = cam.viewmat().astype(np.float32).astype(np.float64), cam.K.astype(np.float32).astype(np.float64)
     ref, ref_alpha, meta = O.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
-                                    vm, K, 256, 256, sh_degree=0, margins=True)
+                                    vm, K, 256, 256, sh_degree=0, margins=True, flip_eps=O.EPS_PATH)
     assert info["n_vis"] == meta["n_vis"] == 9849
     assert info["n_isect"] == meta["n_isect"] == 37024
     assert info["pair_evals"] == meta["pair_evals"]
     # fp32 port vs fp64 oracle: zero pixels over 1e-4 that no threshold within EPS_PATH explains
-    O.check_frame(img, alpha, ref, ref_alpha, meta["margins"], O.EPS_PATH, meta["edge_mask"], what="fp32 port")
+    st = O.check_frame(img, alpha, ref, ref_alpha, meta["margins"], O.EPS_PATH, meta["edge_mask"], what="fp32 port",
+                       flip_weight=meta["flip_weight"], feat_max=meta["feat_max"], require_flip_bound=True)
+    assert st["flip_over_bound"] == 0
     # fp64 instantiation of the port == the NumPy oracle (to the fp32 rounding of its outputs),
     # image and margins alike
     r64, a64, i64 = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vm, K, 256, 256, 0,
-                                       n_threads=4)
+                                       n_threads=4, flip_eps=O.EPS_PATH, want_touched=True)
+    # Gaussians blended into a could-flip pixel: some, not all, and only visible ones
+    assert 0 < i64["touched"].sum() < 0.5 * meta["n_vis"] and not (i64["touched"] & (meta["radii"] <= 0)).any()
     np.testing.assert_allclose(r64, ref, atol=3e-7)
     np.testing.assert_allclose(a64, ref_alpha[..., 0], atol=3e-7)
     both = np.isfinite(meta["margins"]) & np.isfinite(i64["margins"])
@@ -38,6 +42,10 @@ def test_config0_counts_and_image():
     np.testing.assert_allclose(i64["margins"][both], meta["margins"][both], rtol=1e-3, atol=1e-3)
     assert i64["n_edge_gaussians"] == meta["n_edge_gaussians"]
     assert (i64["edge_mask"] == meta["edge_mask"]).all()
+    # the two oracles price the near-flip decisions alike
+    np.testing.assert_allclose(i64["flip_weight"], meta["flip_weight"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(i64["feat_max"], meta["feat_max"], rtol=1e-6)
+    assert 0 < (meta["flip_weight"] > 0).mean() < 0.03
 
 
 def test_port_backward_matches_autograd_oracle():
