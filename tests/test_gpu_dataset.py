@@ -41,7 +41,7 @@ def test_rendered_frame_through_the_writer_and_back(tmp_path):
     stored mask is alpha > 0."""
     from robosimgs_amd import camera_ring, rasterization, synthetic_scene
     from robosimgs_amd.dataset import DatasetWriter, frame_to_dataset, read_dataset_frame
-    g = synthetic_scene(30_000, math.log(0.05), 3, 5)
+    g = synthetic_scene(1_500, math.log(0.02), 3, 5)          # sparse: some pixels see no splat at all
     cams = camera_ring(3, 320, 208)
     t = g.to_torch(DEV, 3)
     wr = DatasetWriter(str(tmp_path))
@@ -55,7 +55,7 @@ def test_rendered_frame_through_the_writer_and_back(tmp_path):
         img, dep = wr.write(i, rgba, dist)
         back_rgba, back_dist = read_dataset_frame(img, dep)
         a = alphas[0, ..., 0].cpu().numpy()
-        assert 0.05 < (a > 0).mean() < 1.0
+        assert 0.01 < (a > 0).mean() < 1.0
         assert np.array_equal(back_rgba[..., 3] > 0, a > 0)
         z = C.distance_to_depth(back_dist, cam.K).astype(np.float32)
         assert np.array_equal(z, colors[0, ..., 3].cpu().numpy())

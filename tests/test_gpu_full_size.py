@@ -158,7 +158,7 @@ def test_config3_backward_matches_fp64_oracle(config2):
     vmf, Kf = np.asarray(cam.viewmat(), np.float32), np.asarray(cam.K, np.float32)
     _, _, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vmf, Kf, W, H, deg,
                                     margins=True, v_render=w_img, v_alpha=w_a, want_projected=True,
-                                    flip_eps=O.EPS_PATH, want_touched=True)
+                                    flip_eps=O.EPS_PATH_GRAD, want_touched=True)
     vis = info["radii"] > 0
     # rows over tolerance must belong to Gaussians blended into a could-flip pixel of the fp64 blend: zero
     # unexplained rows (on top of the 1 % bound on how many may be over at all)
