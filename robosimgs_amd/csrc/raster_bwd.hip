@@ -21,7 +21,7 @@ namespace {
 template <int CHT>
 struct BwdEntry {
   float4 geo0;                       // mean.x, mean.y, conic.a, conic.b
-  float4 geo1;                       // conic.c, opacity, quadrant mask (bits), list index (bits)
+  float4 geo1;                       // conic.c, L = log2(opacity), quadrant mask (bits), list index (bits)
   float4 feat[(CHT + 3) / 4];
   float4 geo2;                       // record slot / Gaussian id (bits), then the conic pre-scaled for exp2:
 };                                   //   A = -0.5 log2e a, B = -log2e b, C = -0.5 log2e c
@@ -55,19 +55,18 @@ struct GaussGrad {
 template <int CHT, bool ABSGRAD>
 __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, float pxf,
                                            float pyf, float mx, float my, float ca, float cb,
-                                           float cc, float A, float B, float C, float opac,
+                                           float cc, float A, float B, float C, float L,
                                            const float* feat, int idx) {
   float dx = mx - pxf, dy = my - pyf;
-  // the forward's own evaluation (raster_fwd.hip blend_pixel): power = -sigma log2(e), bit for bit
-  float power = fmaf(dx, fmaf(B, dy, A * dx), (C * dy) * dy);
-  float vis = __builtin_amdgcn_exp2f(power);
-  float ov = opac * vis;
+  // the forward's own evaluation (raster_fwd.hip blend_pixel, raster_common.h pair_power), bit for bit:
+  // ov = opacity * exp(-sigma) as one exp2 with log2(opacity) folded into the exponent
+  float ov = __builtin_amdgcn_exp2f(pair_power(dx, dy, A, B, C, L));
   float alpha = fminf(kAlphaMax, ov);
-  bool valid = idx <= px.last && power <= 0.f && alpha >= kAlphaMin;
+  bool valid = idx <= px.last && pair_power_sign(dx, dy, A, B, C) <= 0.f && alpha >= kAlphaMin;
   if (__ballot(valid) == 0ull) return false;
   float a_eff = valid ? alpha : 0.f;                       // 0 => T, bv and v_f stay untouched
   bool grad_geo = valid && ov <= kAlphaMax;                // alpha not clamped: sigma/opacity get grads
-  float vis_eff = grad_geo ? vis : 0.f;
+  float ov_eff = grad_geo ? ov : 0.f;
   float ra = __builtin_amdgcn_rcpf(1.0f - a_eff);          // v_rcp_f32; an IEEE divide is 11 instructions
   px.T *= ra;
   float fac = a_eff * px.T;
@@ -79,7 +78,7 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   px.bv = fmaf(fv, fac, px.bv);
 #pragma unroll
   for (int c = 0; c < CHT; ++c) gg.v_f[c] = fmaf(fac, px.v_c[c], gg.v_f[c]);
-  float v_sigma = -(opac * vis_eff) * v_alpha;
+  float v_sigma = -ov_eff * v_alpha;
   float p = v_sigma * dx, q = v_sigma * dy;
   gg.v_ca = fmaf(p, dx, gg.v_ca);
   gg.v_cb = fmaf(p, dy, gg.v_cb);
@@ -90,7 +89,7 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
     gg.a_x += fabsf(fmaf(cb, q, ca * p));
     gg.a_y += fabsf(fmaf(cc, q, cb * p));
   }
-  gg.v_op = fmaf(vis_eff, v_alpha, gg.v_op);
+  gg.v_op = fmaf(ov_eff, v_alpha, gg.v_op);       // opacity * d loss / d opacity: the caller divides by the opacity once
   return valid;
 }
 
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     if (qmask != 0u) {
       BwdEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(xy.x, xy.y, ca, cb);
-      e.geo1 = make_float4(cc, op, __uint_as_float(qmask), __int_as_float(idx));
+      e.geo1 = make_float4(cc, __log2f(op), __uint_as_float(qmask), __int_as_float(idx));
       int gid = g;
       if (RECORDS) {
         const int4 info = pair_info[g];
@@ -352,6 +351,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         pend = false;
       }
       if (__ballot(any) == 0ull) continue;
+      gg.v_op *= __builtin_amdgcn_exp2f(-g1.y);      // grad_pixel summed opacity * d/d opacity: divide by the opacity (2^L)
       if constexpr (RECORDS) {
         // overflowed tile lists (status word set by the binning): slot bases run up to the true
         // n_isect, the workspace only to the capacity -- nothing is written past it

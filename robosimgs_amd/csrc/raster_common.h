@@ -81,11 +81,28 @@ __device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float a, f
 // it to within ~6e-7 S.  A conic with lambda_min / lambda_max >= 1e-4 (det >= 1e-4 trace^2) can therefore
 // never produce sigma < 0 and the test is dead for it.  When every queued conic of a 64-entry batch is
 // such (nearly always) the batch is walked by a copy of the loop without the test: one compare and one
-// scalar AND less per 64 pairs; a batch holding a needle-like conic keeps the full test.  Results are identical.
+// scalar AND less per 64 pairs; a batch holding a needle-like conic keeps the full test.  Results are identical
+// (the exponent below is evaluated by the same expression either way).
 __device__ __forceinline__ bool sigma_sign_is_safe(float a, float b, float c) {
   const float tr = a + c;
   return a > 0.f && c > 0.f && fmaf(a, c, -b * b) >= 1e-4f * tr * tr;     // false for NaN
 }
+
+// ---- alpha of one pixel-Gaussian pair, shared bit for bit by the forward and the backward ------------------
+// The queue entry carries the conic pre-scaled by -log2(e) (A = -0.5 log2e a, B = -log2e b, C = -0.5 log2e c) and
+// L = log2(opacity), so that   opacity * exp(-sigma) = exp2(A dx^2 + B dx dy + C dy^2 + L)
+// is ONE v_exp_f32 of ONE fused expression: L rides in the addend of the last-but-one FMA (no multiply by the
+// opacity afterwards).  `pair_power` is that exponent; `pair_power_sign` is the same expression without L, needed
+// only where sigma >= 0 must be tested (conics that are not sigma_sign_is_safe).
+__device__ __forceinline__ float pair_power(float dx, float dy, float A, float B, float C, float L) {
+  return fmaf(dx, fmaf(B, dy, A * dx), fmaf(C * dy, dy, L));
+}
+__device__ __forceinline__ float pair_power_sign(float dx, float dy, float A, float B, float C) {
+  return fmaf(dx, fmaf(B, dy, A * dx), (C * dy) * dy);
+}
+// Batches whose queued Gaussians all have a well conditioned conic AND an opacity <= kSafeOpacity are walked
+// without the sigma >= 0 test and without the 0.999 clamp: exp2(power + L) <= opacity (1 + 2^-22) < 0.999.
+constexpr float kSafeOpacity = 0.998f;
 
 // full-wave sum: result valid in lane 63
 __device__ __forceinline__ float wave_reduce_to_lane63(float v) {

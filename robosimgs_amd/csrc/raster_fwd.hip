@@ -14,6 +14,17 @@
 // min waves per SIMD asked of the register allocator; 8 / 6 / 5 spill and lose (profiles/r1/05)
 #define MGS_RASTER_WAVES 4
 #endif
+#ifndef MGS_RASTER_REFRESH
+// one-wave-per-tile kernel: re-derive the live quadrants every this many queue entries (power of two; 0 = per batch only,
+// the default: 8 / 16 / 32 measured 205.8 / 204.9 / 206.3 us against 201.4 without, profiles/r3/00_experiments.md)
+#define MGS_RASTER_REFRESH 0
+#endif
+#ifndef MGS_RASTER_SWITCH
+// 1 / 2: one straight-line body per quadrant set (switch on the entry's mask) so that the scheduler can interleave the
+// quadrants' chains -- measured 268-278 us against 197 for the four scalar-branched bodies (109 VGPRs, copies
+// between the fifteen paths): off
+#define MGS_RASTER_SWITCH 0
+#endif
 #ifndef MGS_RASTER_WG_WAVES
 // Independent tiles (waves) per workgroup of the INFERENCE variant; no workgroup barrier is ever
 // used.  One-wave workgroups grab every wave slot the moment it frees up and starve the 4-wave
@@ -30,7 +41,7 @@ namespace {
 template <int CHT>
 struct QueueEntry {
   float4 geo0;                       // mean.x, mean.y, A, B   (A,B,C: conic pre-scaled, below)
-  float4 geo1;                       // C, opacity, quadrant mask (bits), list index (bits)
+  float4 geo1;                       // C, L = log2(opacity), quadrant mask (bits), list index (bits)
   float4 feat[(CHT + 3) / 4];
 };
 
@@ -61,21 +72,21 @@ __device__ unsigned long long g_raster_stats[8];
 #endif
 
 // One Gaussian against the 64 pixels of one quadrant (one pixel per lane).
-//   power = -sigma * log2(e) = A dx^2 + C dy^2 + B dx dy  with  A = -0.5 log2e a, B = -log2e b,
-//   C = -0.5 log2e c, so exp(-sigma) is a single v_exp_f32 and "sigma >= 0" is "power <= 0".
+//   alpha = opacity exp(-sigma) = exp2(A dx^2 + C dy^2 + B dx dy + L)  with  A = -0.5 log2e a, B = -log2e b,
+//   C = -0.5 log2e c, L = log2(opacity): one v_exp_f32, no multiply by the opacity (raster_common.h pair_power);
+//   "sigma >= 0" is "pair_power_sign <= 0".
 // TRACK_LAST: record the list index of the last blended Gaussian (the backward starts there);
 // an inference render drops that select (compares / selects issue at half the FMA rate on gfx950).
 template <int CHT, bool TRACK_LAST, bool SAFE = false>
 __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, float pyf, float mx,
-                                            float my, float A, float B, float C, float opac,
+                                            float my, float A, float B, float C, float L,
                                             const float* feat, int idx) {
   float dx = mx - pxf, dy = my - pyf;
-  float power = fmaf(dx, fmaf(B, dy, A * dx), (C * dy) * dy);   // spelled out: the backward repeats it bit for bit
-  // SAFE: the conic cannot round sigma below zero (sigma_sign_is_safe) and opacity <= 0.999: the sigma test is
-  // dead, exp2(power) <= 1, so opac * exp2(power) <= opac <= 0.999 and the clamp is the identity too
-  const float ov = opac * __builtin_amdgcn_exp2f(power);
+  // SAFE: the conic cannot round sigma below zero (sigma_sign_is_safe) and opacity <= kSafeOpacity: the sigma test
+  // is dead and exp2(power) <= opacity (1 + 2^-22) < 0.999, so the clamp is the identity too
+  const float ov = __builtin_amdgcn_exp2f(pair_power(dx, dy, A, B, C, L));      // the backward repeats it bit for bit
   float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
-  bool valid = SAFE ? alpha >= kAlphaMin : (power <= 0.f && alpha >= kAlphaMin);
+  bool valid = SAFE ? alpha >= kAlphaMin : (pair_power_sign(dx, dy, A, B, C) <= 0.f && alpha >= kAlphaMin);
   // alpha forced to 0 where the Gaussian does not count: an open pixel (T > 1e-4 by invariant)
   // then keeps T and adds nothing, with no second mask to combine
   float a_eff = valid ? alpha : 0.f;
@@ -88,6 +99,61 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
   for (int c = 0; c < CHT; ++c) px.C[c] = fmaf(w, feat[c], px.C[c]);
   px.T = acc ? next_T : -fabsf(px.T);             // not accumulated: the pixel is (or stays) finished
   if (TRACK_LAST) px.last = (acc && valid) ? idx : px.last;
+#ifdef MGS_RASTER_STATS
+  px.n_valid += valid && px.T > 0.f;
+  px.n_acc += acc && valid;
+#endif
+}
+
+#ifndef MGS_RASTER_CMPX
+#define MGS_RASTER_CMPX 1
+#endif
+// The SAFE inference blend (3 or 4 channels) as hand-written gfx950 code: the same arithmetic in the same order as
+// blend_pixel<CHT, false, true> -- bit-identical pixels -- with the alpha >= 1/255 test as a v_cmpx that narrows
+// EXEC to the lanes that count instead of a compare plus a select on alpha (a Gaussian that does not count leaves
+// the pixel untouched: with a_eff = 0 the generic form adds 0 and re-selects the T it had).  18 vector
+// instructions per 64 pairs instead of 19, and the ~60 % of lanes that fail the test stay idle for the ten
+// instructions behind it.  gfx940+ needs two wait states between a VALU write of VCC and a VALU read of it, one
+// after a transcendental: filled with independent work where there is some.
+template <int CHT>
+__device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, float pxf, float pyf, float mx, float my,
+                                                     float A, float B, float C, float L, const float* feat) {
+  static_assert(CHT == 3 || CHT == 4, "hand-written blend: 3 or 4 channels");
+  float dx, dy, t0, t1, nT, w;
+  const float amin = kAlphaMin, tstop = kTStop;
+  float c3 = CHT == 4 ? px.C[CHT - 1] : 0.f;
+  const float f3 = CHT == 4 ? feat[CHT - 1] : 0.f;
+  asm volatile(
+      "v_sub_f32 %[dx], %[mx], %[px]\n"
+      "v_sub_f32 %[dy], %[my], %[py]\n"
+      "v_mul_f32 %[t0], %[A], %[dx]\n"
+      "v_mul_f32 %[t1], %[C], %[dy]\n"
+      "v_fmac_f32 %[t0], %[B], %[dy]\n"
+      "v_fma_f32 %[t1], %[t1], %[dy], %[L]\n"
+      "v_fmac_f32 %[t1], %[dx], %[t0]\n"
+      "v_exp_f32 %[t1], %[t1]\n"
+      "s_nop 0\n"
+      "v_cmpx_le_f32 vcc, %[amin], %[t1]\n"
+      "v_fma_f32 %[nT], -%[t1], %[T], %[T]\n"
+      "v_mul_f32 %[w], %[t1], %[T]\n"
+      "v_cmp_lt_f32 vcc, %[tstop], %[nT]\n"
+      "s_nop 1\n"
+      "v_cndmask_b32 %[w], 0, %[w], vcc\n"
+      "v_cndmask_b32_e64 %[T], -|%[T]|, %[nT], vcc\n"
+      "v_fmac_f32 %[c0], %[w], %[f0]\n"
+      "v_fmac_f32 %[c1], %[w], %[f1]\n"
+      "v_fmac_f32 %[c2], %[w], %[f2]\n"
+      ".if %[four]\n"
+      "v_fmac_f32 %[c3], %[w], %[f3]\n"
+      ".endif\n"
+      "s_mov_b64 exec, -1\n"
+      : [dx] "=&v"(dx), [dy] "=&v"(dy), [t0] "=&v"(t0), [t1] "=&v"(t1), [nT] "=&v"(nT), [w] "=&v"(w),
+        [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3)
+      : [mx] "v"(mx), [my] "v"(my), [px] "v"(pxf), [py] "v"(pyf), [A] "v"(A), [B] "v"(B), [C] "v"(C), [L] "v"(L),
+        [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
+        [four] "n"(CHT == 4 ? 1 : 0)
+      : "vcc");
+  if (CHT == 4) px.C[CHT - 1] = c3;
 }
 
 template <int CHT, bool TRACK_LAST>
@@ -193,7 +259,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     // every queued Gaussian of this batch has a well conditioned conic and an opacity <= 0.999 (nearly
     // always): the sigma >= 0 test and the 0.999 clamp are dead for the whole batch and the walk below runs
     // without them (raster_common.h: sigma_sign_is_safe) -- two compare / min class instructions less per 64 pairs
-    const bool all_safe = __ballot(qmask != 0u && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kAlphaMax)) == 0ull;
+    const bool all_safe = __ballot(qmask != 0u && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
     const int count = __popcll(keep);
     MGS_STAT(0, __popcll(__ballot(c_ok)));
     MGS_STAT(1, count);
@@ -201,7 +267,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     if (qmask != 0u) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
-      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, c_op, __uint_as_float(qmask), __int_as_float(c_idx));
+      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, __log2f(c_op), __uint_as_float(qmask), __int_as_float(c_idx));
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
         float4 v;
@@ -218,6 +284,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 
     // (measured and rejected: reading entry j+1 while blending entry j, 307 vs 292 us; two
     //  entries per loop trip, 291 vs 288 us)
+    unsigned live_now = live;
     auto blend_entry = [&](auto safe_tag, const float4& g0, const float4& g1, const float4* ef) {
       constexpr bool SAFE = decltype(safe_tag)::value;
       float feat[CHT];
@@ -228,17 +295,66 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
         if (4 * f + 2 < CHT) feat[4 * f + 2] = ef[f].z;
         if (4 * f + 3 < CHT) feat[4 * f + 3] = ef[f].w;
       }
-      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z));
+      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z)) & live_now;
       const int idx = __float_as_int(g1.w);
       MGS_STAT(2, __popc(m));
+#if MGS_RASTER_SWITCH
+      // One straight-line body per quadrant SET instead of four scalar-branched ones: the bodies of an entry's
+      // quadrants are independent chains of ~19 dependent instructions each, and only inside one basic block can
+      // the scheduler interleave them (a lone wave issues a dependent chain at one instruction per ~5 cycles).
+#define MGS_Q(k) blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], px0 + 8.f * ((k) & 1), py0 + 8.f * ((k) >> 1), g0.x, g0.y, \
+                                                    g0.z, g0.w, g1.x, g1.y, feat, idx)
+#if MGS_RASTER_SWITCH == 2
+#define MGS_SB __builtin_amdgcn_sched_barrier(0);      // at most two bodies interleaved (register budget)
+#else
+#define MGS_SB
+#endif
+      switch (m) {
+        case 1: MGS_Q(0); break;
+        case 2: MGS_Q(1); break;
+        case 3: MGS_Q(0); MGS_Q(1); break;
+        case 4: MGS_Q(2); break;
+        case 5: MGS_Q(0); MGS_Q(2); break;
+        case 6: MGS_Q(1); MGS_Q(2); break;
+        case 7: MGS_Q(0); MGS_Q(1); MGS_SB MGS_Q(2); break;
+        case 8: MGS_Q(3); break;
+        case 9: MGS_Q(0); MGS_Q(3); break;
+        case 10: MGS_Q(1); MGS_Q(3); break;
+        case 11: MGS_Q(0); MGS_Q(1); MGS_SB MGS_Q(3); break;
+        case 12: MGS_Q(2); MGS_Q(3); break;
+        case 13: MGS_Q(0); MGS_Q(2); MGS_SB MGS_Q(3); break;
+        case 14: MGS_Q(1); MGS_Q(2); MGS_SB MGS_Q(3); break;
+        case 15: MGS_Q(0); MGS_Q(1); MGS_SB MGS_Q(2); MGS_Q(3); break;
+        default: break;
+      }
+#undef MGS_Q
+#undef MGS_SB
+#else
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (m & (1u << k))
-          blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y,
-                                             g0.z, g0.w, g1.x, g1.y, feat, idx);
+        if (m & (1u << k)) {
+          if constexpr (MGS_RASTER_CMPX && SAFE && !TRACK_LAST && (CHT == 3 || CHT == 4))
+            blend_pixel_safe_asm<CHT>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y, g0.z, g0.w, g1.x,
+                                      g1.y, feat);
+          else
+            blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y,
+                                               g0.z, g0.w, g1.x, g1.y, feat, idx);
+        }
+#endif
     };
     auto walk = [&](auto safe_tag) {
       for (int j = 0; j < count; ++j) {
+#if MGS_RASTER_REFRESH
+        // quadrants that saturated since the batch began stop being evaluated within MGS_RASTER_REFRESH entries
+        // instead of at the end of the 64-entry batch (a finished pixel ignores every later Gaussian anyway)
+        if ((j & (MGS_RASTER_REFRESH - 1)) == MGS_RASTER_REFRESH - 1) {
+          live_now = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (__ballot(st[k].T > 0.f) != 0ull) live_now |= 1u << k;
+          if (live_now == 0) break;
+        }
+#endif
         const QueueEntry<CHT>& e = queue[j];
         const float4 g0 = e.geo0, g1 = e.geo1;
         float4 ef[(CHT + 3) / 4];
@@ -386,11 +502,11 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(
     }
     const unsigned long long keep = __ballot(keep_me);
     const int count = __popcll(keep);
-    const bool all_safe = __ballot(keep_me && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kAlphaMax)) == 0ull;
+    const bool all_safe = __ballot(keep_me && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
     if (keep_me) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
-      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, c_op, 0.f, __int_as_float(c_idx));
+      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, __log2f(c_op), 0.f, __int_as_float(c_idx));
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
         float4 v;
@@ -425,7 +541,10 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(
           if (4 * f + 2 < CHT) feat[4 * f + 2] = v.z;
           if (4 * f + 3 < CHT) feat[4 * f + 3] = v.w;
         }
-        blend_pixel<CHT, TRACK_LAST, SAFE>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
+        if constexpr (MGS_RASTER_CMPX && SAFE && !TRACK_LAST && (CHT == 3 || CHT == 4))
+          blend_pixel_safe_asm<CHT>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat);
+        else
+          blend_pixel<CHT, TRACK_LAST, SAFE>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
       }
       }
     };

@@ -24,7 +24,7 @@ for track in (False, True):
         L.mgs_debug_set_raster_opts(o)
         out = None
         def run():
-            return ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out, track_last=track, splats=splats, expected_last=True)
+            return ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, out=out, track_last=track, splats=splats, expected_last=True, group_order=tl.group_order)
         for _ in range(5): out = run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best = 1e9

@@ -30,7 +30,7 @@ def main():
     torch.cuda.synchronize()
     read(out)
     _, _, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K,
-                               W, H, sh_degree=3, render_mode="RGB")
+                               W, H, sh_degree=3, render_mode="RGB+ED", raster_schedule="throughput")
     torch.cuda.synchronize()
     read(out)
     v = [int(x) for x in out]
