@@ -108,16 +108,16 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
 #ifndef MGS_RASTER_CMPX
 #define MGS_RASTER_CMPX 1
 #endif
-// The SAFE inference blend (3 or 4 channels) as hand-written gfx950 code: the same arithmetic in the same order as
+// The SAFE blend (3 or 4 channels; inference and, with one more select for last_ids, training) as hand-written gfx950 code: the same arithmetic in the same order as
 // blend_pixel<CHT, false, true> -- bit-identical pixels -- with the alpha >= 1/255 test as a v_cmpx that narrows
 // EXEC to the lanes that count instead of a compare plus a select on alpha (a Gaussian that does not count leaves
 // the pixel untouched: with a_eff = 0 the generic form adds 0 and re-selects the T it had).  18 vector
 // instructions per 64 pairs instead of 19, and the ~60 % of lanes that fail the test stay idle for the ten
 // instructions behind it.  gfx940+ needs two wait states between a VALU write of VCC and a VALU read of it, one
 // after a transcendental: filled with independent work where there is some.
-template <int CHT>
+template <int CHT, bool TRACK_LAST>
 __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, float pxf, float pyf, float mx, float my,
-                                                     float A, float B, float C, float L, const float* feat) {
+                                                     float A, float B, float C, float L, const float* feat, int idx) {
   static_assert(CHT == 3 || CHT == 4, "hand-written blend: 3 or 4 channels");
   float dx, dy, t0, t1, nT, w;
   const float amin = kAlphaMin, tstop = kTStop;
@@ -146,12 +146,15 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, float 
       ".if %[four]\n"
       "v_fmac_f32 %[c3], %[w], %[f3]\n"
       ".endif\n"
+      ".if %[track]\n"
+      "v_cndmask_b32 %[last], %[last], %[idx], vcc\n"     // EXEC = valid lanes, VCC = accumulated
+      ".endif\n"
       "s_mov_b64 exec, -1\n"
       : [dx] "=&v"(dx), [dy] "=&v"(dy), [t0] "=&v"(t0), [t1] "=&v"(t1), [nT] "=&v"(nT), [w] "=&v"(w),
-        [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3)
+        [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3), [last] "+v"(px.last)
       : [mx] "v"(mx), [my] "v"(my), [px] "v"(pxf), [py] "v"(pyf), [A] "v"(A), [B] "v"(B), [C] "v"(C), [L] "v"(L),
         [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
-        [four] "n"(CHT == 4 ? 1 : 0)
+        [four] "n"(CHT == 4 ? 1 : 0), [track] "n"(TRACK_LAST ? 1 : 0), [idx] "v"(idx)
       : "vcc");
   if (CHT == 4) px.C[CHT - 1] = c3;
 }
@@ -333,9 +336,9 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (m & (1u << k)) {
-          if constexpr (MGS_RASTER_CMPX && SAFE && !TRACK_LAST && (CHT == 3 || CHT == 4))
-            blend_pixel_safe_asm<CHT>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y, g0.z, g0.w, g1.x,
-                                      g1.y, feat);
+          if constexpr (MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4))
+            blend_pixel_safe_asm<CHT, TRACK_LAST>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y, g0.z,
+                                                  g0.w, g1.x, g1.y, feat, idx);
           else
             blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y,
                                                g0.z, g0.w, g1.x, g1.y, feat, idx);
@@ -541,8 +544,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(
           if (4 * f + 2 < CHT) feat[4 * f + 2] = v.z;
           if (4 * f + 3 < CHT) feat[4 * f + 3] = v.w;
         }
-        if constexpr (MGS_RASTER_CMPX && SAFE && !TRACK_LAST && (CHT == 3 || CHT == 4))
-          blend_pixel_safe_asm<CHT>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat);
+        if constexpr (MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4))
+          blend_pixel_safe_asm<CHT, TRACK_LAST>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
         else
           blend_pixel<CHT, TRACK_LAST, SAFE>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
       }
