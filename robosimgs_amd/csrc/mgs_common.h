@@ -40,6 +40,26 @@ __device__ __forceinline__ unsigned mask_rank(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
+// wave-wide OR / AND / sum of one 32-bit value per lane, returned wave-uniform.  Six DPP steps (quad_perm x2,
+// row_half_mirror, row_mirror, row_bcast15, row_bcast31: the total lands in lane 63) and a readlane, instead of six
+// ds_bpermute round trips with their lane-index arithmetic (__shfl_xor).
+#define MGS_DPP_STEP(OP, IDENT, CTRL, RMASK) \
+  v = v OP (uint32_t)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, CTRL, RMASK, 0xf, false);
+#define MGS_WAVE_REDUCE(NAME, OP, IDENT)                                         \
+  __device__ __forceinline__ uint32_t NAME(uint32_t v) {                         \
+    MGS_DPP_STEP(OP, IDENT, 0xB1, 0xf)                                           \
+    MGS_DPP_STEP(OP, IDENT, 0x4E, 0xf)                                           \
+    MGS_DPP_STEP(OP, IDENT, 0x141, 0xf)                                          \
+    MGS_DPP_STEP(OP, IDENT, 0x140, 0xf)                                          \
+    MGS_DPP_STEP(OP, IDENT, 0x142, 0xa)                                          \
+    MGS_DPP_STEP(OP, IDENT, 0x143, 0xc)                                          \
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);                      \
+  }
+MGS_WAVE_REDUCE(wave_or, |, 0u)
+MGS_WAVE_REDUCE(wave_and, &, ~0u)
+MGS_WAVE_REDUCE(wave_sum_u32, +, 0u)
+#undef MGS_WAVE_REDUCE
+#undef MGS_DPP_STEP
 #endif
 
 // ---- internal launchers shared between translation units ---------------------------------

@@ -12,6 +12,8 @@
 //   * atomics (mgs_rasterize_bwd, for externally supplied tile lists): plain DPP reduction to
 //     lane 63, one hardware float atomic per component.  Scattered device atomics sustain only
 //     ~25-30 G/s on MI355X, which made this variant 1.38 ms against 0.78 ms for the records.
+#include <type_traits>
+
 #include "raster_common.h"
 #include "tile_order.h"
 
@@ -52,7 +54,10 @@ struct GaussGrad {
 //     conic is constant per Gaussian, so only S0 = sum p and S1 = sum q are accumulated (v_x,
 //     v_y) and the CONSUMER applies the conic once per Gaussian (finish_geo below); likewise
 //     v_ca / v_cc hold twice the conic gradient until then.
-template <int CHT, bool ABSGRAD>
+// SAFE (chosen per 64-entry batch, as in the forward): every queued Gaussian has a conic that cannot round sigma
+// below zero and an opacity <= kSafeOpacity, so the sigma test and the 0.999 clamp are dead -- alpha = ov, nothing is
+// ever clamped, one select serves a_eff and ov_eff.  Same values bit for bit, six vector instructions less.
+template <int CHT, bool ABSGRAD, bool SAFE = false>
 __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, float pxf,
                                            float pyf, float mx, float my, float ca, float cb,
                                            float cc, float A, float B, float C, float L,
@@ -61,12 +66,13 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   // the forward's own evaluation (raster_fwd.hip blend_pixel, raster_common.h pair_power), bit for bit:
   // ov = opacity * exp(-sigma) as one exp2 with log2(opacity) folded into the exponent
   float ov = __builtin_amdgcn_exp2f(pair_power(dx, dy, A, B, C, L));
-  float alpha = fminf(kAlphaMax, ov);
-  bool valid = idx <= px.last && pair_power_sign(dx, dy, A, B, C) <= 0.f && alpha >= kAlphaMin;
+  float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
+  bool valid = idx <= px.last && alpha >= kAlphaMin;
+  if (!SAFE) valid = valid && pair_power_sign(dx, dy, A, B, C) <= 0.f;
   if (__ballot(valid) == 0ull) return false;
   float a_eff = valid ? alpha : 0.f;                       // 0 => T, bv and v_f stay untouched
   bool grad_geo = valid && ov <= kAlphaMax;                // alpha not clamped: sigma/opacity get grads
-  float ov_eff = grad_geo ? ov : 0.f;
+  float ov_eff = SAFE ? a_eff : (grad_geo ? ov : 0.f);
   float ra = __builtin_amdgcn_rcpf(1.0f - a_eff);          // v_rcp_f32; an IEEE divide is 11 instructions
   px.T *= ra;
   float fac = a_eff * px.T;
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     }
     const unsigned long long keep = __ballot(qmask != 0u);
     const int count = __popcll(keep);
+    const bool all_safe = __ballot(qmask != 0u && !(sigma_sign_is_safe(ca, cb, cc) && op <= kSafeOpacity)) == 0ull;
     if (qmask != 0u) {
       BwdEntry<CHT>& e = queue[mask_rank(keep)];
       e.geo0 = make_float4(xy.x, xy.y, ca, cb);
@@ -315,6 +322,8 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    auto walk = [&](auto safe_tag) {
+    constexpr bool SAFE = decltype(safe_tag)::value;
     for (int j = count - 1; j >= 0; --j) {
       const BwdEntry<CHT>& e = queue[j];
       const float4 g0 = e.geo0, g1 = e.geo1, g2 = e.geo2;
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         if (m & (1u << k))
-          any |= grad_pixel<CHT, ABSGRAD>(st[k], gg, px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1),
+          any |= grad_pixel<CHT, ABSGRAD, SAFE>(st[k], gg, px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1),
                                           g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, g2.z, g2.w, g1.y, feat, gi);
       }
       if (PIPE && pend) {
@@ -455,6 +464,12 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         }
       }
     }
+    };
+#ifdef MGS_RASTER_BWD_NO_SAFE     // measurement: every batch through the general form
+    walk(std::false_type{});
+#else
+    if (all_safe) walk(std::true_type{}); else walk(std::false_type{});
+#endif
     __builtin_amdgcn_wave_barrier();
   }
   if (PIPE && pend) {

@@ -27,9 +27,15 @@ namespace mgs {
 namespace {
 
 constexpr int kTS = 256;            // threads per tile
-constexpr int kBuckets = 1024;
+// buckets of one MSD level
+constexpr int buckets_for(int) { return 1024; }   // (256 for the short-list variant: fewer counters to zero / scan, but ~2 entries per
+                                                  //  bucket make the wave's rank loop as long as its fullest bucket: 22.6 M VALU against 21.8 M)
+constexpr int log2i(int v) { return v <= 1 ? 0 : 1 + log2i(v >> 1); }
 constexpr int kSmall = 48;          // buckets up to this size are finished by rank counting
 constexpr int kStack = 96;          // pending heavy buckets; beyond it a bucket is rank-counted whatever its size
+#ifndef MGS_TSORT_STOP
+#define MGS_TSORT_STOP 0      // measurement only: leave the kernel after phase 1..4 (filter / keys / scan / scatter)
+#endif
 #ifndef MGS_TSORT_FAST
 #define MGS_TSORT_FAST 2048
 #endif
@@ -50,12 +56,18 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // exclusive scan of one value per thread over the workgroup; *total = sum
 __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // inclusive scan over the wave in six DPP adds: row_shr 1 / 2 / 4 / 8 inside the rows of 16 (zero fill), then lane 15
+  // of rows 0 / 2 onto rows 1 / 3 and lane 31 onto rows 2 and 3
   uint32_t incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(incl, d);
-    if (lane >= (unsigned)d) incl += t;
-  }
+#define MGS_SCAN_STEP(CTRL, RMASK, BOUND) \
+  incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, CTRL, RMASK, 0xf, BOUND);
+  MGS_SCAN_STEP(0x111, 0xf, true)
+  MGS_SCAN_STEP(0x112, 0xf, true)
+  MGS_SCAN_STEP(0x114, 0xf, true)
+  MGS_SCAN_STEP(0x118, 0xf, true)
+  MGS_SCAN_STEP(0x142, 0xa, false)
+  MGS_SCAN_STEP(0x143, 0xc, false)
+#undef MGS_SCAN_STEP
   if (lane == 63) wave_sums[wave] = incl;
   __syncthreads();
   uint32_t off = 0, tot = 0;
@@ -79,15 +91,21 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
     uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
     uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out) {
+  constexpr int kBuckets = buckets_for(kFast), kDigitBits = log2i(kBuckets);
   __shared__ uint32_t cnt[kBuckets];
   __shared__ uint32_t cur[kBuckets];
   __shared__ unsigned long long red_min[kTS / 64], red_max[kTS / 64];
+  __shared__ uint32_t red_or[kTS / 64], red_and[kTS / 64];
   __shared__ uint32_t wave_sums[kTS / 64];
   __shared__ int stack_lo[kStack], stack_hi[kStack];
   __shared__ uint8_t stack_src[kStack];
   __shared__ int stack_n;
   constexpr int kItems = kFast / kTS;
-  __shared__ uint32_t lk[kFast], li[kFast];
+  // the tile's list in LDS: first its ids (li, written by the group filter), later -- the ids are in registers by then,
+  // two barriers earlier -- the scattered composites {id, depth bits} as one 64-bit word each (lc), so that the rank loop
+  // reads one ds_read_b64 and makes one 64-bit compare per candidate
+  __shared__ unsigned long long lc[kFast];
+  uint32_t* li = reinterpret_cast<uint32_t*>(lc);
   const int tile = blockIdx.x;
   if (tile >= n_tiles) return;
   const int tid = threadIdx.x;
@@ -110,25 +128,30 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
         const int i = i0 + j * kTS + tid;
         vv[j] = i < ge ? staging[i] : 0u;
       }
+      // the wave's matches of the whole trip take ONE LDS atomic: per item a ballot and a running count
+      unsigned long long mm[kInFlight];
+      uint32_t run[kInFlight], wave_total = 0;
 #pragma unroll
       for (int j = 0; j < kInFlight; ++j) {
         const int i = i0 + j * kTS + tid;
-        if (i0 + j * kTS >= ge) continue;               // uniform
-        const uint32_t v = vv[j], l = v >> (32 - shift);
-        below += (i < ge && l < local) ? 1u : 0u;
-        const bool mine = i < ge && l == local;
-        const unsigned long long m = __ballot(mine);
-        uint32_t base = 0;
-        if ((tid & 63) == 0 && m) base = atomicAdd(&gcount[1], (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (mine) {
-          const uint32_t pos = base + mask_rank(m);
-          if (pos < (uint32_t)kFast) li[pos] = v & id_mask;
+        const uint32_t l = vv[j] >> (32 - shift);
+        const bool in = i < ge;                          // (items past the segment: vv = 0 and in = false)
+        below += (uint32_t)__popcll(__ballot(in && l < local));      // wave-uniform: scalar popcounts, no lane sums
+        mm[j] = __ballot(in && l == local);
+        run[j] = wave_total;
+        wave_total += (uint32_t)__popcll(mm[j]);
+      }
+      uint32_t base = 0;
+      if ((tid & 63) == 0 && wave_total) base = atomicAdd(&gcount[1], wave_total);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int j = 0; j < kInFlight; ++j) {
+        if ((mm[j] >> (tid & 63)) & 1ull) {
+          const uint32_t pos = base + run[j] + mask_rank(mm[j]);
+          if (pos < (uint32_t)kFast) li[pos] = vv[j] & id_mask;
         }
       }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
     if ((tid & 63) == 0 && below) atomicAdd(&gcount[0], below);
     __syncthreads();
     s = gs + (int)gcount[0];
@@ -140,6 +163,9 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
   } else {
     s = offsets[tile]; e = offsets[tile + 1];
   }
+#if MGS_TSORT_STOP == 1
+  return;
+#endif
   if (tile_ids)
     for (int i = s + tid; i < e; i += kTS) tile_ids[i] = (uint32_t)tile;
   if (e - s <= 1) {
@@ -153,45 +179,68 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     uint32_t rk[kItems], ri[kItems];
     // (every item loop below stops, wave-uniformly, at the first item no thread of the workgroup owns:
     //  a 455-entry list executes two of the eight unrolled trips)
+    // (no per-lane branches around the loads: the id of a slot past the end is the list's last one, masked out
+    //  below -- a branch per slot made the compiler wait for every gather before issuing the next)
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       ri[it] = 0u;
       if (it * kTS >= n) continue;
-      const int idx = it * kTS + tid;
-      ri[it] = idx < n ? (GROUPED ? li[idx] : ids_final[s + idx]) : 0u;
+      const int idx = min(it * kTS + tid, n - 1);
+      ri[it] = GROUPED ? li[idx] : ids_final[s + idx];
     }
-    unsigned long long mn = ~0ull, mx = 0ull;
+    // highest bit in which two composites (depth bits << 32 | id) differ: the bits where the depth keys are not
+    // all alike are OR & ~AND over the list (32-bit reductions); only a list of identical depths looks at the ids
+    uint32_t kor = 0u, kand = ~0u;
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       const int idx = it * kTS + tid;
       rk[it] = 0u;
       if (it * kTS >= n) continue;
-      if (idx < n) {
-        rk[it] = __float_as_uint(depths[ri[it]]);
-        const unsigned long long c = ((unsigned long long)rk[it] << 32) | ri[it];
-        mn = c < mn ? c : mn;
-        mx = c > mx ? c : mx;
-      }
+      rk[it] = __float_as_uint(depths[ri[it]]);
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const unsigned long long a = shfl_xor_u64(mn, d), b = shfl_xor_u64(mx, d);
-      mn = a < mn ? a : mn;
-      mx = b > mx ? b : mx;
+    for (int it = 0; it < kItems; ++it) {
+      if (it * kTS >= n) continue;
+      const bool in = it * kTS + tid < n;
+      kor |= in ? rk[it] : 0u;
+      kand &= in ? rk[it] : ~0u;
     }
-    if ((tid & 63) == 0) { red_min[tid >> 6] = mn; red_max[tid >> 6] = mx; }
+    kor = wave_or(kor);
+    kand = wave_and(kand);
+    if ((tid & 63) == 0) { red_or[tid >> 6] = kor; red_and[tid >> 6] = kand; }
 #pragma unroll
     for (int k = 0; k < kBuckets / kTS; ++k) cnt[tid + k * kTS] = 0;
     if (tid == 0) stack_n = 0;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < kTS / 64; ++w) {
-      mn = red_min[w] < mn ? red_min[w] : mn;
-      mx = red_max[w] > mx ? red_max[w] : mx;
+    for (int w = 0; w < kTS / 64; ++w) { kor |= red_or[w]; kand &= red_and[w]; }
+    int hb;
+    if (kor != kand) {                                      // uniform
+      hb = 32 + (31 - __clz((int)(kor ^ kand)));
+    } else {                                                // all depths identical: the ids decide (distinct: n >= 2)
+      uint32_t ior = 0u, iand = ~0u;
+#pragma unroll
+      for (int it = 0; it < kItems; ++it)
+        if (it * kTS + tid < n) { ior |= ri[it]; iand &= ri[it]; }
+      ior = wave_or(ior);
+      iand = wave_and(iand);
+      __syncthreads();
+      if ((tid & 63) == 0) { red_or[tid >> 6] = ior; red_and[tid >> 6] = iand; }
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < kTS / 64; ++w) { ior |= red_or[w]; iand &= red_and[w]; }
+      hb = 31 - __clz((int)(ior ^ iand));
     }
-    const int hb = 63 - __clzll((long long)(mn ^ mx));
-    const int shift = hb > 9 ? hb - 9 : 0;
+#if MGS_TSORT_STOP == 2
+    if (hb >= 0) { if (tid == 0) ids_final[s] = (uint32_t)hb; return; }
+#endif
+    const int shift = hb > kDigitBits - 1 ? hb - (kDigitBits - 1) : 0;
+    // shift >= 32 (the depths differ above their lowest kDigitBits - 1 bits: nearly always): the digit is a bit
+    // field of the 32-bit key
+    const bool key_digit = shift >= 32;
+    const int kshift = shift - 32;
     auto digit = [&](uint32_t k, uint32_t id) -> unsigned {
+      if (key_digit) return (k >> kshift) & (kBuckets - 1);
       const unsigned long long c = ((unsigned long long)k << 32) | id;
       return (unsigned)(c >> shift) & (kBuckets - 1);
     };
@@ -231,22 +280,28 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
       if (tid == 0) stack_n = (int)htot < kStack ? (int)htot : kStack;
     }
     __syncthreads();
+#if MGS_TSORT_STOP == 3
+    if (n > 0) { if (tid == 0) ids_final[s] = cur[3]; return; }
+#endif
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       if (it * kTS >= n) continue;
       if (it * kTS + tid < n) {
         const uint32_t p = atomicAdd(&cur[digit(rk[it], ri[it])], 1u);
-        lk[p] = rk[it];
-        li[p] = ri[it];
+        lc[p] = ((unsigned long long)rk[it] << 32) | ri[it];
       }
     }
     __syncthreads();
+#if MGS_TSORT_STOP == 4
+    if (n > 0) { if (tid == 0) ids_final[s] = (uint32_t)lc[3]; return; }
+#endif
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       const int i = it * kTS + tid;
       if (it * kTS >= n) continue;
       if (i < n) {
-        const uint32_t k = lk[i], id = li[i];
+        const unsigned long long me = lc[i];
+        const uint32_t k = (uint32_t)(me >> 32), id = (uint32_t)me;
         const unsigned d = digit(k, id);
         const uint32_t craw = cnt[d];
         const uint32_t b = craw & ~kBrute;
@@ -256,7 +311,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
         } else {
           const int be = (int)cur[d], bs = be - (int)b;
           int c = 0;
-          for (int j = bs; j < be; ++j) c += comp_less(lk[j], li[j], k, id) ? 1 : 0;
+          for (int j = bs; j < be; ++j) c += lc[j] < me ? 1 : 0;
           ids_final[s + bs + c] = id;
         }
       }
@@ -343,7 +398,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
       mx = red_max[w] > mx ? red_max[w] : mx;
     }
     const int hb = 63 - __clzll((long long)(mn ^ mx));       // composites are distinct: mn != mx
-    const int shift = hb > 9 ? hb - 9 : 0;
+    const int shift = hb > kDigitBits - 1 ? hb - (kDigitBits - 1) : 0;
     auto digit = [&](uint32_t k, uint32_t id) -> unsigned {
       const unsigned long long c = ((unsigned long long)k << 32) | id;
       return (unsigned)(c >> shift) & (kBuckets - 1);

@@ -15,12 +15,18 @@ t = g.to_torch(dev, deg)
 vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)
 K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)
 tw, th = -(-W // 16), -(-H // 16)
-def project():
-    return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, CH == 4, want_splats=True)
+def project(lean=False):
+    # lean = the inference-frame form bench.py's frames run: splats + binning seed + depths only
+    return ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, CH == 4, want_splats=True,
+                                     bin_seed=("tight" if os.environ.get("TIGHT", "1") != "0" else "classic") if lean else None, lean=lean)
 radii, m2d, dep, con, _, feats, splats = project()
 TIGHT = os.environ.get("TIGHT", "1") != "0"      # tightened tile rectangles (the render path's default)
 tkw = dict(conics=con, opacities=t["opacities"]) if TIGHT else {}
 tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 else 8_000_000, want_tiles_per_gauss=False, want_pair_info=True, **tkw)
+# the list capacity bench.py gives its frames (it decides which instantiation of the per-tile sort runs)
+CAP = int(os.environ.get("CAP", int(int(tl.n_isect) * 1.25) + 4096))
+tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, CAP, want_tiles_per_gauss=False, want_pair_info=True, **tkw)
+seed = project(lean=True)[-1]
 out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats)
 torch.cuda.synchronize()
 print("n_isect", int(tl.n_isect))
@@ -39,10 +45,13 @@ for _ in range(reps):
     elif stage == "train":
         from robosimgs_amd.rendering import rasterization
         ps = {k: t[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
-        c, a_, _ = rasterization(ps["means"], ps["quats"], ps["scales"], ps["opacities"], ps["colors"], vm[None], K[None], W, H, sh_degree=deg, isect_capacity=8_000_000, tile_bounds="tight" if TIGHT else "classic")
+        c, a_, _ = rasterization(ps["means"], ps["quats"], ps["scales"], ps["opacities"], ps["colors"], vm[None], K[None], W, H, sh_degree=deg, isect_capacity=CAP, tile_bounds="tight" if TIGHT else "classic")
         (c - vr[None, ..., :3]).abs().mean().backward()
     elif stage == "binning":
-        ops.isect_tiles_raw(m2d, radii, dep, tw, th, 8_000_000, want_tiles_per_gauss=False, **tkw)
+        # seeded by the projection kernel, no tile ids: what a frame runs (the seed's sums are scanned in place:
+        # restore them first)
+        seed = project(lean=True)[-1]
+        ops.isect_tiles_raw(None, None, dep, tw, th, CAP, want_tiles_per_gauss=False, seed=seed, want_tile_ids=False)
     elif stage == "project":
-        project()
+        project(lean=True)
 torch.cuda.synchronize()
