@@ -11,8 +11,10 @@
 #include "tile_order.h"
 
 #ifndef MGS_RASTER_WAVES
-// min waves per SIMD asked of the register allocator; 8 / 6 / 5 spill and lose (profiles/r1/05)
-#define MGS_RASTER_WAVES 4
+// min waves per SIMD asked of the register allocator (one-wave-per-tile kernel).  5 = at most 96 VGPRs: with the
+// hand-written blend body the 4-channel kernels sat at 106-107 registers (4 waves) -- at 5 the same box renders
+// 3,818 instead of 3,674 frames/s with three frames in flight (189.5 vs 191.6 us alone); 6 (80 VGPRs) spills: 3,571
+#define MGS_RASTER_WAVES 5
 #endif
 #ifndef MGS_RASTER_REFRESH
 // one-wave-per-tile kernel: re-derive the live quadrants every this many queue entries (power of two; 0 = per batch only,
@@ -119,7 +121,7 @@ template <int CHT, bool TRACK_LAST>
 __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, float pxf, float pyf, float mx, float my,
                                                      float A, float B, float C, float L, const float* feat, int idx) {
   static_assert(CHT == 3 || CHT == 4, "hand-written blend: 3 or 4 channels");
-  float dx, dy, t0, t1, nT, w;
+  float dx, dy, t0, t1;           // dx doubles as the weight w, t0 as T (1 - alpha): four temporaries per body
   const float amin = kAlphaMin, tstop = kTStop;
   float c3 = CHT == 4 ? px.C[CHT - 1] : 0.f;
   const float f3 = CHT == 4 ? feat[CHT - 1] : 0.f;
@@ -134,23 +136,23 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, float 
       "v_exp_f32 %[t1], %[t1]\n"
       "s_nop 0\n"
       "v_cmpx_le_f32 vcc, %[amin], %[t1]\n"
-      "v_fma_f32 %[nT], -%[t1], %[T], %[T]\n"
-      "v_mul_f32 %[w], %[t1], %[T]\n"
-      "v_cmp_lt_f32 vcc, %[tstop], %[nT]\n"
+      "v_fma_f32 %[t0], -%[t1], %[T], %[T]\n"
+      "v_mul_f32 %[dx], %[t1], %[T]\n"
+      "v_cmp_lt_f32 vcc, %[tstop], %[t0]\n"
       "s_nop 1\n"
-      "v_cndmask_b32 %[w], 0, %[w], vcc\n"
-      "v_cndmask_b32_e64 %[T], -|%[T]|, %[nT], vcc\n"
-      "v_fmac_f32 %[c0], %[w], %[f0]\n"
-      "v_fmac_f32 %[c1], %[w], %[f1]\n"
-      "v_fmac_f32 %[c2], %[w], %[f2]\n"
+      "v_cndmask_b32 %[dx], 0, %[dx], vcc\n"
+      "v_cndmask_b32_e64 %[T], -|%[T]|, %[t0], vcc\n"
+      "v_fmac_f32 %[c0], %[dx], %[f0]\n"
+      "v_fmac_f32 %[c1], %[dx], %[f1]\n"
+      "v_fmac_f32 %[c2], %[dx], %[f2]\n"
       ".if %[four]\n"
-      "v_fmac_f32 %[c3], %[w], %[f3]\n"
+      "v_fmac_f32 %[c3], %[dx], %[f3]\n"
       ".endif\n"
       ".if %[track]\n"
       "v_cndmask_b32 %[last], %[last], %[idx], vcc\n"     // EXEC = valid lanes, VCC = accumulated
       ".endif\n"
       "s_mov_b64 exec, -1\n"
-      : [dx] "=&v"(dx), [dy] "=&v"(dy), [t0] "=&v"(t0), [t1] "=&v"(t1), [nT] "=&v"(nT), [w] "=&v"(w),
+      : [dx] "=&v"(dx), [dy] "=&v"(dy), [t0] "=&v"(t0), [t1] "=&v"(t1),
         [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3), [last] "+v"(px.last)
       : [mx] "v"(mx), [my] "v"(my), [px] "v"(pxf), [py] "v"(pyf), [A] "v"(A), [B] "v"(B), [C] "v"(C), [L] "v"(L),
         [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 // The price is that the list is fetched and culled by each of the four waves (L2 hits) and that the
 // pixel offset (2 subtractions) is paid per evaluation instead of per queue entry.
 template <int CHT, bool TRACK_LAST>
-__global__ __launch_bounds__(256) void raster_fwd_q_kernel(
+__global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64 VGPRs / 8 waves per SIMD: 166-172 -> 182 us, left free: 66)
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
