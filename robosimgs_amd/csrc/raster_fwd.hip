@@ -21,6 +21,10 @@
 // the default: 8 / 16 / 32 measured 205.8 / 204.9 / 206.3 us against 201.4 without, profiles/r3/00_experiments.md)
 #define MGS_RASTER_REFRESH 0
 #endif
+#ifndef MGS_RASTER_NO_PREFETCH
+#define MGS_RASTER_NO_PREFETCH 1     // 1: the one-wave-per-tile kernel fetches a batch when it needs it instead of one batch ahead (ten
+                                     // registers live across the walk less): 188.2 -> 186.2 us alone, 3,819 -> 3,866 frames/s; 0 = prefetch
+#endif
 #ifndef MGS_RASTER_SWITCH
 // 1 / 2: one straight-line body per quadrant set (switch on the entry's mask) so that the scheduler can interleave the
 // quadrants' chains -- measured 268-278 us against 197 for the four scalar-branched bodies (109 VGPRs, copies
@@ -247,6 +251,9 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     if (live == 0) break;
 
     // take the prefetched batch, start the next one
+#if MGS_RASTER_NO_PREFETCH
+    if (b != start) { r_idx = b + (int)lane; r_ok = r_idx < end; fetch(r_idx, r_ok); }
+#endif
     const int c_idx = r_idx;
     const bool c_ok = r_ok;
     const float2 c_xy = r_xy;
@@ -254,9 +261,11 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     float c_feat[CHT];
 #pragma unroll
     for (int c = 0; c < CHT; ++c) c_feat[c] = r_feat[c];
+#if !MGS_RASTER_NO_PREFETCH
     r_idx = b + kQueue + (int)lane;
     r_ok = r_idx < end;
     fetch(r_idx, r_ok);
+#endif
 
     unsigned qmask = 0;
     if (c_ok) qmask = (cull ? quadrant_mask(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, c_op, tile_x, tile_y) : 0xfu) & live;
