@@ -22,8 +22,9 @@ namespace {
 
 template <int CHT>
 struct BwdEntry {
-  float4 geo0;                       // mean.x, mean.y, conic.a, conic.b
+  float4 geo0;                       // mean - tile centre (x, y), conic.a, conic.b
   float4 geo1;                       // conic.c, L = log2(opacity), quadrant mask (bits), list index (bits)
+  float4 geo3;                       // q0, q1, q2 of the exponent's polynomial about the tile centre (raster_common.h)
   float4 feat[(CHT + 3) / 4];
   float4 geo2;                       // record slot / Gaussian id (bits), then the conic pre-scaled for exp2:
 };                                   //   A = -0.5 log2e a, B = -log2e b, C = -0.5 log2e c
@@ -58,14 +59,15 @@ struct GaussGrad {
 // below zero and an opacity <= kSafeOpacity, so the sigma test and the 0.999 clamp are dead -- alpha = ov, nothing is
 // ever clamped, one select serves a_eff and ov_eff.  Same values bit for bit, six vector instructions less.
 template <int CHT, bool ABSGRAD, bool SAFE = false>
-__device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, float pxf,
-                                           float pyf, float mx, float my, float ca, float cb,
-                                           float cc, float A, float B, float C, float L,
+__device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, const PixelPoly& pp,
+                                           float mx, float my, float ca, float cb,
+                                           float cc, float A, float B, float C, float q0, float q1, float q2,
                                            const float* feat, int idx) {
-  float dx = mx - pxf, dy = my - pyf;
-  // the forward's own evaluation (raster_fwd.hip blend_pixel, raster_common.h pair_power), bit for bit:
-  // ov = opacity * exp(-sigma) as one exp2 with log2(opacity) folded into the exponent
-  float ov = __builtin_amdgcn_exp2f(pair_power(dx, dy, A, B, C, L));
+  // mx, my: the mean's offset from the tile centre; pp: the pixel's (raster_common.h)
+  float dx = mx - pp.x, dy = my - pp.y;
+  // the forward's own evaluation (raster_fwd.hip blend_pixel, raster_common.h pair_power_poly), bit for bit:
+  // ov = opacity * exp(-sigma) as one exp2 of the exponent's polynomial about the tile centre
+  float ov = __builtin_amdgcn_exp2f(pair_power_poly(pp, q0, q1, q2, A, B, C));
   float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
   bool valid = idx <= px.last && alpha >= kAlphaMin;
   if (!SAFE) valid = valid && pair_power_sign(dx, dy, A, B, C) <= 0.f;
@@ -173,7 +175,11 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
   //  LDS wait inside it into a wait for everything -- scalar loads return out of order)
   if (RECORDS && capacity == 0u) return;
   const int ix = tx * 16 + (int)(lane & 7), iy = ty * 16 + 8 * half + (int)(lane >> 3);
-  const float px0 = (float)ix + 0.5f, py0 = (float)iy + 0.5f;
+  // this lane's pixels as offsets from the tile centre, with their products (raster_common.h: PixelPoly)
+  PixelPoly pq[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k)
+    pq[k] = pixel_poly((float)(lane & 7) - 7.5f + 8.f * (k & 1), (float)(8 * half + (int)(lane >> 3)) - 7.5f + 8.f * (k >> 1));
 
   BwdPixel<CHT> st[NQ];
   int hi = -1;
@@ -301,15 +307,19 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     const bool all_safe = __ballot(qmask != 0u && !(sigma_sign_is_safe(ca, cb, cc) && op <= kSafeOpacity)) == 0ull;
     if (qmask != 0u) {
       BwdEntry<CHT>& e = queue[mask_rank(keep)];
-      e.geo0 = make_float4(xy.x, xy.y, ca, cb);
-      e.geo1 = make_float4(cc, __log2f(op), __uint_as_float(qmask), __int_as_float(idx));
+      constexpr float kLog2e = 1.4426950408889634f;
+      const float sA = -0.5f * kLog2e * ca, sB = -kLog2e * cb, sC = -0.5f * kLog2e * cc, L = __log2f(op);
+      const float m_x = xy.x - (tile_x + 8.f), m_y = xy.y - (tile_y + 8.f);
+      const PolyCoef pc = poly_coefs(m_x, m_y, sA, sB, sC, L);
+      e.geo0 = make_float4(m_x, m_y, ca, cb);
+      e.geo1 = make_float4(cc, L, __uint_as_float(qmask), __int_as_float(idx));
+      e.geo3 = make_float4(pc.q0, pc.q1, pc.q2, 0.f);
       int gid = g;
       if (RECORDS) {
         const int4 info = pair_info[g];
         gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
       }
-      constexpr float kLog2e = 1.4426950408889634f;
-      e.geo2 = make_float4(__int_as_float(gid), -0.5f * kLog2e * ca, -kLog2e * cb, -0.5f * kLog2e * cc);
+      e.geo2 = make_float4(__int_as_float(gid), sA, sB, sC);
       float f[((CHT + 3) / 4) * 4];
 #pragma unroll
       for (int c = 0; c < ((CHT + 3) / 4) * 4; ++c)
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     constexpr bool SAFE = decltype(safe_tag)::value;
     for (int j = count - 1; j >= 0; --j) {
       const BwdEntry<CHT>& e = queue[j];
-      const float4 g0 = e.geo0, g1 = e.geo1, g2 = e.geo2;
+      const float4 g0 = e.geo0, g1 = e.geo1, g2 = e.geo2, g3 = e.geo3;
       float feat[CHT];
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
@@ -352,8 +362,8 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         if (m & (1u << k))
-          any |= grad_pixel<CHT, ABSGRAD, SAFE>(st[k], gg, px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1),
-                                          g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, g2.z, g2.w, g1.y, feat, gi);
+          any |= grad_pixel<CHT, ABSGRAD, SAFE>(st[k], gg, pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, g2.z, g2.w,
+                                                g3.x, g3.y, g3.z, feat, gi);
       }
       if (PIPE && pend) {
         red_finish(pend_slot, pa0, pb0, pa1, pb1);

@@ -16,20 +16,16 @@
 // 3,818 instead of 3,674 frames/s with three frames in flight (189.5 vs 191.6 us alone); 6 (80 VGPRs) spills: 3,571
 #define MGS_RASTER_WAVES 5
 #endif
-#ifndef MGS_RASTER_REFRESH
-// one-wave-per-tile kernel: re-derive the live quadrants every this many queue entries (power of two; 0 = per batch only,
-// the default: 8 / 16 / 32 measured 205.8 / 204.9 / 206.3 us against 201.4 without, profiles/r3/00_experiments.md)
-#define MGS_RASTER_REFRESH 0
+#ifndef MGS_RASTER_PIPE
+// 1: the one-wave-per-tile kernel reads queue entry j + 1 from LDS while it blends entry j (two register sets in turn).
+// PMC has the waves parked on s_waitcnt for 39 % of their cycles, but both forms of the prefetch lose: 249 us (copies
+// between the sets) / 214 us (ping-pong) against 188 us -- 30 more dwords spilled around the cull at the 96-register
+// bound, and the read-ahead does not shorten the entry's own dependency chain.  Off.
+#define MGS_RASTER_PIPE 0
 #endif
 #ifndef MGS_RASTER_NO_PREFETCH
 #define MGS_RASTER_NO_PREFETCH 1     // 1: the one-wave-per-tile kernel fetches a batch when it needs it instead of one batch ahead (ten
                                      // registers live across the walk less): 188.2 -> 186.2 us alone, 3,819 -> 3,866 frames/s; 0 = prefetch
-#endif
-#ifndef MGS_RASTER_SWITCH
-// 1 / 2: one straight-line body per quadrant set (switch on the entry's mask) so that the scheduler can interleave the
-// quadrants' chains -- measured 268-278 us against 197 for the four scalar-branched bodies (109 VGPRs, copies
-// between the fifteen paths): off
-#define MGS_RASTER_SWITCH 0
 #endif
 #ifndef MGS_RASTER_WG_WAVES
 // Independent tiles (waves) per workgroup of the INFERENCE variant; no workgroup barrier is ever
@@ -46,9 +42,10 @@ namespace {
 
 template <int CHT>
 struct QueueEntry {
-  float4 geo0;                       // mean.x, mean.y, A, B   (A,B,C: conic pre-scaled, below)
-  float4 geo1;                       // C, L = log2(opacity), quadrant mask (bits), list index (bits)
+  float4 geo0;                       // q0, q1, q2, A   (raster_common.h: poly_coefs; A,B,C: conic pre-scaled)
+  float4 geo1;                       // B, C, quadrant mask (bits), list index (bits)
   float4 feat[(CHT + 3) / 4];
+  float4 geo3;                       // mean - tile centre (x, y): read only by batches that test sigma >= 0
 };
 
 // Per-pixel state.  T > 0: transmittance, pixel still open.  T < 0: pixel finished, |T| is its
@@ -84,15 +81,15 @@ __device__ unsigned long long g_raster_stats[8];
 // TRACK_LAST: record the list index of the last blended Gaussian (the backward starts there);
 // an inference render drops that select (compares / selects issue at half the FMA rate on gfx950).
 template <int CHT, bool TRACK_LAST, bool SAFE = false>
-__device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, float pyf, float mx,
-                                            float my, float A, float B, float C, float L,
+__device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, const PixelPoly& pp, float q0, float q1,
+                                            float q2, float A, float B, float C, float m_x, float m_y,
                                             const float* feat, int idx) {
-  float dx = mx - pxf, dy = my - pyf;
   // SAFE: the conic cannot round sigma below zero (sigma_sign_is_safe) and opacity <= kSafeOpacity: the sigma test
   // is dead and exp2(power) <= opacity (1 + 2^-22) < 0.999, so the clamp is the identity too
-  const float ov = __builtin_amdgcn_exp2f(pair_power(dx, dy, A, B, C, L));      // the backward repeats it bit for bit
+  const float ov = __builtin_amdgcn_exp2f(pair_power_poly(pp, q0, q1, q2, A, B, C));   // the backward repeats it bit for bit
   float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
-  bool valid = SAFE ? alpha >= kAlphaMin : (pair_power_sign(dx, dy, A, B, C) <= 0.f && alpha >= kAlphaMin);
+  bool valid = alpha >= kAlphaMin;
+  if (!SAFE) valid = valid && pair_power_sign(m_x - pp.x, m_y - pp.y, A, B, C) <= 0.f;
   // alpha forced to 0 where the Gaussian does not count: an open pixel (T > 1e-4 by invariant)
   // then keeps T and adds nothing, with no second mask to combine
   float a_eff = valid ? alpha : 0.f;
@@ -118,25 +115,23 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, float pxf, floa
 // blend_pixel<CHT, false, true> -- bit-identical pixels -- with the alpha >= 1/255 test as a v_cmpx that narrows
 // EXEC to the lanes that count instead of a compare plus a select on alpha (a Gaussian that does not count leaves
 // the pixel untouched: with a_eff = 0 the generic form adds 0 and re-selects the T it had).  18 vector
-// instructions per 64 pairs instead of 19, and the ~60 % of lanes that fail the test stay idle for the ten
+// instructions per 64 pairs instead of 17 (16 = 5 exponent + exp + 10), and the ~60 % of lanes that fail the test stay idle for the ten
 // instructions behind it.  gfx940+ needs two wait states between a VALU write of VCC and a VALU read of it, one
 // after a transcendental: filled with independent work where there is some.
 template <int CHT, bool TRACK_LAST>
-__device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, float pxf, float pyf, float mx, float my,
-                                                     float A, float B, float C, float L, const float* feat, int idx) {
+__device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, const PixelPoly& pp, float q0, float q1,
+                                                     float q2, float A, float B, float C, const float* feat, int idx) {
   static_assert(CHT == 3 || CHT == 4, "hand-written blend: 3 or 4 channels");
-  float dx, dy, t0, t1;           // dx doubles as the weight w, t0 as T (1 - alpha): four temporaries per body
+  float dx, t0, t1;               // dx: the weight w, t0: T (1 - alpha), t1: exponent, then alpha
   const float amin = kAlphaMin, tstop = kTStop;
   float c3 = CHT == 4 ? px.C[CHT - 1] : 0.f;
   const float f3 = CHT == 4 ? feat[CHT - 1] : 0.f;
   asm volatile(
-      "v_sub_f32 %[dx], %[mx], %[px]\n"
-      "v_sub_f32 %[dy], %[my], %[py]\n"
-      "v_mul_f32 %[t0], %[A], %[dx]\n"
-      "v_mul_f32 %[t1], %[C], %[dy]\n"
-      "v_fmac_f32 %[t0], %[B], %[dy]\n"
-      "v_fma_f32 %[t1], %[t1], %[dy], %[L]\n"
-      "v_fmac_f32 %[t1], %[dx], %[t0]\n"
+      "v_fma_f32 %[t1], %[q1], %[x], %[q0]\n"          // pair_power_poly, same order
+      "v_fmac_f32 %[t1], %[q2], %[y]\n"
+      "v_fmac_f32 %[t1], %[A], %[xx]\n"
+      "v_fmac_f32 %[t1], %[B], %[xy]\n"
+      "v_fmac_f32 %[t1], %[C], %[yy]\n"
       "v_exp_f32 %[t1], %[t1]\n"
       "s_nop 0\n"
       "v_cmpx_le_f32 vcc, %[amin], %[t1]\n"
@@ -156,9 +151,10 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, float 
       "v_cndmask_b32 %[last], %[last], %[idx], vcc\n"     // EXEC = valid lanes, VCC = accumulated
       ".endif\n"
       "s_mov_b64 exec, -1\n"
-      : [dx] "=&v"(dx), [dy] "=&v"(dy), [t0] "=&v"(t0), [t1] "=&v"(t1),
+      : [dx] "=&v"(dx), [t0] "=&v"(t0), [t1] "=&v"(t1),
         [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3), [last] "+v"(px.last)
-      : [mx] "v"(mx), [my] "v"(my), [px] "v"(pxf), [py] "v"(pyf), [A] "v"(A), [B] "v"(B), [C] "v"(C), [L] "v"(L),
+      : [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [x] "v"(pp.x), [y] "v"(pp.y), [xx] "v"(pp.xx), [xy] "v"(pp.xy),
+        [yy] "v"(pp.yy), [A] "v"(A), [B] "v"(B), [C] "v"(C),
         [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
         [four] "n"(CHT == 4 ? 1 : 0), [track] "n"(TRACK_LAST ? 1 : 0), [idx] "v"(idx)
       : "vcc");
@@ -196,7 +192,12 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 
   // pixel centres of quadrant 0; quadrant k adds (8*(k&1), 8*(k>>1))
   const int ix = tx * 16 + (int)(lane & 7), iy = ty * 16 + (int)(lane >> 3);
-  const float px0 = (float)ix + 0.5f, py0 = (float)iy + 0.5f;
+  // offsets of this lane's four pixels from the tile centre, and their products (raster_common.h: PixelPoly)
+  const float xo = (float)(lane & 7) - 7.5f, yo = (float)(lane >> 3) - 7.5f;
+  PixelPoly pq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pq[k] = pixel_poly(xo + 8.f * (k & 1), yo + 8.f * (k >> 1));
+  const float ctr_x = tile_x + 8.f, ctr_y = tile_y + 8.f;
 
 #ifdef MGS_RASTER_STATS
   unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -280,8 +281,12 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     MGS_STAT(5, 1);
     if (qmask != 0u) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
-      e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
-      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, __log2f(c_op), __uint_as_float(qmask), __int_as_float(c_idx));
+      const float sA = -0.5f * kLog2e * c_ca, sB = -kLog2e * c_cb, sC = -0.5f * kLog2e * c_cc;
+      const float m_x = c_xy.x - ctr_x, m_y = c_xy.y - ctr_y;
+      const PolyCoef q = poly_coefs(m_x, m_y, sA, sB, sC, __log2f(c_op));
+      e.geo0 = make_float4(q.q0, q.q1, q.q2, sA);
+      e.geo1 = make_float4(sB, sC, __uint_as_float(qmask), __int_as_float(c_idx));
+      e.geo3 = make_float4(m_x, m_y, 0.f, 0.f);
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
         float4 v;
@@ -298,8 +303,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 
     // (measured and rejected: reading entry j+1 while blending entry j, 307 vs 292 us; two
     //  entries per loop trip, 291 vs 288 us)
-    unsigned live_now = live;
-    auto blend_entry = [&](auto safe_tag, const float4& g0, const float4& g1, const float4* ef) {
+    auto blend_entry = [&](auto safe_tag, const float4& g0, const float4& g1, const float4* ef, const float4& g3) {
       constexpr bool SAFE = decltype(safe_tag)::value;
       float feat[CHT];
 #pragma unroll
@@ -309,72 +313,57 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
         if (4 * f + 2 < CHT) feat[4 * f + 2] = ef[f].z;
         if (4 * f + 3 < CHT) feat[4 * f + 3] = ef[f].w;
       }
-      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z)) & live_now;
+      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z));
       const int idx = __float_as_int(g1.w);
       MGS_STAT(2, __popc(m));
-#if MGS_RASTER_SWITCH
-      // One straight-line body per quadrant SET instead of four scalar-branched ones: the bodies of an entry's
-      // quadrants are independent chains of ~19 dependent instructions each, and only inside one basic block can
-      // the scheduler interleave them (a lone wave issues a dependent chain at one instruction per ~5 cycles).
-#define MGS_Q(k) blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], px0 + 8.f * ((k) & 1), py0 + 8.f * ((k) >> 1), g0.x, g0.y, \
-                                                    g0.z, g0.w, g1.x, g1.y, feat, idx)
-#if MGS_RASTER_SWITCH == 2
-#define MGS_SB __builtin_amdgcn_sched_barrier(0);      // at most two bodies interleaved (register budget)
-#else
-#define MGS_SB
-#endif
-      switch (m) {
-        case 1: MGS_Q(0); break;
-        case 2: MGS_Q(1); break;
-        case 3: MGS_Q(0); MGS_Q(1); break;
-        case 4: MGS_Q(2); break;
-        case 5: MGS_Q(0); MGS_Q(2); break;
-        case 6: MGS_Q(1); MGS_Q(2); break;
-        case 7: MGS_Q(0); MGS_Q(1); MGS_SB MGS_Q(2); break;
-        case 8: MGS_Q(3); break;
-        case 9: MGS_Q(0); MGS_Q(3); break;
-        case 10: MGS_Q(1); MGS_Q(3); break;
-        case 11: MGS_Q(0); MGS_Q(1); MGS_SB MGS_Q(3); break;
-        case 12: MGS_Q(2); MGS_Q(3); break;
-        case 13: MGS_Q(0); MGS_Q(2); MGS_SB MGS_Q(3); break;
-        case 14: MGS_Q(1); MGS_Q(2); MGS_SB MGS_Q(3); break;
-        case 15: MGS_Q(0); MGS_Q(1); MGS_SB MGS_Q(2); MGS_Q(3); break;
-        default: break;
-      }
-#undef MGS_Q
-#undef MGS_SB
-#else
+      // (measured and rejected, profiles/r3/00_experiments.md: one straight-line body per quadrant SET behind a
+      //  switch on the mask, 268-278 us against 197; the live quadrants re-derived every 8 / 16 / 32 entries, +2 %)
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (m & (1u << k)) {
           if constexpr (MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4))
-            blend_pixel_safe_asm<CHT, TRACK_LAST>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y, g0.z,
-                                                  g0.w, g1.x, g1.y, feat, idx);
+            blend_pixel_safe_asm<CHT, TRACK_LAST>(st[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, idx);
           else
-            blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], px0 + 8.f * (k & 1), py0 + 8.f * (k >> 1), g0.x, g0.y,
-                                               g0.z, g0.w, g1.x, g1.y, feat, idx);
+            blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x, g3.y, feat, idx);
         }
-#endif
     };
     auto walk = [&](auto safe_tag) {
-      for (int j = 0; j < count; ++j) {
-#if MGS_RASTER_REFRESH
-        // quadrants that saturated since the batch began stop being evaluated within MGS_RASTER_REFRESH entries
-        // instead of at the end of the 64-entry batch (a finished pixel ignores every later Gaussian anyway)
-        if ((j & (MGS_RASTER_REFRESH - 1)) == MGS_RASTER_REFRESH - 1) {
-          live_now = 0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (__ballot(st[k].T > 0.f) != 0ull) live_now |= 1u << k;
-          if (live_now == 0) break;
+      constexpr bool SAFE = decltype(safe_tag)::value;
+#if MGS_RASTER_PIPE
+      // entry j + 1 is read from LDS while entry j is blended (the queue has one spare slot: the read past the last
+      // entry is harmless): PMC had the waves parked on s_waitcnt for 39 % of their cycles, most of it these reads
+      if constexpr (CHT <= 4) {
+        // two register sets in turn (no copies): while set A is blended set B is on its way, and vice versa
+        float4 a0 = queue[0].geo0, a1 = queue[0].geo1, af = queue[0].feat[0], a3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 b0, b1, bf, b3 = a3;
+        if constexpr (!SAFE) a3 = queue[0].geo3;
+        for (int j = 0; j < count; j += 2) {
+          {
+            const QueueEntry<CHT>& e = queue[j + 1];
+            b0 = e.geo0; b1 = e.geo1; bf = e.feat[0];
+            if constexpr (!SAFE) b3 = e.geo3;
+          }
+          blend_entry(safe_tag, a0, a1, &af, a3);
+          if (j + 1 >= count) break;
+          {
+            const QueueEntry<CHT>& e = queue[min(j + 2, kQueue)];
+            a0 = e.geo0; a1 = e.geo1; af = e.feat[0];
+            if constexpr (!SAFE) a3 = e.geo3;
+          }
+          blend_entry(safe_tag, b0, b1, &bf, b3);
         }
+        return;
+      }
 #endif
+      for (int j = 0; j < count; ++j) {
         const QueueEntry<CHT>& e = queue[j];
         const float4 g0 = e.geo0, g1 = e.geo1;
         float4 ef[(CHT + 3) / 4];
 #pragma unroll
         for (int f = 0; f < (CHT + 3) / 4; ++f) ef[f] = e.feat[f];
-        blend_entry(safe_tag, g0, g1, ef);
+        float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (!SAFE) g3 = e.geo3;            // the mean's offset: only the sigma >= 0 test reads it
+        blend_entry(safe_tag, g0, g1, ef, g3);
       }
     };
     if (all_safe) walk(std::true_type{}); else walk(std::false_type{});
@@ -443,7 +432,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
   const int tx = tile % tile_w, ty = tile / tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   const int ix = tx * 16 + 8 * (k & 1) + (int)(lane & 7), iy = ty * 16 + 8 * (k >> 1) + (int)(lane >> 3);
-  const float pxf = (float)ix + 0.5f, pyf = (float)iy + 0.5f;
+  // this lane's pixel as an offset from the TILE centre (the same coordinates as the one-wave-per-tile kernel: same bits)
+  const PixelPoly pp = pixel_poly((float)(8 * (k & 1) + (int)(lane & 7)) - 7.5f, (float)(8 * (k >> 1) + (int)(lane >> 3)) - 7.5f);
   const bool inside = ix < width && iy < height;
   QuadRect rect;
   rect.x0 = (float)(tx * 16 + 8 * (k & 1)) + 0.5f; rect.x1 = rect.x0 + 7.f;
@@ -519,8 +509,12 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
     const bool all_safe = __ballot(keep_me && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
     if (keep_me) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
-      e.geo0 = make_float4(c_xy.x, c_xy.y, -0.5f * kLog2e * c_ca, -kLog2e * c_cb);
-      e.geo1 = make_float4(-0.5f * kLog2e * c_cc, __log2f(c_op), 0.f, __int_as_float(c_idx));
+      const float sA = -0.5f * kLog2e * c_ca, sB = -kLog2e * c_cb, sC = -0.5f * kLog2e * c_cc;
+      const float m_x = c_xy.x - (tile_x + 8.f), m_y = c_xy.y - (tile_y + 8.f);
+      const PolyCoef q = poly_coefs(m_x, m_y, sA, sB, sC, __log2f(c_op));
+      e.geo0 = make_float4(q.q0, q.q1, q.q2, sA);
+      e.geo1 = make_float4(sB, sC, 0.f, __int_as_float(c_idx));
+      e.geo3 = make_float4(m_x, m_y, 0.f, 0.f);
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
         float4 v;
@@ -555,10 +549,13 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
           if (4 * f + 2 < CHT) feat[4 * f + 2] = v.z;
           if (4 * f + 3 < CHT) feat[4 * f + 3] = v.w;
         }
-        if constexpr (MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4))
-          blend_pixel_safe_asm<CHT, TRACK_LAST>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
-        else
-          blend_pixel<CHT, TRACK_LAST, SAFE>(st, pxf, pyf, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
+        if constexpr (MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4)) {
+          blend_pixel_safe_asm<CHT, TRACK_LAST>(st, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
+        } else {
+          float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (!SAFE) g3 = e.geo3;
+          blend_pixel<CHT, TRACK_LAST, SAFE>(st, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x, g3.y, feat, __float_as_int(g1.w));
+        }
       }
       }
     };
