@@ -538,9 +538,10 @@ def pmc_traffic(kernel_key, standard_workload):
         return None, f"no PMC record ({type(e).__name__})"
 
 
-# Issue cost of the blend's instruction mix, SIMD-cycles per wave64 vector instruction: 13 fma-class at 2.4, 7
-# compare / select-class at 4.1 and one v_exp at 8.15 = 65 cycles per 21 (scripts/ubench/valu_issue.hip)
-VALU_ISSUE_FLOOR = 65.0 / 21.0
+# Issue cost of the blend's instruction mix, SIMD-cycles per wave64 vector instruction (scripts/ubench/valu_issue.hip,
+# DESIGN.md 4.0): the round-3 body is 11 fma-class at 2.4, 4 compare / select-class at 4.1 and one v_exp at 8.15 =
+# 51 cycles per 16 (round 2: 65 per 21)
+VALU_ISSUE_FLOOR = 51.0 / 16.0
 
 
 def pmc_valu(kernel_name, standard_workload):
@@ -565,7 +566,7 @@ def pmc_valu(kernel_name, standard_workload):
                 "note": "the floor is the blend loop's mix; fetch, cull and queue instructions are mostly of the cheaper "
                         "class, so a kernel at the bound can read slightly above 1",
                 "source": "rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE in the run that took `traffic` "
-                          "(profiles/pmc_traffic.json, profiles/r2/06_pmc_counters.md); floor: "
+                          "(profiles/pmc_traffic.json, profiles/r3/06_pmc_counters.md); floor: "
                           "scripts/ubench/valu_issue.hip"}
     except Exception:
         return None

@@ -101,6 +101,16 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   return valid;
 }
 
+// Record layout.  Value-major (MGS_BWD_SOA, default): value p of slot s lives at records[p * n_slots + s], so the
+// reduce kernel's lanes -- one Gaussian each, slots ascending with the Gaussian index -- read neighbouring words per
+// value instead of one word out of every 40-byte record.  0: slot-major records of `rs` floats.
+#ifndef MGS_BWD_SOA
+#define MGS_BWD_SOA 1
+#endif
+__device__ __forceinline__ size_t rec_index(size_t slot, int p, int rs, size_t n_slots) {
+  return MGS_BWD_SOA ? (size_t)p * n_slots + slot : slot * (size_t)rs + (size_t)p;
+}
+
 // Sums of grad_pixel's raw geometric accumulators -> gradients of mean2d and conic.
 __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& v_x, float& v_y,
                                            float& v_ca, float& v_cc) {
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
   constexpr int NV = 6 + CHT + (ABSGRAD ? 2 : 0);      // values reduced over the wave per list entry
   constexpr bool PIPE = RECORDS && MGS_RASTER_BWD_PIPE != 0 && NV > 8 && NV <= 16;
   const int rs = 6 + channels + (ABSGRAD ? 2 : 0);     // floats per record
+  const size_t n_slots = (size_t)capacity * (HALF ? 2 : 1);
   // record position of value j: channels above `channels` are padding and are dropped,
   // the absgrad pair follows the real channels
   auto rec_pos = [&](int j) {
@@ -245,7 +256,6 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
   };
   // ... and finish the sums and store the record
   auto red_finish = [&](size_t rslot, const float4& a0, const float4& b0, const float4& a1, const float4& b1) {
-    float* rec = records + rslot * rs;
     const int v1 = 8 + (int)(lane >> 3);
     float t0 = ((a0.x + a0.y) + (a0.z + a0.w)) + ((b0.x + b0.y) + (b0.z + b0.w));
     float t1 = ((a1.x + a1.y) + (a1.z + a1.w)) + ((b1.x + b1.y) + (b1.z + b1.w));
@@ -257,10 +267,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     t1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t1), 0x141, 0xf, 0xf, false));
     if ((lane & 7) == 0) {
       const int p0 = rec_pos((int)(lane >> 3));
-      if (p0 >= 0) rec[p0] = t0;
+      if (p0 >= 0) records[rec_index(rslot, p0, rs, n_slots)] = t0;
       if (v1 < NV) {
         const int p1 = rec_pos(v1);
-        if (p1 >= 0) rec[p1] = t1;
+        if (p1 >= 0) records[rec_index(rslot, p1, rs, n_slots)] = t1;
       }
     }
     if (lane == 0) flags[rslot] = 1;
@@ -384,7 +394,6 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
 #pragma unroll
         for (int c = 0; c < CHT; ++c) vals[6 + c] = gg.v_f[c];
         if (ABSGRAD) { vals[6 + CHT] = gg.a_x; vals[7 + CHT] = gg.a_y; }
-        float* rec = records + rslot * rs;
         int done = 0;
         // Through LDS, eight values per group: every lane parks its partial sums lane-linear
         // (red[i][lane], conflict-free), lane L then reads the eight partials red[L >> 3][8 (L & 7) ..]
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
           t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x141, 0xf, 0xf, false));  // row_half_mirror
           if ((lane & 7) == 0) {
             int pos = rec_pos(done + (int)(lane >> 3));
-            if (pos >= 0) rec[pos] = t;
+            if (pos >= 0) records[rec_index(rslot, pos, rs, n_slots)] = t;
           }
           __builtin_amdgcn_wave_barrier();          // the next round overwrites red
           done += 8;
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
           int i = wave_reduce_scatter_index<V>(lane);                          \
           if (i >= 0) {                                                        \
             int pos = rec_pos(done + i);                                       \
-            if (pos >= 0) rec[pos] = t;                                        \
+            if (pos >= 0) records[rec_index(rslot, pos, rs, n_slots)] = t;                                        \
           }                                                                    \
           done += V;                                                           \
         }
@@ -504,6 +513,7 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   const int cnt = npair * SLOTS;
   const size_t first = (size_t)info.x * SLOTS;
   const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
+  const size_t n_slots = (size_t)capacity * SLOTS;
   float acc[6], af[CHT], ab[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[i] = 0.f;
@@ -521,14 +531,14 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
     float r[4][6], rf[4][CHT], ra[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float* rec = records + (first + sl + i) * rs;
+      const size_t slot = first + sl + i;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) r[i][k] = on[i] ? rec[k] : 0.f;
+      for (int k = 0; k < 6; ++k) r[i][k] = on[i] ? records[rec_index(slot, k, rs, n_slots)] : 0.f;
 #pragma unroll
-      for (int c = 0; c < CHT; ++c) rf[i][c] = (on[i] && c < channels) ? rec[6 + c] : 0.f;
+      for (int c = 0; c < CHT; ++c) rf[i][c] = (on[i] && c < channels) ? records[rec_index(slot, 6 + c, rs, n_slots)] : 0.f;
       if (ABSGRAD) {
-        ra[i][0] = on[i] ? rec[6 + channels] : 0.f;
-        ra[i][1] = on[i] ? rec[7 + channels] : 0.f;
+        ra[i][0] = on[i] ? records[rec_index(slot, 6 + channels, rs, n_slots)] : 0.f;
+        ra[i][1] = on[i] ? records[rec_index(slot, 7 + channels, rs, n_slots)] : 0.f;
       }
     }
 #pragma unroll
