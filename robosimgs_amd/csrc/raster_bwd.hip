@@ -101,11 +101,12 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   return valid;
 }
 
-// Record layout.  Value-major (MGS_BWD_SOA, default): value p of slot s lives at records[p * n_slots + s], so the
-// reduce kernel's lanes -- one Gaussian each, slots ascending with the Gaussian index -- read neighbouring words per
-// value instead of one word out of every 40-byte record.  0: slot-major records of `rs` floats.
+// Record layout: slot-major records of `rs` floats (default).  MGS_BWD_SOA = 1 lays them out value-major (value p of
+// slot s at records[p * n_slots + s]) so that the reduce kernel's lanes read neighbouring words per value -- measured
+// and left off: the ten 4-byte stores of a record then land in ten different lines and the raster backward pays more
+// than the reduce gains (memset + backward + reduce 547 -> 686 us).
 #ifndef MGS_BWD_SOA
-#define MGS_BWD_SOA 1
+#define MGS_BWD_SOA 0
 #endif
 __device__ __forceinline__ size_t rec_index(size_t slot, int p, int rs, size_t n_slots) {
   return MGS_BWD_SOA ? (size_t)p * n_slots + slot : slot * (size_t)rs + (size_t)p;

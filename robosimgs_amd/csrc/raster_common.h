@@ -129,6 +129,20 @@ __device__ __forceinline__ float pair_power_poly(const PixelPoly& p, float q0, f
 // without the sigma >= 0 test and without the 0.999 clamp: exp2(power + L) <= opacity (1 + 2^-22) < 0.999.
 constexpr float kSafeOpacity = 0.998f;
 
+// A queue entry part is read from LDS as ONE ds_read_b128: an empty asm that "uses" all four lanes of the register
+// tuple keeps the compiler from narrowing the load to the components the caller happens to touch (it split a 16-byte
+// read into b64 + b32 + 2 x read2_b32: five LDS instructions per entry instead of three).
+typedef float mgs_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_read_3f4(const float4* pa, const float4* pb, const float4* pc, float4& a, float4& b,
+                                             float4& c) {
+  mgs_f4 va = *reinterpret_cast<const mgs_f4*>(pa), vb = *reinterpret_cast<const mgs_f4*>(pb),
+         vc = *reinterpret_cast<const mgs_f4*>(pc);
+  asm volatile("" : "+v"(va), "+v"(vb), "+v"(vc));      // (one statement: the three reads stay in flight together)
+  a = make_float4(va.x, va.y, va.z, va.w);
+  b = make_float4(vb.x, vb.y, vb.z, vb.w);
+  c = make_float4(vc.x, vc.y, vc.z, vc.w);
+}
+
 // full-wave sum: result valid in lane 63
 __device__ __forceinline__ float wave_reduce_to_lane63(float v) {
   int i;

@@ -357,10 +357,14 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 #endif
       for (int j = 0; j < count; ++j) {
         const QueueEntry<CHT>& e = queue[j];
-        const float4 g0 = e.geo0, g1 = e.geo1;
-        float4 ef[(CHT + 3) / 4];
+        float4 g0, g1, ef[(CHT + 3) / 4];
+        if constexpr (CHT <= 4) {
+          lds_read_3f4(&e.geo0, &e.geo1, &e.feat[0], g0, g1, ef[0]);
+        } else {
+          g0 = e.geo0; g1 = e.geo1;
 #pragma unroll
-        for (int f = 0; f < (CHT + 3) / 4; ++f) ef[f] = e.feat[f];
+          for (int f = 0; f < (CHT + 3) / 4; ++f) ef[f] = e.feat[f];
+        }
         float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (!SAFE) g3 = e.geo3;            // the mean's offset: only the sigma >= 0 test reads it
         blend_entry(safe_tag, g0, g1, ef, g3);
@@ -539,11 +543,13 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
         const int j1 = min(j0 + kChunk, count);
       for (int j = j0; j < j1; ++j) {
         const QueueEntry<CHT>& e = queue[j];
-        const float4 g0 = e.geo0, g1 = e.geo1;
+        float4 g0, g1, ef0;
+        if constexpr (CHT <= 4) lds_read_3f4(&e.geo0, &e.geo1, &e.feat[0], g0, g1, ef0);
+        else { g0 = e.geo0; g1 = e.geo1; ef0 = e.feat[0]; }
         float feat[CHT];
 #pragma unroll
         for (int f = 0; f < (CHT + 3) / 4; ++f) {
-          const float4 v = e.feat[f];
+          const float4 v = f == 0 ? ef0 : e.feat[f];
           feat[4 * f] = v.x;
           if (4 * f + 1 < CHT) feat[4 * f + 1] = v.y;
           if (4 * f + 2 < CHT) feat[4 * f + 2] = v.z;
