@@ -476,9 +476,11 @@ def main():
         # kernel wrote -- and as the standalone operator, which computes them itself first.
         seed = proj()[-1]
         def binning(seeded):
+            # the seed's per-64 sums are consumed by the call (scanned in place on the paths that need them): every
+            # call gets a fresh copy of the 62 KB array, as every frame gets fresh sums from its projection kernel
             return ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False,
-                                       conics=con, opacities=t["opacities"], seed=seed if seeded else None,
-                                       want_tile_ids=not seeded)
+                                       conics=con, opacities=t["opacities"],
+                                       seed=(seed[0], seed[1].clone()) if seeded else None, want_tile_ids=not seeded)
         bin_times = {}
         for seeded in (True, False):
             for _ in range(5):

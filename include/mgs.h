@@ -195,6 +195,26 @@ int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const flo
                     uint32_t *status, const uint32_t *seed_info, uint32_t *seed_sums,
                     void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
 
+/* -------------------------------------------------------------------------------------
+ * A batch of inference frames in ONE call (gsplat `rasterization(...)` for C cameras, no gradients):
+ * per camera mgs_project_color_fwd -> mgs_isect_tiles -> mgs_rasterize_fwd in their inference-frame form
+ * (packed records + binning seed, tightened tile rectangles, no per-Gaussian outputs), enqueued back to back
+ * on `stream`.  viewmats[C,4,4], Ks[C,3,3]; channels 3 (RGB) or 4 (RGB + camera-space depth as the last
+ * channel); flags as mgs_rasterize_fwd (MGS_RASTER_EXPECTED_LAST turns that channel into "ED");
+ * backgrounds[C,channels] nullable; antialiased != 0 = rasterize_mode "antialiased".
+ * out: render[C,H,W,channels], alphas[C,H,W], n_isect[C], status[C] (as mgs_isect_tiles, per camera).
+ * The per-camera intermediates live in `workspace` (two-phase size query; 256-byte aligned) and are reused
+ * from camera to camera, so any batch needs one camera's worth of scratch: ~76 B per Gaussian + 4 B per
+ * list slot + the binning's own workspace.  No host read-back: capturable like a single frame.
+ * ----------------------------------------------------------------------------------- */
+int mgs_render_frames(int n, const float *means, const float *quats, const float *scales,
+                      const float *opacities, int sh_degree, int coeff_stride, const float *sh_coeffs,
+                      int n_cams, const float *viewmats, const float *Ks, int width, int height,
+                      float eps2d, float near_plane, float far_plane, float radius_clip,
+                      int antialiased, int channels, int flags, const float *backgrounds,
+                      uint32_t isect_capacity, float *render, float *alphas, uint32_t *n_isect,
+                      uint32_t *status, void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
+
 /* gsplat `isect_offset_encode`: first sorted index per (cam, tile) from sorted int64 keys.
  * n_isect is a HOST value here (the operator takes a materialised key tensor).
  * offsets[n_cams*tile_h*tile_w]. */

@@ -50,6 +50,7 @@ def _load() -> ctypes.CDLL:
         "mgs_project_color_bwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, i, p], c_int),
         "mgs_isect_tiles": ([i, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
+        "mgs_render_frames": ([i, p, p, p, p, i, i, p, i, p, p, i, i, f, f, f, f, i, i, i, p, u32, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_rasterize_fwd": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, i, p, p, p, p], c_int),
         "mgs_rasterize_bwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_composite_over": ([i, p, p, p, p, p, p, p, p, p, p], c_int),
@@ -89,7 +90,7 @@ EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_debug_set_raster_cull", 
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
            "mgs_rasterize_bwd_det", "mgs_composite_over", "mgs_points_project",
            "mgs_points_depth_map", "mgs_points_sample_mask", "mgs_l1_loss_fwd", "mgs_l1_loss_bwd",
-           "mgs_transform_gaussians", "mgs_frame_to_u8", "mgs_frame_to_dataset"]
+           "mgs_transform_gaussians", "mgs_frame_to_u8", "mgs_frame_to_dataset", "mgs_render_frames"]
 
 
 def check(rc: int, what: str) -> None:

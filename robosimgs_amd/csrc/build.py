@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "projection.hip", "sort.hip", "binning.hip", "tile_sort.hip", "raster_fwd.hip",
-           "raster_bwd.hip", "backward.hip", "composite.hip", "points.hip", "loss.hip", "transform.hip"]
+           "raster_bwd.hip", "backward.hip", "composite.hip", "points.hip", "loss.hip", "transform.hip", "frame.hip"]
 HEADERS = ["mgs_common.h", "mgs_math.h", "raster_common.h", "sh_staging.h", "tile_rect.h", "tile_order.h",
            "../../include/mgs.h"]
 LIB = os.path.join(HERE, "libmgs.so")

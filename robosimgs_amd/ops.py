@@ -152,6 +152,37 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     return out
 
 
+def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height,
+                      eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth, capacity,
+                      backgrounds=None, expected_last=False, latency=False, out=None):
+    """mgs_render_frames: C inference frames in one C call (no per-Gaussian outputs, scratch reused from camera to
+    camera).  viewmats [C,4,4], Ks [C,3,3], backgrounds [C,ch] or None.  Returns (render [C,H,W,ch], alphas [C,H,W],
+    n_isects [C] i32, isect_status [C] i32); out = (render, alphas) to write into existing buffers."""
+    dev = means.device
+    C, n = viewmats.shape[0], means.shape[0]
+    ch = 4 if with_depth else 3
+    if out is None:
+        render = torch.empty(C, height, width, ch, dtype=torch.float32, device=dev)
+        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+    else:
+        render, alphas = out
+    n_isect = torch.empty(C, dtype=torch.int32, device=dev)
+    status = torch.empty(C, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t(0)
+    args = [n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), int(sh_degree), sh_coeffs.shape[1], ptr(sh_coeffs),
+            C, ptr(viewmats), ptr(Ks), int(width), int(height), eps2d, near_plane, far_plane, radius_clip,
+            int(bool(antialiased)), ch, int(bool(expected_last)) | (2 if latency else 0), ptr(backgrounds),
+            int(capacity), ptr(render), ptr(alphas), ptr(n_isect), ptr(status)]
+    check(L.mgs_render_frames(*args, None, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames(size query)")
+    ws = _workspace(nbytes.value + 256, dev)
+    base = ws.data_ptr()
+    aligned = (base + 255) // 256 * 256
+    nbytes = ctypes.c_size_t(ws.numel() - (aligned - base))
+    check(L.mgs_render_frames(*args, aligned, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames")
+    return render, alphas, n_isect, status
+
+
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                       tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None,
                       expected_last=False, latency=False, group_order=None, channels=None):

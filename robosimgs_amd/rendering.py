@@ -72,6 +72,16 @@ class _RenderSH(torch.autograd.Function):
         # records, the binning seed and the depths; radii / means2d / conics / feats / tiles_per_gauss are neither
         # written nor returned (36 + 4 MB of stores per 1 M Gaussians)
         lean = bool(lean) and not training and isect_capacity is not None
+        if lean:
+            # the whole batch of cameras behind ONE C call (mgs_render_frames): per-camera scratch is reused, nothing
+            # per Gaussian is returned
+            _, _, n_isects, status = ops.render_frames_raw(
+                means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d,
+                near_plane, far_plane, radius_clip, antialiased, with_depth, isect_capacity, backgrounds=backgrounds,
+                expected_last=expected_depth, latency=latency, out=(render, alphas))
+            meta_out["lean"] = dict(n_isects=n_isects, isect_status=status)
+            ctx.set_materialize_grads(False)
+            return render, alphas.unsqueeze(-1)
         per_cam = []
         for c in range(C):
             # the projection kernel also seeds the binning (tile rectangle + count per Gaussian)
@@ -190,9 +200,10 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                   lean_meta: bool = False) -> Tuple[Tensor, Tensor, Dict]:
     """Render N Gaussians from C cameras.
 
-    lean_meta (SH path, isect_capacity given, no gradients): the frame keeps only what its own kernels read;
-    meta then lacks radii / means2d / conics / tiles_per_gauss (depths, n_isects, isect_status and tile_lists
-    stay) and the projection kernel skips 40 MB of stores per 1 M Gaussians.  FrameRenderer's default.
+    lean_meta (SH path, isect_capacity given, no gradients): all C cameras go through ONE C call
+    (mgs_render_frames) whose frames keep only what their own kernels read; meta then holds n_isects and
+    isect_status [C] and nothing per Gaussian or per tile, and the projection kernel skips 40 MB of stores per
+    1 M Gaussians.  FrameRenderer's default.
 
     raster_schedule (SH path): "latency" runs the tile raster with one wave per 8x8 block (the launch
     has the GPU to itself: a single frame, a training step; -19 % kernel time), "throughput" with
@@ -265,6 +276,9 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             bool(lean_meta))
         if depth_only_via_sh:
             render = render[..., 3:4]
+        if "lean" in store:             # inference frames through mgs_render_frames: counts and status only
+            meta.update(store.pop("lean"))
+            return render, alphas, meta
         per_cam = store.pop("per_cam")
 
         def _stk(xs):                 # no copy for the common single-camera call

@@ -23,7 +23,7 @@ def _declared():
 def test_header_symbols_are_exported_and_bound():
     from robosimgs_amd import _lib
     decl = _declared()
-    assert len(decl) == 25, sorted(decl)
+    assert len(decl) == 26, sorted(decl)
     assert sorted(decl) == sorted(_lib.EXPORTS)
     L = _lib.lib()
     for name, nargs in decl.items():
