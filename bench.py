@@ -11,15 +11,16 @@ libmgs.so, replayed as one HIP graph with the scene resident in HBM.
 N > 1 (configs[3]; one process per GPU over RCCL -- started by torch.distributed.run as the driver does, or by
 bench.py itself when it is called as plain `python bench.py --gpus N` without WORLD_SIZE in the environment): a step is one
 pass over the 64-camera novel-view ring theta_k = 2 pi k / 64; rank r renders the contiguous block
-shard_cameras(64, N, r) through its FrameRenderer and rank 0 gathers all 64 finished frames (fp32
-RGB + depth + alpha, 20 bytes per pixel, is the payload `value` is measured with; the same run then times
-the ring again with the 8-bit RGB images a dataset writer stores and reports that rate beside it as
-config.gather_other_payload -- `--gather-dtype u8` swaps the two, `--one-payload` skips the second).
-The fp32 payload is 41.5 MB per frame: at 8 ranks rank 0 takes 7/8 of every frame over its seven xGMI
-links, which bounds the whole job at (rank 0's inbound xGMI rate) / 41.5 MB -- 8-9 k frames/s if RCCL's
-point-to-point gather sustains ~50 GB/s per link (not measured: no multi-GPU box in this round) -- whatever
-the renderers do; the 8-bit payload (6.2 MB per frame) moves the same bound to ~55 k frames/s and shows the
-renderers' own scaling.
+shard_cameras(64, N, r) through its FrameRenderer and rank 0 gathers all 64 finished frames.  The payload `value`
+is measured with is the DATASET frame -- RGBA8 + fp32 ray distance, 8 bytes per pixel = 16.6 MB per frame, the layout
+DatasetWriter stores and the reference's load_images / load_depths read, converted on the device inside the timed
+region (mgs_frame_to_dataset); the same run then times the ring again with the raw fp32 renders (RGB + expected depth
++ alpha, 20 B per pixel = 41.5 MB per frame) and reports that rate beside it as config.gather_other_payload
+(`--gather-dtype fp32 | u8` picks another payload for `value`, `--one-payload` skips the second leg).  At 8 ranks rank 0
+takes 7/8 of every frame over its seven xGMI links, which bounds the whole job at (rank 0's inbound xGMI rate) /
+(payload per frame) whatever the renderers do: ~21 k frames/s for the dataset frames and 8-9 k for the raw renders if
+RCCL's point-to-point gather sustains ~50 GB/s per link (not measured: no multi-GPU box in this round), ~55 k for
+8-bit RGB alone.
 Total work is fixed as N grows: scaling is "strong"; value = frames all ranks rendered / time.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
@@ -56,6 +57,10 @@ from robosimgs_amd.rendering import rasterization  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
 MODE = "RGB+ED"                # what splatfacto renders and INTEGRATION.md tells users to call
 RING = 64                      # configs[3]: 64 novel-view cameras
+PAYLOADS = {"dataset": "dataset frames: RGBA8 + fp32 ray distance, 8 B per pixel, the layout DatasetWriter stores and the "
+                       "reference's load_images / load_depths read (mgs_frame_to_dataset on the device, inside the timed region)",
+            "fp32": "fp32 RGB + expected depth + alpha (20 B per pixel)",
+            "u8": "8-bit RGB images (frame_to_u8 on the device, inside the timed region)"}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -73,10 +78,11 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step region until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    # N > 1: what rank 0 collects.  "fp32" (default) = the raw renders, RGB + depth + alpha, 41.5 MB per
-    # frame (332 MB per rank and pass at 8 ranks); "u8" = the 8-bit RGB images a dataset
-    # writer stores, quantised on the device inside the timed region (6.2 MB per frame).
-    ap.add_argument("--gather-dtype", choices=("fp32", "u8"), default="fp32")
+    # N > 1: what rank 0 collects.  "dataset" (default) = the frame as the dataset writer stores it and the reference's
+    # load_images / load_depths read it: RGBA8 + fp32 ray distance, 8 B per pixel = 16.6 MB per frame, converted on the
+    # device inside the timed region (mgs_frame_to_dataset); "fp32" = the raw renders, RGB + depth + alpha, 41.5 MB per
+    # frame (332 MB per rank and pass at 8 ranks); "u8" = 8-bit RGB only (6.2 MB per frame).
+    ap.add_argument("--gather-dtype", choices=("dataset", "fp32", "u8"), default="dataset")
     ap.add_argument("--gather-batch", type=int, default=4, help="frames per collective (N > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
@@ -146,6 +152,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or a.force_gather
+    out_fd = None
+    if use_dist:
+        # rank 0's JSON line must be the only thing on stdout: RCCL prints its version banner there (NCCL_DEBUG=VERSION
+        # is set on the GPU boxes), so file descriptor 1 points at stderr from here on and the line goes to the saved one
+        sys.stdout.flush()
+        out_fd = os.dup(1)
+        os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -203,6 +216,8 @@ def main():
     # VALU-bound raster of another.  Every submit is one whole frame (projection + binning +
     # raster) and every timed region ends with a full sync.
     from robosimgs_amd import FrameRenderer, frame_to_u8
+    from robosimgs_amd.dataset import frame_to_dataset
+    K_host = np.asarray(sizing_cam.K, dtype=np.float64)        # the ring's cameras share their intrinsics
     n_fl = max(1, a.inflight)
     fr = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap)
     cam_devs = [FrameRenderer.pack_camera(*[x[0].contiguous() for x in cam_tensors(c)]) for c in cams]
@@ -217,11 +232,14 @@ def main():
     # costs ~80 us of launch / stream hand-over each, a quarter of a frame time.
     GB = max(1, min(a.gather_batch, max(1, math.ceil(RING / world)))) if ring else 1
 
-    def time_frames(g_u8):
-        """Warm-up, then regions of K steps until min_seconds are timed; the gathered payload is fp32 RGB +
-        expected depth + alpha (g_u8 False) or the 8-bit RGB image (g_u8 True).  Returns (regions, collectives)."""
-        g_dtype = torch.uint8 if g_u8 else torch.float32
-        g_ch = 3 if g_u8 else 5                            # u8: RGB; fp32: RGB, expected depth, alpha
+    def time_frames(g_mode):
+        """Warm-up, then regions of K steps until min_seconds are timed; the gathered payload is the dataset frame
+        (RGBA8 plane + fp32 ray-distance plane, 8 B per pixel), fp32 RGB + expected depth + alpha, or the 8-bit RGB
+        image.  Returns (regions, collectives)."""
+        g_u8 = g_mode == "u8"
+        g_ds = g_mode == "dataset"
+        g_dtype = torch.float32 if g_mode == "fp32" else torch.uint8
+        g_ch = {"dataset": 8, "u8": 3, "fp32": 5}[g_mode]  # dataset: per frame [RGBA8 plane | fp32 distance plane] as bytes
         batch_shape = (GB, H, W, g_ch)
         staging = [torch.empty(batch_shape, device=dev, dtype=g_dtype) for _ in range(2)] if do_gather else None
         host_staging = ([torch.empty(batch_shape, device="cpu", dtype=g_dtype) for _ in range(2)]
@@ -254,7 +272,11 @@ def main():
                 if j == 0 and pending[cur] is not None:    # the collective that last read this staging buffer
                     pending[cur].wait()                    # (NCCL: the current STREAM waits, not the host)
                     pending[cur] = None
-                if g_u8:                                   # quantise on the device, inside the timed region
+                if g_ds:                                   # RGBA8 + ray distance, one kernel, inside the timed region
+                    flat = staging[cur][j].view(-1)
+                    frame_to_dataset(f["colors"], f["alphas"], K_host, out=(flat[:H * W * 4].view(H, W, 4),
+                                                                            flat[H * W * 4:].view(torch.float32).view(H, W, 1)))
+                elif g_u8:                                 # quantise on the device, inside the timed region
                     frame_to_u8(f["colors"], f["alphas"], out=staging[cur][j].view(-1, 3))
                 else:                                      # RGB + depth | alpha, straight from the slot's buffers
                     staging[cur][j][..., :4].copy_(f["colors"], non_blocking=True)
@@ -318,13 +340,15 @@ def main():
                 assert float(gather_bufs[0][r_][0].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
         return regs, state["shipped"]
 
-    g_u8 = a.gather_dtype == "u8"
-    regions, n_collectives = time_frames(g_u8)
+    g_mode = a.gather_dtype
+    g_u8 = g_mode == "u8"
+    regions, n_collectives = time_frames(g_mode)
     elapsed = float(np.median(regions))
     # the other payload, timed the same way in the same run (N > 1 only): both are reported
     other = None
     if do_gather and not a.one_payload:
-        o_regions, _ = time_frames(not g_u8)
+        other_mode = "fp32" if g_mode != "fp32" else "dataset"
+        o_regions, _ = time_frames(other_mode)
         other = float(np.median(o_regions))
     # single-frame latency (one slot, nothing else in flight), for reference
     torch.cuda.synchronize()
@@ -368,12 +392,10 @@ def main():
                    "frames_per_step_all_ranks": RING if ring else 1,
                    "frames_per_step_this_rank": frames_per_step,
                    "frames_per_rank": [len(shard_cameras(RING, world, r)) for r in range(world)] if ring else [1],
-                   "gather": ((("8-bit RGB images (frame_to_u8 on the device, inside the timed region)" if g_u8
-                                else "fp32 RGB + expected depth + alpha (20 B per pixel)")
+                   "gather": ((PAYLOADS[g_mode]
                                + f" to rank 0 (RCCL), {GB} frames per collective, "
                                  f"{n_collectives} collectives issued") if do_gather else "none"),
-                   "gather_other_payload": ({"payload": ("fp32 RGB + expected depth + alpha (20 B per pixel)" if g_u8 else
-                                                         "8-bit RGB images (frame_to_u8 on the device, inside the timed region)"),
+                   "gather_other_payload": ({"payload": PAYLOADS[other_mode],
                                              "frames_per_s": round(total_frames / other, 2),
                                              "ms_per_step": round(other / a.steps * 1e3, 4)} if other else None),
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
@@ -513,7 +535,10 @@ def main():
         # ---- CPU baseline: the oracle's C++/OpenMP port on this box's host cores -----------
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(scene, sizing_cam, W, H, deg, a.cpu_seconds)
-        print(json.dumps(result), flush=True)
+        if out_fd is None:
+            print(json.dumps(result), flush=True)
+        else:
+            os.write(out_fd, (json.dumps(result) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

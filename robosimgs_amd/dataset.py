@@ -10,7 +10,7 @@ The reference ships the readers of a rendered dataset, not the writer:
 tests/golden/dataset_reference.npz holds what the reference's own readers return for files written here
 (generator: tests/golden/make_dataset_golden.py).
 
-The host half (PNG / npy.gz encoding, `load_ns_point_cloud_points`) needs only numpy; the device half needs
+The host half (PNG / npy.gz encoding, `unnormalize_points`) needs only numpy; the device half needs
 torch and libmgs.so (no CPU fallback).
 """
 from __future__ import annotations
@@ -136,12 +136,13 @@ def unnormalize_points(points: np.ndarray, transform: np.ndarray, scale: float) 
 
 # ---- device half --------------------------------------------------------------------------------------
 def frame_to_dataset(colors, alphas, K=None, background: Optional[Sequence[float]] = None,
-                     distance_dtype=None, want_rgba: bool = True):
+                     distance_dtype=None, want_rgba: bool = True, out=None):
     """colors [H,W,D] (first three channels RGB; for the distance map the LAST channel is the z-depth of an
     "RGB+ED" / "RGB+D" frame), alphas [H,W,1] or [H,W], K [3,3] (numpy / list; None = image only).
     Returns (rgba uint8 [H,W,4] or None, distance [H,W,1] or None) on the device.
     distance_dtype: torch.float32 (default, what `ns-render` stores; the reader recovers z to one ulp) or
-    torch.float64 (the reader recovers z to the last fp32 bit)."""
+    torch.float64 (the reader recovers z to the last fp32 bit).
+    out = (rgba uint8 [H,W,4], distance [H,W,1]) writes into existing contiguous buffers (e.g. a gather's staging area)."""
     import torch
 
     from . import _lib
@@ -153,8 +154,15 @@ def frame_to_dataset(colors, alphas, K=None, background: Optional[Sequence[float
     c = colors.to(torch.float32).contiguous()
     a = alphas.to(torch.float32).reshape(h, w).contiguous()
     dev = colors.device
-    rgba = torch.empty(h, w, 4, dtype=torch.uint8, device=dev) if want_rgba else None
+    rgba = torch.empty(h, w, 4, dtype=torch.uint8, device=dev) if (want_rgba and out is None) else None
     dist, kinv = None, None
+    if out is not None:
+        rgba, dist_out = out
+        if (rgba is not None and (rgba.dtype != torch.uint8 or not rgba.is_contiguous() or rgba.numel() != h * w * 4)) or \
+                (dist_out is not None and (not dist_out.is_contiguous() or dist_out.numel() != h * w)):
+            raise ValueError("out = (uint8 [H,W,4], float [H,W,1]), both contiguous")
+        if dist_out is not None:
+            distance_dtype = dist_out.dtype
     f64 = distance_dtype == torch.float64
     if K is not None:
         if d < 4:
@@ -162,7 +170,8 @@ def frame_to_dataset(colors, alphas, K=None, background: Optional[Sequence[float
         if distance_dtype not in (None, torch.float32, torch.float64):
             raise ValueError("distance_dtype must be torch.float32 or torch.float64")
         kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(K, dtype=np.float64).reshape(3, 3)))
-        dist = torch.empty(h, w, 1, dtype=torch.float64 if f64 else torch.float32, device=dev)
+        dist = (out[1] if out is not None and out[1] is not None
+                else torch.empty(h, w, 1, dtype=torch.float64 if f64 else torch.float32, device=dev))
     bg = torch.tensor(list(background), dtype=torch.float32, device=dev) if background is not None else None
     check(_lib.lib().mgs_frame_to_dataset(w, h, ptr(c), d, ptr(a), ptr(bg),
                                           kinv.ctypes.data if kinv is not None else None, ptr(rgba), ptr(dist),
