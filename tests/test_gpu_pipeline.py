@@ -175,3 +175,29 @@ def test_batched_cameras_through_one_call_equal_the_per_camera_frames():
     rc = L.mgs_render_frames(4, None, None, None, None, 0, 1, None, 1, None, None, 16, 16, 0.3, 0.01, 1e10, 0.0, 0, 7, 0, None,
                              100, None, None, None, None, None, None, None)
     assert rc == -1 and b"channels" in L.mgs_last_error_string()
+
+
+def test_batched_frames_ragged_sizes_empty_scene_and_everything_culled():
+    """mgs_render_frames at a resolution that is no multiple of the tile size, with a camera that sees nothing, and with
+    an empty scene: frames equal the per-camera path (or are empty) and nothing faults."""
+    from robosimgs_amd import rasterization
+    g = synthetic_scene(8_000, math.log(0.06), 1, 11)
+    cams = camera_ring(2, 333, 207)
+    t = g.to_torch(DEV, 1)
+    away = np.array(cams[0].viewmat(), dtype=np.float64)
+    away[2, 3] = -1e3                                             # everything behind the camera
+    vm = _t(np.stack([cams[0].viewmat(), away, cams[1].viewmat()]))
+    Ks = _t(np.stack([cams[0].K, cams[0].K, cams[1].K]))
+    with torch.no_grad():
+        c0, a0, m0 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, 333, 207,
+                                   sh_degree=1, render_mode="RGB+ED", isect_capacity=400_000)
+        c1, a1, m1 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, 333, 207,
+                                   sh_degree=1, render_mode="RGB+ED", isect_capacity=400_000, lean_meta=True)
+    assert torch.equal(c0, c1) and torch.equal(a0, a1)
+    assert int(m1["n_isects"][1]) == 0 and float(a1[1].abs().max()) == 0.0 and float(c1[1].abs().max()) == 0.0
+    assert int(m1["n_isects"][0]) > 0 and int(m1["n_isects"][2]) > 0
+    e = {k: (v[:0].contiguous() if torch.is_tensor(v) else v) for k, v in t.items()}
+    with torch.no_grad():
+        c2, a2, m2 = rasterization(e["means"], e["quats"], e["scales"], e["opacities"], e["colors"], vm[:1], Ks[:1], 333, 207,
+                                   sh_degree=1, render_mode="RGB", isect_capacity=1000, lean_meta=True)
+    assert c2.shape == (1, 207, 333, 3) and float(c2.abs().max()) == 0.0 and int(m2["n_isects"][0]) == 0
