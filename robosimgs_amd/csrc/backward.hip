@@ -117,7 +117,7 @@ __device__ __forceinline__ void sh_bwd_rows(int n, int stride_f, int g, bool act
   if constexpr (STAGED) {
     const unsigned lane = threadIdx.x & (kWave - 1);
     const int g0 = g - (int)lane;
-    unsigned long long wave_mask = __ballot(active);
+    unsigned long long wave_mask = ballot(active);
     sh_rows_to_lds(coeffs, g0, n, wave_mask, lds_wave);
     __syncthreads();
     float* row = reinterpret_cast<float*>(lds_wave + lane * kShPitchF4);

@@ -271,7 +271,7 @@ __device__ __forceinline__ void for_each_tile(uint32_t pack, uint32_t cnt, uint3
       if (++dx == w) { dx = 0; t += (uint32_t)tile_w; }
     }
   }
-  unsigned long long m = __ballot(big);
+  unsigned long long m = ballot(big);
   const unsigned lane = lane_id();
   while (m) {
     const int src = __ffsll((long long)m) - 1;

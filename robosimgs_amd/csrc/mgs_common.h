@@ -35,6 +35,10 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
+// wave64 ballot of a predicate: the lane mask the compare already produced.  (HIP's __ballot(int) turns the predicate
+// into 0 / 1 and compares that with zero again: a v_cndmask and a v_cmp per call that the compiler does not always fold
+// away -- two of the per-tile sort's group filter's instructions per list entry were exactly these.)
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // number of set bits of `mask` strictly below this lane
 __device__ __forceinline__ unsigned mask_rank(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),

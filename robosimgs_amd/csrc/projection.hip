@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void sh_fwd_kernel(
   __shared__ float4 lds[STAGED ? (kBlock / kWave) * kWave * kShPitchF4 : 1];
   int g = blockIdx.x * kBlock + threadIdx.x;
   bool active = g < n && (masks == nullptr || masks[g] != 0);
-  unsigned long long wave_mask = __ballot(active);
+  unsigned long long wave_mask = ballot(active);
   int g0 = blockIdx.x * kBlock + (threadIdx.x & ~(kWave - 1));
   float c[sh_reg_floats(DEG)];
   fetch_sh_row<DEG, STAGED>(coeffs, stride_f, g, g0, n, active, wave_mask,
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if ((threadIdx.x & (kWave - 1)) == 0 && g < n) bin_sums[g / kWave] = c;
   }
-  unsigned long long wave_mask = __ballot(active);
+  unsigned long long wave_mask = ballot(active);
   int g0 = blockIdx.x * kBlock + (threadIdx.x & ~(kWave - 1));
   float c[sh_reg_floats(DEG)];
   fetch_sh_row<DEG, STAGED>(coeffs, stride_f, g, g0, n, active, wave_mask,

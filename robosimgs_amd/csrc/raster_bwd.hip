@@ -71,7 +71,7 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
   bool valid = idx <= px.last && alpha >= kAlphaMin;
   if (!SAFE) valid = valid && pair_power_sign(dx, dy, A, B, C) <= 0.f;
-  if (__ballot(valid) == 0ull) return false;
+  if (ballot(valid) == 0ull) return false;
   float a_eff = valid ? alpha : 0.f;                       // 0 => T, bv and v_f stay untouched
   bool grad_geo = valid && ov <= kAlphaMax;                // alpha not clamped: sigma/opacity get grads
   float ov_eff = SAFE ? a_eff : (grad_geo ? ov : 0.f);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     unsigned live = 0;
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-      if (__ballot(st[k].last >= b) != 0ull) live |= 1u << k;
+      if (ballot(st[k].last >= b) != 0ull) live |= 1u << k;
     if (live == 0) continue;
 
     const int idx = b + (int)lane;
@@ -313,9 +313,9 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
       if (HALF) qmask = (qmask >> (2 * half)) & 3u;       // this half's two blocks
       qmask &= live;
     }
-    const unsigned long long keep = __ballot(qmask != 0u);
+    const unsigned long long keep = ballot(qmask != 0u);
     const int count = __popcll(keep);
-    const bool all_safe = __ballot(qmask != 0u && !(sigma_sign_is_safe(ca, cb, cc) && op <= kSafeOpacity)) == 0ull;
+    const bool all_safe = ballot(qmask != 0u && !(sigma_sign_is_safe(ca, cb, cc) && op <= kSafeOpacity)) == 0ull;
     if (qmask != 0u) {
       BwdEntry<CHT>& e = queue[mask_rank(keep)];
       constexpr float kLog2e = 1.4426950408889634f;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         red_finish(pend_slot, pa0, pb0, pa1, pb1);
         pend = false;
       }
-      if (__ballot(any) == 0ull) continue;
+      if (ballot(any) == 0ull) continue;
       gg.v_op *= __builtin_amdgcn_exp2f(-g1.y);      // grad_pixel summed opacity * d/d opacity: divide by the opacity (2^L)
       if constexpr (RECORDS) {
         // overflowed tile lists (status word set by the binning): slot bases run up to the true

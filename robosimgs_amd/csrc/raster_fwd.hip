@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     unsigned live = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (__ballot(st[k].T > 0.f) != 0ull) live |= 1u << k;
+      if (ballot(st[k].T > 0.f) != 0ull) live |= 1u << k;
     if (live == 0) break;
 
     // take the prefetched batch, start the next one
@@ -270,13 +270,13 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 
     unsigned qmask = 0;
     if (c_ok) qmask = (cull ? quadrant_mask(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, c_op, tile_x, tile_y) : 0xfu) & live;
-    const unsigned long long keep = __ballot(qmask != 0u);
+    const unsigned long long keep = ballot(qmask != 0u);
     // every queued Gaussian of this batch has a well conditioned conic and an opacity <= 0.999 (nearly
     // always): the sigma >= 0 test and the 0.999 clamp are dead for the whole batch and the walk below runs
     // without them (raster_common.h: sigma_sign_is_safe) -- two compare / min class instructions less per 64 pairs
-    const bool all_safe = __ballot(qmask != 0u && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
+    const bool all_safe = ballot(qmask != 0u && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
     const int count = __popcll(keep);
-    MGS_STAT(0, __popcll(__ballot(c_ok)));
+    MGS_STAT(0, __popcll(ballot(c_ok)));
     MGS_STAT(1, count);
     MGS_STAT(5, 1);
     if (qmask != 0u) {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
   fetch(r_idx, r_ok);
 
   for (int b = start; b < end; b += kQueue) {
-    if (__ballot(st.T > 0.f) == 0ull) break;          // every pixel of the block is finished
+    if (ballot(st.T > 0.f) == 0ull) break;          // every pixel of the block is finished
     const int c_idx = r_idx;
     const bool c_ok = r_ok;
     const float2 c_xy = r_xy;
@@ -508,9 +508,9 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
         }
       }
     }
-    const unsigned long long keep = __ballot(keep_me);
+    const unsigned long long keep = ballot(keep_me);
     const int count = __popcll(keep);
-    const bool all_safe = __ballot(keep_me && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
+    const bool all_safe = ballot(keep_me && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
     if (keep_me) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
       const float sA = -0.5f * kLog2e * c_ca, sB = -kLog2e * c_cb, sC = -0.5f * kLog2e * c_cc;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
       // for the inference variant (whose loop the compiler unrolls four times when left whole).
       constexpr int kChunk = TRACK_LAST ? 8 : kQueue;
       for (int j0 = 0; j0 < count; j0 += kChunk) {
-        if (j0 && __ballot(st.T > 0.f) == 0ull) break;
+        if (j0 && ballot(st.T > 0.f) == 0ull) break;
         const int j1 = min(j0 + kChunk, count);
       for (int j = j0; j < j1; ++j) {
         const QueueEntry<CHT>& e = queue[j];

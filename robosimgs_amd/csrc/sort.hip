@@ -137,10 +137,10 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(
     uint32_t idx = wbase + r * 64 + lane;
     bool valid = idx < n;
     unsigned d = digit_of(key[r], shift, mask);
-    unsigned long long peers = __ballot(valid);
+    unsigned long long peers = ballot(valid);
 #pragma unroll
     for (int b = 0; b < BITS; ++b) {
-      unsigned long long m = __ballot((d >> b) & 1u);
+      unsigned long long m = ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
     unsigned below = mask_rank(peers);
@@ -310,10 +310,10 @@ __global__ __launch_bounds__(kThreads) void onesweep_scatter_kernel(
     uint32_t idx = wbase + r * 64 + lane;
     bool valid = idx < n;
     unsigned d = digit_of(key[r], shift, mask);
-    unsigned long long peers = __ballot(valid);
+    unsigned long long peers = ballot(valid);
 #pragma unroll
     for (int b = 0; b < BITS; ++b) {
-      unsigned long long m = __ballot((d >> b) & 1u);
+      unsigned long long m = ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
     unsigned below = mask_rank(peers);

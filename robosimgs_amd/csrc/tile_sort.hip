@@ -130,14 +130,16 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
       }
       // the wave's matches of the whole trip take ONE LDS atomic: per item a ballot and a running count
       unsigned long long mm[kInFlight];
+      bool mine[kInFlight];
       uint32_t run[kInFlight], wave_total = 0;
 #pragma unroll
       for (int j = 0; j < kInFlight; ++j) {
         const int i = i0 + j * kTS + tid;
         const uint32_t l = vv[j] >> (32 - shift);
         const bool in = i < ge;                          // (items past the segment: vv = 0 and in = false)
-        below += (uint32_t)__popcll(__ballot(in && l < local));      // wave-uniform: scalar popcounts, no lane sums
-        mm[j] = __ballot(in && l == local);
+        below += (uint32_t)__popcll(ballot(in && l < local));      // wave-uniform: scalar popcounts, no lane sums
+        mine[j] = in && l == local;
+        mm[j] = ballot(mine[j]);
         run[j] = wave_total;
         wave_total += (uint32_t)__popcll(mm[j]);
       }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
       base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
       for (int j = 0; j < kInFlight; ++j) {
-        if ((mm[j] >> (tid & 63)) & 1ull) {
+        if (mine[j]) {
           const uint32_t pos = base + run[j] + mask_rank(mm[j]);
           if (pos < (uint32_t)kFast) li[pos] = vv[j] & id_mask;
         }
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
         const int i = i0 + tid;
         const uint32_t v = i < ge ? staging[i] : 0u;
         const bool mine = i < ge && (v >> (32 - shift)) == local;
-        const unsigned long long m = __ballot(mine);
+        const unsigned long long m = ballot(mine);
         uint32_t base = 0;
         if ((tid & 63) == 0 && m) base = atomicAdd(&gcount[1], (uint32_t)__popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void transform_kernel(
     // rows of moving Gaussians are fetched, rotated and written; when the output is a different
     // buffer the other rows are copied through (wave_mask = all rows)
     const bool copy_all = sh_out != sh_in;
-    const unsigned long long need = copy_all ? __ballot(g < n) : __ballot(moving);
+    const unsigned long long need = copy_all ? ballot(g < n) : ballot(moving);
     if (need == 0ull) return;
     const int g0 = blockIdx.x * kBlock;
     const int kc = (sh_degree + 1) * (sh_degree + 1) - 1;      // coefficients above the DC term
