@@ -28,14 +28,27 @@ from . import _lib
 from .rendering import rasterization
 
 
+def locality_order(means: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """Permutation (int64 [N]: new position -> index in `means`) that puts the Gaussians in Morton (Z-curve) order of
+    their means: neighbours in space become neighbours in memory.  Same ordering as Gaussians.sorted_by_locality()."""
+    m = means.detach().to(torch.float32)
+    lo, hi = m.min(dim=0).values, m.max(dim=0).values
+    q = ((m - lo) / (hi - lo).clamp_min(1e-30) * float((1 << bits) - 1)).to(torch.int64).clamp_(0, (1 << bits) - 1)
+    code = torch.zeros(m.shape[0], dtype=torch.int64, device=m.device)
+    for b in range(bits):
+        for axis in range(3):
+            code |= ((q[:, axis] >> b) & 1) << (3 * b + axis)
+    return torch.argsort(code, stable=True)
+
+
 class FrameRenderer:
     def __init__(self, tensors: Dict, width: int, height: int, render_mode: str = "RGB",
                  frames_in_flight: int = 3, isect_capacity: Optional[int] = None,
                  capacity_margin: float = 1.5, background: Optional[torch.Tensor] = None,
                  sizing_camera=None, group_ids: Optional[torch.Tensor] = None, n_groups: int = 0,
-                 rotate_sh: bool = True, **raster_kw):
+                 rotate_sh: bool = True, reorder: Optional[str] = "morton", **raster_kw):
         """tensors: dict(means, quats, scales, opacities, colors, sh_degree) on the GPU
-        (Gaussians.to_torch()).  isect_capacity: slots reserved for tile intersections per
+        (Gaussians.to_torch()); `self.t` is the renderer's own (by default Morton-ordered) copy.  isect_capacity: slots reserved for tile intersections per
         frame; if None it is measured once with `sizing_camera` = (viewmat, K) (required then)
         and multiplied by `capacity_margin`.  A frame that needs more raises on fetch().
 
@@ -44,6 +57,23 @@ class FrameRenderer:
         the groups for that frame.  Every slot owns a posed copy of the Gaussians and its graph
         starts with mgs_transform_gaussians(rest pose -> copy) reading the slot's transform buffer,
         so a posed frame costs one small upload and 14-97 us of GPU time more than a static one."""
+        # reorder="morton" (default): the renderer keeps ITS OWN copy of the scene in Morton order of the means -- a
+        # one-off at construction, like any acceleration structure of a static scene.  Frames carry nothing per
+        # Gaussian, so nothing has to be mapped back; the image is the one the caller's order gives except where two
+        # Gaussians of a pixel tie in depth to the last bit (ties go by index).  With three frames in flight the sorted
+        # scene renders 4,400 instead of 3,880 frames/s at 1 M Gaussians: a tile's list entries gather from a narrow
+        # index range, a binning workgroup's pairs fall into few tile groups, culled Gaussians are culled by the wave.
+        # `self.order` maps the renderer's index to the caller's; reorder=None keeps the caller's order.
+        if reorder not in (None, "morton"):
+            raise ValueError(f"reorder {reorder!r} not in (None, 'morton')")
+        self.order = None
+        if reorder == "morton" and tensors["means"].shape[0] > 1:
+            self.order = locality_order(tensors["means"])
+            n = tensors["means"].shape[0]
+            tensors = {k: (v.index_select(0, self.order).contiguous()
+                           if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n else v) for k, v in tensors.items()}
+            if group_ids is not None:
+                group_ids = group_ids.index_select(0, self.order)
         self.t = tensors
         self.group_ids = group_ids.to(torch.int32).contiguous() if group_ids is not None else None
         self.n_groups = int(n_groups)

@@ -8,6 +8,8 @@ opts_list = [int(x, 0) for x in sys.argv[1:]] or [1, 5]     # 1: one wave per ti
 n, mu, W, H, deg = int(os.environ.get("N", 1_000_000)), float(os.environ.get("MU", 0.012)), int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080)), 3
 dev = "cuda"
 g = synthetic_scene(n, math.log(mu), deg, 0)
+if os.environ.get("MORTON", "1") != "0":      # the order FrameRenderer keeps its resident scene in
+    g = g.sorted_by_locality()
 cam = camera_ring(1, W, H, thetas=[0.3])[0]
 t = g.to_torch(dev, deg)
 vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)

@@ -6,6 +6,8 @@ from robosimgs_amd import synthetic_scene, camera_ring, ops
 n, mu, W, H, deg = 1_000_000, 0.012, 1920, 1080, 3
 dev = "cuda"
 g = synthetic_scene(n, math.log(mu), deg, 0)
+if os.environ.get("MORTON", "1") != "0":      # the order FrameRenderer keeps its resident scene in
+    g = g.sorted_by_locality()
 cam = camera_ring(1, W, H, thetas=[0.3])[0]
 t = g.to_torch(dev, deg)
 vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)

@@ -10,6 +10,8 @@ n, mu, W, H, deg = int(os.environ.get("N", 1_000_000)), float(os.environ.get("MU
 CH = int(os.environ.get("CH", 4))      # 4 = RGB + depth (the headline "RGB+ED" frames), 3 = RGB
 dev = "cuda"
 g = synthetic_scene(n, math.log(mu), deg, 0)
+if os.environ.get("MORTON", "1") != "0":      # the order FrameRenderer keeps its resident scene in
+    g = g.sorted_by_locality()
 cam = camera_ring(1, W, H, thetas=[0.3])[0]
 t = g.to_torch(dev, deg)
 vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)

@@ -129,7 +129,8 @@ def test_frame_renderer_poses_groups_per_frame():
         got.append((f["colors"].clone(), f["alphas"].clone()))
         r.release(tk)
     for (c, a), cam, (Rs, ts) in zip(got, cams, poses):
-        posed = transform_gaussians(t0, Rs, ts, group_ids=gid)
+        # (the renderer keeps its own Morton-ordered copy of the scene, group ids permuted with it: r.t, r.group_ids)
+        posed = transform_gaussians(r.t, Rs, ts, group_ids=r.group_ids)
         rc, ra, _ = rasterization(posed["means"], posed["quats"], posed["scales"], posed["opacities"],
                                   posed["colors"], _t(cam.viewmat())[None], _t(cam.K)[None], 256, 160,
                                   sh_degree=3, render_mode="RGB+ED")
