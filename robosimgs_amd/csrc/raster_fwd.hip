@@ -1,10 +1,11 @@
 // raster_fwd.hip -- per-tile depth-ordered alpha compositing, forward (A.2 step 9), gfx950.
-// Geometry, queue and culling: raster_common.h.  Vector-ALU-bound: 13 FMA-class + 7 compare/select-class
-// instructions + one v_exp per 64 pixel-Gaussian pairs = 65 cycles (2.4 / 4.1 / 8.15 cycles per class,
-// scripts/ubench/valu_issue.hip) against 44 bytes per tile-Gaussian pair, so the design spends its effort
-// on evaluating fewer pairs, on cheaper evaluations and on keeping enough waves resident, not on moving
-// bytes.  Two schedules of the same blend: raster_fwd_kernel (one wave per 16x16 tile, four pixels per lane:
-// fewest instructions) and raster_fwd_q_kernel (one wave per 8x8 block: shortest launch); DESIGN.md 4.3.
+// Geometry, queue and culling: raster_common.h.  Not bandwidth-bound: 16 vector instructions per 64 pixel-Gaussian
+// pairs (five FMAs for the exponent's polynomial about the tile centre, v_exp, the alpha test as v_cmpx, T (1 - alpha),
+// one compare, two selects, the colour FMAs: 11 FMA-class + 4 compare / select-class + one v_exp = 51 cycles by
+// scripts/ubench/valu_issue.hip) against 44 bytes per tile-Gaussian pair, so the design spends its effort on evaluating
+// fewer pairs, on cheaper evaluations and on keeping enough waves resident, not on moving bytes.  Two schedules of the
+// same blend: raster_fwd_kernel (one wave per 16x16 tile, four pixels per lane: fewest instructions, what several
+// frames in flight run) and raster_fwd_q_kernel (one wave per 8x8 block: shortest launch); DESIGN.md 4.3.
 #include <type_traits>
 
 #include "raster_common.h"
