@@ -22,12 +22,12 @@ namespace {
 
 template <int CHT>
 struct BwdEntry {
-  float4 geo0;                       // mean - tile centre (x, y), conic.a, conic.b
-  float4 geo1;                       // conic.c, L = log2(opacity), quadrant mask (bits), list index (bits)
-  float4 geo3;                       // q0, q1, q2 of the exponent's polynomial about the tile centre (raster_common.h)
+  float4 geo0;                       // q0, q1, q2 of the exponent's polynomial about the tile centre (raster_common.h), A
+  float4 geo1;                       // B, C, quadrant mask (bits), list index (bits); A = -0.5 log2e a, B = -log2e b, C = -0.5 log2e c
   float4 feat[(CHT + 3) / 4];
-  float4 geo2;                       // record slot / Gaussian id (bits), then the conic pre-scaled for exp2:
-};                                   //   A = -0.5 log2e a, B = -log2e b, C = -0.5 log2e c
+  float4 geo2;                       // record slot / Gaussian id (bits), mean - tile centre (x, y), L = log2(opacity)
+  float4 geo3;                       // conic a, b, c (absgrad and the atomic path only)
+};
 
 template <int CHT>
 struct BwdPixel {
@@ -38,9 +38,15 @@ struct BwdPixel {
   int last;
 };
 
+// What one (tile, Gaussian) pair accumulates over the tile's pixels: the MOMENTS of v_sigma = d loss / d sigma about the
+// tile centre (x, y = the pixel's offset from it, PixelPoly) and the colour gradient.  Everything else follows from
+// them once per pair (moments_to_mean below): with d = m - (x, y), m = mean - tile centre,
+//   sum v_sigma dx = m_x s - s_x,   sum v_sigma dx^2 = m_x (m_x s - s_x) - (m_x s_x - s_xx),   ...
+// and opacity * d loss / d opacity = -s.  Round 2 accumulated sum p, sum q, sum p dx, ... with p = v_sigma dx per
+// pixel: two subtractions and two products more per (pixel, Gaussian), plus an exp2 per pair for 1 / opacity.
 template <int CHT>
 struct GaussGrad {
-  float v_x, v_y, v_ca, v_cb, v_cc, v_op, a_x, a_y;
+  float s, s_x, s_y, s_xx, s_xy, s_yy, a_x, a_y;
   float v_f[CHT];
 };
 
@@ -48,13 +54,13 @@ struct GaussGrad {
 // contributes; inside, the per-lane condition is folded into two masked factors (alpha_eff and
 // the opacity*vis product) so that every update is an unconditional FMA into the accumulators --
 // the branchy form made the compiler zero-initialise and merge nine temporaries per quadrant.
-// Two algebraic savings over the textbook per-pixel form (A.2 step 10), 38 -> 27 VALU per call:
+// Algebraic savings over the textbook per-pixel form (A.2 step 10):
 //   * colour only enters through dot products with the pixel's v_c, so the "colour behind"
 //     buffer is kept as the scalar bv = buffer . v_c and the Gaussian's colour as fv = feat . v_c;
-//   * with p = v_sigma dx, q = v_sigma dy the mean gradient is (ca p + cb q, cb p + cc q): the
-//     conic is constant per Gaussian, so only S0 = sum p and S1 = sum q are accumulated (v_x,
-//     v_y) and the CONSUMER applies the conic once per Gaussian (finish_geo below); likewise
-//     v_ca / v_cc hold twice the conic gradient until then.
+//   * the geometric gradients are polynomials in the pixel's offset from the tile centre times v_sigma: only the six
+//     moments above are accumulated (the products x^2, xy, y^2 are per-lane constants the exponent's polynomial
+//     already keeps in registers) and the CONSUMER turns them into gradients once per pair and applies the conic
+//     once per Gaussian (moments_to_mean, finish_geo).
 // SAFE (chosen per 64-entry batch, as in the forward): every queued Gaussian has a conic that cannot round sigma
 // below zero and an opacity <= kSafeOpacity, so the sigma test and the 0.999 clamp are dead -- alpha = ov, nothing is
 // ever clamped, one select serves a_eff and ov_eff.  Same values bit for bit, six vector instructions less.
@@ -64,13 +70,12 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
                                            float cc, float A, float B, float C, float q0, float q1, float q2,
                                            const float* feat, int idx) {
   // mx, my: the mean's offset from the tile centre; pp: the pixel's (raster_common.h)
-  float dx = mx - pp.x, dy = my - pp.y;
   // the forward's own evaluation (raster_fwd.hip blend_pixel, raster_common.h pair_power_poly), bit for bit:
   // ov = opacity * exp(-sigma) as one exp2 of the exponent's polynomial about the tile centre
   float ov = __builtin_amdgcn_exp2f(pair_power_poly(pp, q0, q1, q2, A, B, C));
   float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
   bool valid = idx <= px.last && alpha >= kAlphaMin;
-  if (!SAFE) valid = valid && pair_power_sign(dx, dy, A, B, C) <= 0.f;
+  if (!SAFE) valid = valid && pair_power_sign(mx - pp.x, my - pp.y, A, B, C) <= 0.f;
   if (ballot(valid) == 0ull) return false;
   float a_eff = valid ? alpha : 0.f;                       // 0 => T, bv and v_f stay untouched
   bool grad_geo = valid && ov <= kAlphaMax;                // alpha not clamped: sigma/opacity get grads
@@ -87,18 +92,31 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
 #pragma unroll
   for (int c = 0; c < CHT; ++c) gg.v_f[c] = fmaf(fac, px.v_c[c], gg.v_f[c]);
   float v_sigma = -ov_eff * v_alpha;
-  float p = v_sigma * dx, q = v_sigma * dy;
-  gg.v_ca = fmaf(p, dx, gg.v_ca);
-  gg.v_cb = fmaf(p, dy, gg.v_cb);
-  gg.v_cc = fmaf(q, dy, gg.v_cc);
-  gg.v_x += p;
-  gg.v_y += q;
+  gg.s += v_sigma;
+  gg.s_x = fmaf(v_sigma, pp.x, gg.s_x);
+  gg.s_y = fmaf(v_sigma, pp.y, gg.s_y);
+  gg.s_xx = fmaf(v_sigma, pp.xx, gg.s_xx);
+  gg.s_xy = fmaf(v_sigma, pp.xy, gg.s_xy);
+  gg.s_yy = fmaf(v_sigma, pp.yy, gg.s_yy);
   if (ABSGRAD) {
+    float p = v_sigma * (mx - pp.x), q = v_sigma * (my - pp.y);
     gg.a_x += fabsf(fmaf(cb, q, ca * p));
     gg.a_y += fabsf(fmaf(cc, q, cb * p));
   }
-  gg.v_op = fmaf(ov_eff, v_alpha, gg.v_op);       // opacity * d loss / d opacity: the caller divides by the opacity once
   return valid;
+}
+
+// Moments of v_sigma about the tile centre -> sums about the Gaussian's mean, m = mean - tile centre:
+//   P = sum v_sigma dx, Q = sum v_sigma dy, Vaa = sum v_sigma dx^2, Vab = sum v_sigma dx dy, Vbb = sum v_sigma dy^2.
+// Written as nested differences (m_x P - (m_x s_x - s_xx)) so that the large m^2 s term never appears on its own.
+__device__ __forceinline__ void moments_to_mean(float mx, float my, float s, float s_x, float s_y, float s_xx,
+                                                float s_xy, float s_yy, float& P, float& Q, float& Vaa, float& Vab,
+                                                float& Vbb) {
+  P = fmaf(mx, s, -s_x);
+  Q = fmaf(my, s, -s_y);
+  Vaa = fmaf(mx, P, -fmaf(mx, s_x, -s_xx));
+  Vab = fmaf(my, P, -fmaf(mx, s_y, -s_xy));
+  Vbb = fmaf(my, Q, -fmaf(my, s_y, -s_yy));
 }
 
 // Record layout: slot-major records of `rs` floats (default).  MGS_BWD_SOA = 1 lays them out value-major (value p of
@@ -151,6 +169,9 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 #endif
 #ifndef MGS_RASTER_BWD_ORDER
 #define MGS_RASTER_BWD_ORDER 1         // launch the tiles by falling list length (tile_order_kernel): 623 -> 572 us
+#endif
+#ifdef MGS_RASTER_BWD_TIMING          // measurement build (scripts/dbg/bwd_timeline.py): per tile {start, end} on the 100 MHz clock, entries, pairs
+__device__ unsigned long long g_bwd_times[4 * 16384];
 #endif
 template <int CHT, bool ABSGRAD, bool RECORDS, bool HALF = false>
 __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WAVES) void raster_bwd_kernel(
@@ -229,6 +250,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
   for (int d = 32; d >= 1; d >>= 1) hi = max(hi, __shfl_xor(hi, d));
   hi = min(hi, end - 1);
   if (hi < start) return;
+#ifdef MGS_RASTER_BWD_TIMING
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned long long n_walked = 0, n_pairs = 0;
+#endif
 #ifdef MGS_RASTER_BWD_PRIO
   {   // issue priority by the length of the walk (see raster_fwd.hip)
     const int avg = tile_offsets[n_tiles] / n_tiles, len = hi - start + 1;
@@ -264,8 +289,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     t1 += dpp_f(t1, kDppXor1);
     t0 += dpp_f(t0, kDppXor2);
     t1 += dpp_f(t1, kDppXor2);
-    t0 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t0), 0x141, 0xf, 0xf, false));  // row_half_mirror
-    t1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t1), 0x141, 0xf, 0xf, false));
+    // (as text: the compiler sinks the last add into the storing lanes' branch and then cannot fold the DPP move into
+    //  it -- two v_mov 0, two v_mov_dpp and two adds instead of two v_add_f32_dpp)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(t0), "+v"(t1));
     if ((lane & 7) == 0) {
       const int p0 = rec_pos((int)(lane >> 3));
       if (p0 >= 0) records[rec_index(rslot, p0, rs, n_slots)] = t0;
@@ -315,6 +342,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     }
     const unsigned long long keep = ballot(qmask != 0u);
     const int count = __popcll(keep);
+#ifdef MGS_RASTER_BWD_TIMING
+    n_walked += (unsigned long long)min(64, hi - b + 1);
+    n_pairs += (unsigned long long)count;
+#endif
     const bool all_safe = ballot(qmask != 0u && !(sigma_sign_is_safe(ca, cb, cc) && op <= kSafeOpacity)) == 0ull;
     if (qmask != 0u) {
       BwdEntry<CHT>& e = queue[mask_rank(keep)];
@@ -322,15 +353,15 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
       const float sA = -0.5f * kLog2e * ca, sB = -kLog2e * cb, sC = -0.5f * kLog2e * cc, L = __log2f(op);
       const float m_x = xy.x - (tile_x + 8.f), m_y = xy.y - (tile_y + 8.f);
       const PolyCoef pc = poly_coefs(m_x, m_y, sA, sB, sC, L);
-      e.geo0 = make_float4(m_x, m_y, ca, cb);
-      e.geo1 = make_float4(cc, L, __uint_as_float(qmask), __int_as_float(idx));
-      e.geo3 = make_float4(pc.q0, pc.q1, pc.q2, 0.f);
+      e.geo0 = make_float4(pc.q0, pc.q1, pc.q2, sA);
+      e.geo1 = make_float4(sB, sC, __uint_as_float(qmask), __int_as_float(idx));
       int gid = g;
       if (RECORDS) {
         const int4 info = pair_info[g];
         gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
       }
-      e.geo2 = make_float4(__int_as_float(gid), sA, sB, sC);
+      e.geo2 = make_float4(__int_as_float(gid), m_x, m_y, L);
+      e.geo3 = make_float4(ca, cb, cc, 0.f);
       float f[((CHT + 3) / 4) * 4];
 #pragma unroll
       for (int c = 0; c < ((CHT + 3) / 4) * 4; ++c)
@@ -347,7 +378,9 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     constexpr bool SAFE = decltype(safe_tag)::value;
     for (int j = count - 1; j >= 0; --j) {
       const BwdEntry<CHT>& e = queue[j];
-      const float4 g0 = e.geo0, g1 = e.geo1, g2 = e.geo2, g3 = e.geo3;
+      const float4 g0 = e.geo0, g1 = e.geo1, g2 = e.geo2;
+      float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ABSGRAD || !RECORDS) g3 = e.geo3;
       float feat[CHT];
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
@@ -366,22 +399,21 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
       const int gi = __float_as_int(g1.w);
       const int gid = __builtin_amdgcn_readfirstlane(__float_as_int(g2.x));
       GaussGrad<CHT> gg;
-      gg.v_x = gg.v_y = gg.v_ca = gg.v_cb = gg.v_cc = gg.v_op = gg.a_x = gg.a_y = 0.f;
+      gg.s = gg.s_x = gg.s_y = gg.s_xx = gg.s_xy = gg.s_yy = gg.a_x = gg.a_y = 0.f;
 #pragma unroll
       for (int c = 0; c < CHT; ++c) gg.v_f[c] = 0.f;
       bool any = false;
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         if (m & (1u << k))
-          any |= grad_pixel<CHT, ABSGRAD, SAFE>(st[k], gg, pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g2.y, g2.z, g2.w,
-                                                g3.x, g3.y, g3.z, feat, gi);
+          any |= grad_pixel<CHT, ABSGRAD, SAFE>(st[k], gg, pq[k], g2.y, g2.z, g3.x, g3.y, g3.z, g0.w, g1.x, g1.y,
+                                                g0.x, g0.y, g0.z, feat, gi);
       }
       if (PIPE && pend) {
         red_finish(pend_slot, pa0, pb0, pa1, pb1);
         pend = false;
       }
       if (ballot(any) == 0ull) continue;
-      gg.v_op *= __builtin_amdgcn_exp2f(-g1.y);      // grad_pixel summed opacity * d/d opacity: divide by the opacity (2^L)
       if constexpr (RECORDS) {
         // overflowed tile lists (status word set by the binning): slot bases run up to the true
         // n_isect, the workspace only to the capacity -- nothing is written past it
@@ -390,11 +422,13 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         // reduce-scatter butterfly: 8 values at a time, totals land in 8 lanes that store the
         // record slice with one instruction
         float vals[NV];
-        vals[0] = gg.v_x; vals[1] = gg.v_y; vals[2] = gg.v_ca; vals[3] = gg.v_cb;
-        vals[4] = gg.v_cc; vals[5] = gg.v_op;
+        // the record holds the pair's raw moments; reduce_records_kernel turns them into gradients (it knows the
+        // pair's tile from the slot, hence m)
+        vals[0] = gg.s; vals[1] = gg.s_x; vals[2] = gg.s_y; vals[3] = gg.s_xx;
+        vals[4] = gg.s_xy; vals[5] = gg.s_yy;
 #pragma unroll
         for (int c = 0; c < CHT; ++c) vals[6 + c] = gg.v_f[c];
-        if (ABSGRAD) { vals[6 + CHT] = gg.a_x; vals[7 + CHT] = gg.a_y; }
+        if constexpr (ABSGRAD) { vals[6 + CHT] = gg.a_x; vals[7 + CHT] = gg.a_y; }
         int done = 0;
         // Through LDS, eight values per group: every lane parks its partial sums lane-linear
         // (red[i][lane], conflict-free), lane L then reads the eight partials red[L >> 3][8 (L & 7) ..]
@@ -458,16 +492,19 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         if (lane == 0) flags[rslot] = 1;
       } else {
         // plain wave reduction, then one atomic per component from lane 63
-        float rx = wave_reduce_to_lane63(gg.v_x), ry = wave_reduce_to_lane63(gg.v_y);
-        float ra = wave_reduce_to_lane63(gg.v_ca), rb = wave_reduce_to_lane63(gg.v_cb);
-        float rc = wave_reduce_to_lane63(gg.v_cc), ro = wave_reduce_to_lane63(gg.v_op);
+        const float ws = wave_reduce_to_lane63(gg.s), wx = wave_reduce_to_lane63(gg.s_x);
+        const float wy = wave_reduce_to_lane63(gg.s_y), wxx = wave_reduce_to_lane63(gg.s_xx);
+        const float wxy = wave_reduce_to_lane63(gg.s_xy), wyy = wave_reduce_to_lane63(gg.s_yy);
+        float rx, ry, ra, rb, rc;
+        moments_to_mean(g2.y, g2.z, ws, wx, wy, wxx, wxy, wyy, rx, ry, ra, rb, rc);
+        const float ro = -ws * __builtin_amdgcn_exp2f(-g2.w);     // opacity * d/d opacity = -sum v_sigma; opacity = 2^L
         float rf[CHT];
 #pragma unroll
         for (int c = 0; c < CHT; ++c) rf[c] = wave_reduce_to_lane63(gg.v_f[c]);
         float ax = 0.f, ay = 0.f;
         if (ABSGRAD) { ax = wave_reduce_to_lane63(gg.a_x); ay = wave_reduce_to_lane63(gg.a_y); }
         if (lane == 63) {
-          finish_geo(g0.z, g0.w, g1.x, rx, ry, ra, rc);
+          finish_geo(g3.x, g3.y, g3.z, rx, ry, ra, rc);
           unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 0], rx);
           unsafeAtomicAdd(&v_means2d[2 * (size_t)gid + 1], ry);
           unsafeAtomicAdd(&v_conics[3 * (size_t)gid + 0], ra);
@@ -497,20 +534,34 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     red_load(a0, b0, a1, b1);
     red_finish(pend_slot, a0, b0, a1, b1);
   }
+#ifdef MGS_RASTER_BWD_TIMING
+  if (lane == 0 && tile < 16384) {
+    g_bwd_times[4 * tile + 0] = t_begin;
+    g_bwd_times[4 * tile + 1] = __builtin_amdgcn_s_memrealtime();
+    g_bwd_times[4 * tile + 2] = n_walked;
+    g_bwd_times[4 * tile + 3] = n_pairs;
+  }
+#endif
 }
 
-// Sum the records of each Gaussian's slots (its tile rectangle, emit order) into the outputs.
+// Sum the records of each Gaussian's slots (its tile rectangle, emit order) into the outputs.  A record holds the
+// pair's moments of v_sigma about ITS tile's centre (GaussGrad); the slot's position in the rectangle gives the tile,
+// hence m = mean - tile centre (the very expression the raster kernel queued), moments_to_mean the pair's sums about the
+// mean; those add up over the pairs, then the conic is applied once (finish_geo) and -sum s / opacity is the opacity's
+// gradient.
 template <int CHT, bool ABSGRAD, int SLOTS = 1>      // SLOTS: record slots per (tile, Gaussian) pair (2: half tiles)
 __global__ __launch_bounds__(256) void reduce_records_kernel(
     int n, const int4* __restrict__ pair_info, const float* __restrict__ records,
-    const uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ conics,
+    const uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ means2d,
+    const float* __restrict__ conics, const float* __restrict__ opacities,
     const float4* __restrict__ splats, int channels, float* __restrict__ v_means2d,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
     float* __restrict__ v_feats, float* __restrict__ v_opacities) {
   int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= n) return;
   const int4 info = pair_info[g];
-  const int npair = (info.w & 0xffff) * ((unsigned)info.w >> 16);
+  const int rect_w = info.w & 0xffff;
+  const int npair = rect_w * ((unsigned)info.w >> 16);
   const int cnt = npair * SLOTS;
   const size_t first = (size_t)info.x * SLOTS;
   const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
@@ -520,10 +571,22 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   for (int i = 0; i < 6; ++i) acc[i] = 0.f;
 #pragma unroll
   for (int c = 0; c < CHT; ++c) af[c] = 0.f;
+  float mean_x = 0.f, mean_y = 0.f, ca = 1.f, cb = 0.f, cc = 1.f, op = 1.f;
+  if (cnt > 0) {
+    if (splats) {
+      const float4 p0 = splats[3 * (size_t)g], p1 = splats[3 * (size_t)g + 1];
+      mean_x = p0.x; mean_y = p0.y; ca = p0.z; cb = p0.w; cc = p1.x; op = p1.y;
+    } else {
+      mean_x = means2d[2 * (size_t)g]; mean_y = means2d[2 * (size_t)g + 1];
+      ca = conics[3 * (size_t)g]; cb = conics[3 * (size_t)g + 1]; cc = conics[3 * (size_t)g + 2];
+      op = opacities[g];
+    }
+  }
   // (loading the records unconditionally and selecting by the flag afterwards -- one round trip instead
   //  of two -- was measured: 618 -> 676 us for the whole backward; the extra 64 MB cost more)
   // four slots per trip with predicated loads: the flag and record loads of a trip are all in
   // flight together instead of one dependent round trip per slot (summation order is unchanged)
+  int col = 0, row = 0;                // the pair's tile inside the rectangle (slots are row-major, SLOTS per pair)
   for (int sl = 0; sl < cnt; sl += 4) {
     bool on[4];
 #pragma unroll
@@ -544,22 +607,21 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc[k] += r[i][k];
+      // m exactly as the raster kernel formed it: mean - (16 tile + 8)
+      const float mx = mean_x - ((float)((info.y + col) * 16) + 8.f), my = mean_y - ((float)((info.z + row) * 16) + 8.f);
+      float P, Q, Vaa, Vab, Vbb;
+      moments_to_mean(mx, my, r[i][0], r[i][1], r[i][2], r[i][3], r[i][4], r[i][5], P, Q, Vaa, Vab, Vbb);
+      acc[0] += P; acc[1] += Q; acc[2] += Vaa; acc[3] += Vab; acc[4] += Vbb; acc[5] += r[i][0];
 #pragma unroll
       for (int c = 0; c < CHT; ++c) af[c] += rf[i][c];
       if (ABSGRAD) { ab[0] += ra[i][0]; ab[1] += ra[i][1]; }
+      if (SLOTS == 1 || ((sl + i) % SLOTS) == SLOTS - 1)
+        if (++col == rect_w) { col = 0; ++row; }
     }
   }
-  if (cnt > 0) {   // records hold grad_pixel's raw sums: apply the Gaussian's conic once, here
-    float ca, cb, cc;
-    if (splats) {
-      const float4 p0 = splats[3 * (size_t)g];
-      ca = p0.z; cb = p0.w; cc = splats[3 * (size_t)g + 1].x;
-    } else {
-      ca = conics[3 * (size_t)g]; cb = conics[3 * (size_t)g + 1]; cc = conics[3 * (size_t)g + 2];
-    }
+  if (cnt > 0) {   // apply the Gaussian's conic once, here; opacity * d/d opacity = -sum v_sigma
     finish_geo(ca, cb, cc, acc[0], acc[1], acc[2], acc[4]);
+    acc[5] = -acc[5] / op;
   }
   reinterpret_cast<float2*>(v_means2d)[g] = make_float2(acc[0], acc[1]);
   v_conics[3 * (size_t)g + 0] = acc[2];
@@ -577,6 +639,12 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
 
 using namespace mgs;
 
+#ifdef MGS_RASTER_BWD_TIMING
+extern "C" int mgs_debug_bwd_times(unsigned long long* host, int n_words) {
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_times), (size_t)n_words * 8);
+  return e == hipSuccess ? 0 : (int)e;
+}
+#endif
 extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conics,
                                  const float* feats, const float* opacities,
                                  const float* background, int channels, int width, int height,
@@ -682,7 +750,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                      (float*)nullptr, info, records, flags, (uint32_t)cap, expected_render,    \
                      (const int32_t*)order);                                                   \
   hipLaunchKernelGGL((reduce_records_kernel<C, A, (int)kSlots>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
-                     info, records, flags, (uint32_t)cap, conics,                              \
+                     info, records, flags, (uint32_t)cap, means2d, conics, opacities,          \
                      reinterpret_cast<const float4*>(splats),                                  \
                      channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities)
 #define MGS_RD(C) if (v_means2d_abs) { MGS_RD_LAUNCH(C, true); } else { MGS_RD_LAUNCH(C, false); }

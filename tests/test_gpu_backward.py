@@ -278,7 +278,9 @@ def test_screen_space_gradients_are_published():
     g2d, gabs = meta["means2d_grad"][0], meta["means2d_absgrad"][0]
     assert torch.equal(meta["means2d"].grad[0], g2d) and torch.equal(meta["means2d"].absgrad[0], gabs)
     assert g2d.shape == (3000, 2) and float(g2d.abs().sum()) > 0
-    assert bool((gabs + 1e-6 >= g2d.abs()).all())
+    # |sum| <= sum |.|, up to rounding: the signed sums go through the tile-centred moments (raster_bwd.hip
+    # moments_to_mean), the absolute ones are summed per pixel
+    assert bool((gabs * (1 + 2e-5) + 2e-6 >= g2d.abs()).all()), float((g2d.abs() - gabs).max())
     assert bool((g2d[meta["radii"][0] == 0] == 0).all())
 
 
