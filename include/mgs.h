@@ -258,11 +258,13 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
 
 /* Deterministic raster backward (no float atomics; bit-reproducible).  Same inputs as
  * mgs_rasterize_bwd plus pair_info[N,4] from mgs_isect_tiles and the list capacity.  Every
- * (tile, Gaussian) pair writes one record of 6 + channels (+2 with absgrad) floats at its
- * slot; a second kernel sums each Gaussian's records.  Outputs are OVERWRITTEN for all N
- * rows (zeros where nothing contributed).  Workspace: two-phase size query as above
- * (capacity * (record floats * 4 + 1) bytes).  Scattered device atomics sustain only ~30 G/s
- * on MI355X, which makes the atomic variant 3x slower at 1 M Gaussians.  *   expected_render (nullable): the forward's render[H,W,channels] when it ran with
+ * (tile, Gaussian) pair writes one record at its slot -- the six moments of d loss / d sigma about
+ * the tile centre, the colour gradients (+2 with absgrad), padded to a multiple of four floats -- and a
+ * second kernel turns each record into the pair's gradients and sums each Gaussian's records.
+ * Outputs are OVERWRITTEN for all N rows (zeros where nothing contributed).  Workspace: two-phase
+ * size query as above (capacity * (record floats * 4 + 1) bytes; 16-byte aligned).  Scattered device
+ * atomics sustain only ~30 G/s on MI355X, which makes the atomic variant 3x slower at 1 M Gaussians.
+ *   expected_render (nullable): the forward's render[H,W,channels] when it ran with
  *   MGS_RASTER_EXPECTED_LAST -- v_render's last channel is then the cotangent of
  *   channel / max(alpha, 1e-10) and the kernel's prologue converts it (and v_alphas) back to the
  *   cotangents of the un-normalised blend: no pass over the frame in between.

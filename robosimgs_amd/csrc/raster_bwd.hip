@@ -88,7 +88,8 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   for (int c = 1; c < CHT; ++c) fv = fmaf(feat[c], px.v_c[c], fv);
   float v_alpha = fmaf(fv, px.T, px.tfv * ra);
   v_alpha = fmaf(-px.bv, ra, v_alpha);
-  px.bv = fmaf(fv, fac, px.bv);
+  asm volatile("" : "+v"(px.bv), "+v"(v_alpha));   // bv is updated in place AFTER its last use (the compiler formed
+  px.bv = fmaf(fv, fac, px.bv);                    // the new value early in a temporary and copied it back)
 #pragma unroll
   for (int c = 0; c < CHT; ++c) gg.v_f[c] = fmaf(fac, px.v_c[c], gg.v_f[c]);
   float v_sigma = -ov_eff * v_alpha;
@@ -119,15 +120,16 @@ __device__ __forceinline__ void moments_to_mean(float mx, float my, float s, flo
   Vbb = fmaf(my, Q, -fmaf(my, s_y, -s_yy));
 }
 
-// Record layout: slot-major records of `rs` floats (default).  MGS_BWD_SOA = 1 lays them out value-major (value p of
-// slot s at records[p * n_slots + s]) so that the reduce kernel's lanes read neighbouring words per value -- measured
-// and left off: the ten 4-byte stores of a record then land in ten different lines and the raster backward pays more
-// than the reduce gains (memset + backward + reduce 547 -> 686 us).
-#ifndef MGS_BWD_SOA
-#define MGS_BWD_SOA 0
-#endif
-__device__ __forceinline__ size_t rec_index(size_t slot, int p, int rs, size_t n_slots) {
-  return MGS_BWD_SOA ? (size_t)p * n_slots + slot : slot * (size_t)rs + (size_t)p;
+// Record layout: one record per (tile, Gaussian) slot, `record_floats` floats apart -- the 6 moments, the CHT colour
+// gradients (channels past `channels` are zero), the absgrad pair, padded to a multiple of FOUR floats so that the
+// reduce kernel reads a record as 16-byte pieces (three `global_load_dwordx4` per slot at 4 channels instead of ten
+// scattered `global_load_dword`: its lanes each walk their own Gaussian's slots, so every load instruction touches 64
+// different places and the kernel is bound by the number of those, not by bytes).  A value-major layout (value p of
+// slot s at records[p * n_slots + s]) was measured in round 3: the ten 4-byte stores of a record then land in ten
+// different lines and the raster backward pays more than the reduce gains (547 -> 686 us).
+__host__ __device__ constexpr int record_floats(int cht, bool absgrad) { return (6 + cht + (absgrad ? 2 : 0) + 3) / 4 * 4; }
+__host__ __device__ constexpr int padded_channels(int channels) {
+  return channels <= 4 ? channels : channels <= 8 ? 8 : channels <= 16 ? 16 : 32;
 }
 
 // Sums of grad_pixel's raw geometric accumulators -> gradients of mean2d and conic.
@@ -265,14 +267,9 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
 
   constexpr int NV = 6 + CHT + (ABSGRAD ? 2 : 0);      // values reduced over the wave per list entry
   constexpr bool PIPE = RECORDS && MGS_RASTER_BWD_PIPE != 0 && NV > 8 && NV <= 16;
-  const int rs = 6 + channels + (ABSGRAD ? 2 : 0);     // floats per record
-  const size_t n_slots = (size_t)capacity * (HALF ? 2 : 1);
-  // record position of value j: channels above `channels` are padding and are dropped,
-  // the absgrad pair follows the real channels
-  auto rec_pos = [&](int j) {
-    if (j < 6 + CHT) return j < 6 + channels ? j : -1;
-    return j - CHT + channels;
-  };
+  constexpr int RSP = record_floats(CHT, ABSGRAD);     // floats per record (stride)
+  // record position of value j: the values in the order they are reduced (padding channels hold zeros)
+  auto rec_pos = [&](int j) { return j; };
   // the two halves of the 9..16-value reduction (see below): read back the parked partial sums ...
   auto red_load = [&](float4& a0, float4& b0, float4& a1, float4& b1) {
     const int v1 = 8 + (int)(lane >> 3);                          // second group's value for this lane
@@ -295,10 +292,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
                  "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(t0), "+v"(t1));
     if ((lane & 7) == 0) {
       const int p0 = rec_pos((int)(lane >> 3));
-      if (p0 >= 0) records[rec_index(rslot, p0, rs, n_slots)] = t0;
+      if (p0 >= 0) records[rslot * RSP + p0] = t0;
       if (v1 < NV) {
         const int p1 = rec_pos(v1);
-        if (p1 >= 0) records[rec_index(rslot, p1, rs, n_slots)] = t1;
+        if (p1 >= 0) records[rslot * RSP + p1] = t1;
       }
     }
     if (lane == 0) flags[rslot] = 1;
@@ -470,7 +467,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
           t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x141, 0xf, 0xf, false));  // row_half_mirror
           if ((lane & 7) == 0) {
             int pos = rec_pos(done + (int)(lane >> 3));
-            if (pos >= 0) records[rec_index(rslot, pos, rs, n_slots)] = t;
+            if (pos >= 0) records[rslot * RSP + pos] = t;
           }
           __builtin_amdgcn_wave_barrier();          // the next round overwrites red
           done += 8;
@@ -481,7 +478,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
           int i = wave_reduce_scatter_index<V>(lane);                          \
           if (i >= 0) {                                                        \
             int pos = rec_pos(done + i);                                       \
-            if (pos >= 0) records[rec_index(rslot, pos, rs, n_slots)] = t;                                        \
+            if (pos >= 0) records[rslot * RSP + pos] = t;                                        \
           }                                                                    \
           done += V;                                                           \
         }
@@ -564,8 +561,8 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   const int npair = rect_w * ((unsigned)info.w >> 16);
   const int cnt = npair * SLOTS;
   const size_t first = (size_t)info.x * SLOTS;
-  const int rs = 6 + channels + (ABSGRAD ? 2 : 0);
-  const size_t n_slots = (size_t)capacity * SLOTS;
+  constexpr int RSP = record_floats(CHT, ABSGRAD), R4 = RSP / 4;
+  const float4* rec4 = reinterpret_cast<const float4*>(records);
   float acc[6], af[CHT], ab[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[i] = 0.f;
@@ -592,17 +589,14 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i)      // slots at or past the capacity do not exist (overflowed lists)
       on[i] = sl + i < cnt && (uint32_t)(info.x + (sl + i) / SLOTS) < capacity && flags[first + sl + i] != 0;
-    float r[4][6], rf[4][CHT], ra[4][2];
+    float r[4][RSP];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t slot = first + sl + i;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) r[i][k] = on[i] ? records[rec_index(slot, k, rs, n_slots)] : 0.f;
-#pragma unroll
-      for (int c = 0; c < CHT; ++c) rf[i][c] = (on[i] && c < channels) ? records[rec_index(slot, 6 + c, rs, n_slots)] : 0.f;
-      if (ABSGRAD) {
-        ra[i][0] = on[i] ? records[rec_index(slot, 6 + channels, rs, n_slots)] : 0.f;
-        ra[i][1] = on[i] ? records[rec_index(slot, 7 + channels, rs, n_slots)] : 0.f;
+      for (int k = 0; k < R4; ++k) {
+        const float4 v = on[i] ? rec4[slot * R4 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[i][4 * k] = v.x; r[i][4 * k + 1] = v.y; r[i][4 * k + 2] = v.z; r[i][4 * k + 3] = v.w;
       }
     }
 #pragma unroll
@@ -613,8 +607,8 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
       moments_to_mean(mx, my, r[i][0], r[i][1], r[i][2], r[i][3], r[i][4], r[i][5], P, Q, Vaa, Vab, Vbb);
       acc[0] += P; acc[1] += Q; acc[2] += Vaa; acc[3] += Vab; acc[4] += Vbb; acc[5] += r[i][0];
 #pragma unroll
-      for (int c = 0; c < CHT; ++c) af[c] += rf[i][c];
-      if (ABSGRAD) { ab[0] += ra[i][0]; ab[1] += ra[i][1]; }
+      for (int c = 0; c < CHT; ++c) af[c] += r[i][6 + c];
+      if constexpr (ABSGRAD) { ab[0] += r[i][6 + CHT]; ab[1] += r[i][7 + CHT]; }
       if (SLOTS == 1 || ((sl + i) % SLOTS) == SLOTS - 1)
         if (++col == rect_w) { col = 0; ++row; }
     }
@@ -704,7 +698,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
               "rasterize_bwd_det: tile grid does not match the image at tile size 16");
   MGS_REQUIRE(workspace_bytes, "rasterize_bwd_det: workspace_bytes is null");
-  const int rs = 6 + channels + (v_means2d_abs ? 2 : 0);
+  const int rs = record_floats(padded_channels(channels), v_means2d_abs != nullptr);   // floats per record
   const size_t cap = isect_capacity ? isect_capacity : 1;
   constexpr bool kHalf = MGS_RASTER_BWD_HALF != 0;
   constexpr size_t kSlots = kHalf ? 2 : 1;
@@ -719,6 +713,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
     return set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "rasterize_bwd_det: workspace %zu < %zu bytes",
                      *workspace_bytes, need);
   if (n == 0) return MGS_OK;
+  MGS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0, "rasterize_bwd_det: workspace must be 16-byte aligned");
   MGS_REQUIRE(!splats || channels <= 4, "rasterize_bwd_det: packed splats carry at most 4 channels");
   MGS_REQUIRE((splats || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
                   alphas && last_ids && v_render && pair_info && v_means2d && v_conics &&
