@@ -1,8 +1,9 @@
 // raster_fwd.hip -- per-tile depth-ordered alpha compositing, forward (A.2 step 9), gfx950.
-// Geometry, queue and culling: raster_common.h.  Not bandwidth-bound: 16 vector instructions per 64 pixel-Gaussian
-// pairs (five FMAs for the exponent's polynomial about the tile centre, v_exp, the alpha test as v_cmpx, T (1 - alpha),
-// one compare, two selects, the colour FMAs: 11 FMA-class + 4 compare / select-class + one v_exp = 51 cycles by
-// scripts/ubench/valu_issue.hip) against 44 bytes per tile-Gaussian pair, so the design spends its effort on evaluating
+// Geometry, queue and culling: raster_common.h.  Not bandwidth-bound: 15 vector instructions per 64 pixel-Gaussian
+// pairs (five FMAs for the exponent's polynomial about the tile centre, v_exp, the alpha test and the T (1 - alpha) > 1e-4
+// test as v_cmpx under an EXEC that starts as the quadrant's open pixels, one move, the colour FMAs: 12 FMA-class + 2
+// compare-class + one v_exp = 45 cycles by scripts/ubench/valu_issue.hip) against 44 bytes per tile-Gaussian pair, so
+// the design spends its effort on evaluating
 // fewer pairs, on cheaper evaluations and on keeping enough waves resident, not on moving bytes.  Two schedules of the
 // same blend: raster_fwd_kernel (one wave per 16x16 tile, four pixels per lane: fewest instructions, what several
 // frames in flight run) and raster_fwd_q_kernel (one wave per 8x8 block: shortest launch); DESIGN.md 4.3.
@@ -49,9 +50,12 @@ struct QueueEntry {
   float4 geo3;                       // mean - tile centre (x, y): read only by batches that test sigma >= 0
 };
 
-// Per-pixel state.  T > 0: transmittance, pixel still open.  T < 0: pixel finished, |T| is its
-// final transmittance (the "done" flag of A.2 step 9 lives in the sign bit, so the blend needs
-// no separate flag and a finished pixel can never accumulate again: T*(1-alpha) < 0 < 1e-4).
+// Per-pixel state.  Two ways to remember that a pixel is finished (A.2 step 9's "done" flag):
+//   * sign of T (kernels without the hand-written body): T > 0 open, T < 0 finished with |T| its final transmittance --
+//     no separate flag, and a finished pixel can never accumulate again: T*(1-alpha) < 0 < 1e-4;
+//   * `alive` (kMasks kernels: 3 and 4 channels): one 64-bit lane mask per quadrant in SGPRs, T stays positive.  The
+//     blend runs with EXEC = alive & (alpha >= 1/255) & (T (1 - alpha) > 1e-4), so "finished" costs no vector
+//     instruction at all -- the sign form pays a compare-class select on w and one on T per 64 pairs.
 template <int CHT>
 struct PixelState {
   float T;
@@ -81,9 +85,9 @@ __device__ unsigned long long g_raster_stats[8];
 //   "sigma >= 0" is "pair_power_sign <= 0".
 // TRACK_LAST: record the list index of the last blended Gaussian (the backward starts there);
 // an inference render drops that select (compares / selects issue at half the FMA rate on gfx950).
-template <int CHT, bool TRACK_LAST, bool SAFE = false>
-__device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, const PixelPoly& pp, float q0, float q1,
-                                            float q2, float A, float B, float C, float m_x, float m_y,
+template <int CHT, bool TRACK_LAST, bool SAFE = false, bool MASKS = false>
+__device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, unsigned long long& alive, const PixelPoly& pp, float q0,
+                                            float q1, float q2, float A, float B, float C, float m_x, float m_y,
                                             const float* feat, int idx) {
   // SAFE: the conic cannot round sigma below zero (sigma_sign_is_safe) and opacity <= kSafeOpacity: the sigma test
   // is dead and exp2(power) <= opacity (1 + 2^-22) < 0.999, so the clamp is the identity too
@@ -91,17 +95,23 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, const PixelPoly
   float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
   bool valid = alpha >= kAlphaMin;
   if (!SAFE) valid = valid && pair_power_sign(m_x - pp.x, m_y - pp.y, A, B, C) <= 0.f;
+  if (MASKS) valid = valid && __builtin_amdgcn_inverse_ballot_w64(alive);     // the mask IS the condition register
   // alpha forced to 0 where the Gaussian does not count: an open pixel (T > 1e-4 by invariant)
   // then keeps T and adds nothing, with no second mask to combine
   float a_eff = valid ? alpha : 0.f;
   float next_T = fmaf(-a_eff, px.T, px.T);
-  bool acc = next_T > kTStop;                     // false for finished pixels (T < 0) and for the closing Gaussian
+  bool acc = next_T > kTStop;                     // false for the closing Gaussian (and, in the sign form, for finished pixels)
   float w = a_eff * px.T;
   w = acc ? w : 0.f;      // (w = |T| - |T_new| -- a subtraction instead of a multiply and a select -- puts the weight
                           //  behind the T select on the dependency chain: measured 218 -> 226 us, 3,575 -> 3,417 frames/s)
 #pragma unroll
   for (int c = 0; c < CHT; ++c) px.C[c] = fmaf(w, feat[c], px.C[c]);
-  px.T = acc ? next_T : -fabsf(px.T);             // not accumulated: the pixel is (or stays) finished
+  if (MASKS) {
+    px.T = acc ? next_T : px.T;                   // a pixel this Gaussian closes keeps the T it had and leaves the mask
+    alive &= ~ballot(!acc);
+  } else {
+    px.T = acc ? next_T : -fabsf(px.T);           // not accumulated: the pixel is (or stays) finished
+  }
   if (TRACK_LAST) px.last = (acc && valid) ? idx : px.last;
 #ifdef MGS_RASTER_STATS
   px.n_valid += valid && px.T > 0.f;
@@ -112,22 +122,31 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, const PixelPoly
 #ifndef MGS_RASTER_CMPX
 #define MGS_RASTER_CMPX 1
 #endif
-// The SAFE blend (3 or 4 channels; inference and, with one more select for last_ids, training) as hand-written gfx950 code: the same arithmetic in the same order as
-// blend_pixel<CHT, false, true> -- bit-identical pixels -- with the alpha >= 1/255 test as a v_cmpx that narrows
-// EXEC to the lanes that count instead of a compare plus a select on alpha (a Gaussian that does not count leaves
-// the pixel untouched: with a_eff = 0 the generic form adds 0 and re-selects the T it had).  18 vector
-// instructions per 64 pairs instead of 17 (16 = 5 exponent + exp + 10), and the ~60 % of lanes that fail the test stay idle for the ten
-// instructions behind it.  gfx940+ needs two wait states between a VALU write of VCC and a VALU read of it, one
-// after a transcendental: filled with independent work where there is some.
+// Kernels of 3 and 4 channels keep "finished" in lane masks (PixelState above) and run the SAFE blend as the
+// hand-written body below.
+template <int CHT>
+constexpr bool kMasks = MGS_RASTER_CMPX != 0 && (CHT == 3 || CHT == 4);
+
+// The SAFE blend (3 or 4 channels; inference and, with one more move for last_ids, training) as hand-written gfx950
+// code: the same arithmetic in the same order as blend_pixel<CHT, ., true> -- bit-identical pixels -- under an EXEC that
+// is narrowed three times instead of selects: to the quadrant's open pixels (s_mov from `alive`), by the alpha >= 1/255
+// test (v_cmpx; a Gaussian that does not count leaves the pixel untouched) and by the T (1 - alpha) > 1e-4 test
+// (v_cmpx again: what is left accumulates; the lanes the second test dropped are the pixels this Gaussian closes and
+// leave `alive`).  15 vector instructions per 64 pairs -- 12 FMA-class, two compares, one v_exp: 45 cycles by
+// scripts/ubench/valu_issue.hip; the round-3 form with the sign of T as the flag had two selects more (16, 51 cycles).
+// gfx940+ needs one wait state after a transcendental before its result is read.
 template <int CHT, bool TRACK_LAST>
-__device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, const PixelPoly& pp, float q0, float q1,
-                                                     float q2, float A, float B, float C, const float* feat, int idx) {
+__device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, unsigned long long& alive, const PixelPoly& pp,
+                                                     float q0, float q1, float q2, float A, float B, float C,
+                                                     const float* feat, int idx) {
   static_assert(CHT == 3 || CHT == 4, "hand-written blend: 3 or 4 channels");
   float dx, t0, t1;               // dx: the weight w, t0: T (1 - alpha), t1: exponent, then alpha
+  unsigned long long acc;         // lanes that accumulate
   const float amin = kAlphaMin, tstop = kTStop;
   float c3 = CHT == 4 ? px.C[CHT - 1] : 0.f;
   const float f3 = CHT == 4 ? feat[CHT - 1] : 0.f;
   asm volatile(
+      "s_mov_b64 exec, %[alive]\n"
       "v_fma_f32 %[t1], %[q1], %[x], %[q0]\n"          // pair_power_poly, same order
       "v_fmac_f32 %[t1], %[q2], %[y]\n"
       "v_fmac_f32 %[t1], %[A], %[xx]\n"
@@ -135,13 +154,11 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, const 
       "v_fmac_f32 %[t1], %[C], %[yy]\n"
       "v_exp_f32 %[t1], %[t1]\n"
       "s_nop 0\n"
-      "v_cmpx_le_f32 vcc, %[amin], %[t1]\n"
+      "v_cmpx_le_f32 vcc, %[amin], %[t1]\n"            // EXEC = VCC = open pixels the Gaussian counts for
       "v_fma_f32 %[t0], -%[t1], %[T], %[T]\n"
       "v_mul_f32 %[dx], %[t1], %[T]\n"
-      "v_cmp_lt_f32 vcc, %[tstop], %[t0]\n"
-      "s_nop 1\n"
-      "v_cndmask_b32 %[dx], 0, %[dx], vcc\n"
-      "v_cndmask_b32_e64 %[T], -|%[T]|, %[t0], vcc\n"
+      "v_cmpx_lt_f32_e64 %[acc], %[tstop], %[t0]\n"    // EXEC = acc = those of them that accumulate
+      "v_mov_b32 %[T], %[t0]\n"
       "v_fmac_f32 %[c0], %[dx], %[f0]\n"
       "v_fmac_f32 %[c1], %[dx], %[f1]\n"
       "v_fmac_f32 %[c2], %[dx], %[f2]\n"
@@ -149,16 +166,18 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, const 
       "v_fmac_f32 %[c3], %[dx], %[f3]\n"
       ".endif\n"
       ".if %[track]\n"
-      "v_cndmask_b32 %[last], %[last], %[idx], vcc\n"     // EXEC = valid lanes, VCC = accumulated
+      "v_mov_b32 %[last], %[idx]\n"
       ".endif\n"
+      "s_xor_b64 vcc, vcc, %[acc]\n"                   // counted but not accumulated: the pixels this Gaussian closes
+      "s_andn2_b64 %[alive], %[alive], vcc\n"
       "s_mov_b64 exec, -1\n"
-      : [dx] "=&v"(dx), [t0] "=&v"(t0), [t1] "=&v"(t1),
+      : [dx] "=&v"(dx), [t0] "=&v"(t0), [t1] "=&v"(t1), [acc] "=&s"(acc), [alive] "+s"(alive),
         [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3), [last] "+v"(px.last)
       : [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [x] "v"(pp.x), [y] "v"(pp.y), [xx] "v"(pp.xx), [xy] "v"(pp.xy),
         [yy] "v"(pp.yy), [A] "v"(A), [B] "v"(B), [C] "v"(C),
         [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
         [four] "n"(CHT == 4 ? 1 : 0), [track] "n"(TRACK_LAST ? 1 : 0), [idx] "v"(idx)
-      : "vcc");
+      : "vcc", "scc");            // (s_xor / s_andn2 write SCC: the loop counter's compare must not straddle the body)
   if (CHT == 4) px.C[CHT - 1] = c3;
 }
 
@@ -205,10 +224,12 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
   stat[6] = (unsigned)(end - start + kQueue - 1) / kQueue;
 #endif
   PixelState<CHT> st[4];
+  unsigned long long alive[4];                   // kMasks: the quadrant's open pixels
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool inside = ix + 8 * (k & 1) < width && iy + 8 * (k >> 1) < height;
-    st[k].T = inside ? 1.f : -1.f;               // pixels outside the image start finished
+    st[k].T = (inside || kMasks<CHT>) ? 1.f : -1.f;    // pixels outside the image start finished
+    alive[k] = ballot(inside);
     st[k].last = 0;
 #pragma unroll
     for (int c = 0; c < CHT; ++c) st[k].C[c] = 0.f;
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     unsigned live = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (ballot(st[k].T > 0.f) != 0ull) live |= 1u << k;
+      if ((kMasks<CHT> ? alive[k] : ballot(st[k].T > 0.f)) != 0ull) live |= 1u << k;
     if (live == 0) break;
 
     // take the prefetched batch, start the next one
@@ -322,10 +343,11 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (m & (1u << k)) {
-          if constexpr (MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4))
-            blend_pixel_safe_asm<CHT, TRACK_LAST>(st[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, idx);
+          if constexpr (kMasks<CHT> && SAFE)
+            blend_pixel_safe_asm<CHT, TRACK_LAST>(st[k], alive[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, idx);
           else
-            blend_pixel<CHT, TRACK_LAST, SAFE>(st[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x, g3.y, feat, idx);
+            blend_pixel<CHT, TRACK_LAST, SAFE, kMasks<CHT>>(st[k], alive[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x,
+                                                             g3.y, feat, idx);
         }
     };
     auto walk = [&](auto safe_tag) {
@@ -446,7 +468,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
   const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
 
   PixelState<CHT> st;
-  st.T = inside ? 1.f : -1.f;
+  st.T = (inside || kMasks<CHT>) ? 1.f : -1.f;
+  unsigned long long alive = ballot(inside);     // kMasks: the block's open pixels
   st.last = 0;
 #pragma unroll
   for (int c = 0; c < CHT; ++c) st.C[c] = 0.f;
@@ -481,7 +504,7 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
   fetch(r_idx, r_ok);
 
   for (int b = start; b < end; b += kQueue) {
-    if (ballot(st.T > 0.f) == 0ull) break;          // every pixel of the block is finished
+    if ((kMasks<CHT> ? alive : ballot(st.T > 0.f)) == 0ull) break;          // every pixel of the block is finished
     const int c_idx = r_idx;
     const bool c_ok = r_ok;
     const float2 c_xy = r_xy;
@@ -540,7 +563,7 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
       // for the inference variant (whose loop the compiler unrolls four times when left whole).
       constexpr int kChunk = TRACK_LAST ? 8 : kQueue;
       for (int j0 = 0; j0 < count; j0 += kChunk) {
-        if (j0 && ballot(st.T > 0.f) == 0ull) break;
+        if (j0 && (kMasks<CHT> ? alive : ballot(st.T > 0.f)) == 0ull) break;
         const int j1 = min(j0 + kChunk, count);
       for (int j = j0; j < j1; ++j) {
         const QueueEntry<CHT>& e = queue[j];
@@ -556,12 +579,13 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
           if (4 * f + 2 < CHT) feat[4 * f + 2] = v.z;
           if (4 * f + 3 < CHT) feat[4 * f + 3] = v.w;
         }
-        if constexpr (MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4)) {
-          blend_pixel_safe_asm<CHT, TRACK_LAST>(st, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
+        if constexpr (kMasks<CHT> && SAFE) {
+          blend_pixel_safe_asm<CHT, TRACK_LAST>(st, alive, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
         } else {
           float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
           if constexpr (!SAFE) g3 = e.geo3;
-          blend_pixel<CHT, TRACK_LAST, SAFE>(st, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x, g3.y, feat, __float_as_int(g1.w));
+          blend_pixel<CHT, TRACK_LAST, SAFE, kMasks<CHT>>(st, alive, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x, g3.y, feat,
+                                                           __float_as_int(g1.w));
         }
       }
       }
