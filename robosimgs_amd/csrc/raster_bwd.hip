@@ -546,6 +546,9 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
 // hence m = mean - tile centre (the very expression the raster kernel queued), moments_to_mean the pair's sums about the
 // mean; those add up over the pairs, then the conic is applied once (finish_geo) and -sum s / opacity is the opacity's
 // gradient.
+#ifndef MGS_REDUCE_EXP
+#define MGS_REDUCE_EXP 0
+#endif
 template <int CHT, bool ABSGRAD, int SLOTS = 1>      // SLOTS: record slots per (tile, Gaussian) pair (2: half tiles)
 __global__ __launch_bounds__(256) void reduce_records_kernel(
     int n, const int4* __restrict__ pair_info, const float* __restrict__ records,
@@ -583,19 +586,34 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   //  of two -- was measured: 618 -> 676 us for the whole backward; the extra 64 MB cost more)
   // four slots per trip with predicated loads: the flag and record loads of a trip are all in
   // flight together instead of one dependent round trip per slot (summation order is unchanged)
+  // The four flags of a trip are ONE aligned 4-byte load: trips cover the aligned groups of four slots that overlap
+  // the Gaussian's range (a group's slots outside the range are skipped), not four byte loads whose 64 lanes each
+  // touch a different place -- the kernel is bound by the number of such scattered loads (round-3 ablation: 34 of its
+  // 65 us remained with the record loads removed).
   int col = 0, row = 0;                // the pair's tile inside the rectangle (slots are row-major, SLOTS per pair)
-  for (int sl = 0; sl < cnt; sl += 4) {
+  const int lead = (int)(first & 3);   // slots of the first group that belong to the previous Gaussian
+  for (int sl = -lead; sl < cnt; sl += 4) {
     bool on[4];
+#if MGS_REDUCE_EXP == 2      // measurement: no flag loads (every slot read)
+    const uint32_t fw = 0x01010101u;
+#else
+    // (first + sl) is a multiple of 4; groups past the capacity (overflowed lists) lie outside the workspace
+    const uint32_t fw = first + sl < (size_t)capacity * SLOTS ? *reinterpret_cast<const uint32_t*>(flags + (first + sl)) : 0u;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)      // slots at or past the capacity do not exist (overflowed lists)
-      on[i] = sl + i < cnt && (uint32_t)(info.x + (sl + i) / SLOTS) < capacity && flags[first + sl + i] != 0;
+      on[i] = sl + i >= 0 && sl + i < cnt && (uint32_t)(info.x + (sl + i) / SLOTS) < capacity && ((fw >> (8 * i)) & 0xffu) != 0;
     float r[4][RSP];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t slot = first + sl + i;
 #pragma unroll
       for (int k = 0; k < R4; ++k) {
+#if MGS_REDUCE_EXP == 1      // measurement: no record loads
+        const float4 v = make_float4(on[i] ? 1.f : 0.f, 0.f, 0.f, 0.f);
+#else
         const float4 v = on[i] ? rec4[slot * R4 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         r[i][4 * k] = v.x; r[i][4 * k + 1] = v.y; r[i][4 * k + 2] = v.z; r[i][4 * k + 3] = v.w;
       }
     }
@@ -609,7 +627,7 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
 #pragma unroll
       for (int c = 0; c < CHT; ++c) af[c] += r[i][6 + c];
       if constexpr (ABSGRAD) { ab[0] += r[i][6 + CHT]; ab[1] += r[i][7 + CHT]; }
-      if (SLOTS == 1 || ((sl + i) % SLOTS) == SLOTS - 1)
+      if (sl + i >= 0 && (SLOTS == 1 || ((sl + i) % SLOTS) == SLOTS - 1))
         if (++col == rect_w) { col = 0; ++row; }
     }
   }
@@ -617,6 +635,9 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
     finish_geo(ca, cb, cc, acc[0], acc[1], acc[2], acc[4]);
     acc[5] = -acc[5] / op;
   }
+#if MGS_REDUCE_EXP == 3      // measurement: (nearly) no stores
+  if (acc[0] != 12345.f) return;
+#endif
   reinterpret_cast<float2*>(v_means2d)[g] = make_float2(acc[0], acc[1]);
   v_conics[3 * (size_t)g + 0] = acc[2];
   v_conics[3 * (size_t)g + 1] = acc[3];

@@ -122,6 +122,12 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, unsigned long l
 #ifndef MGS_RASTER_CMPX
 #define MGS_RASTER_CMPX 1
 #endif
+#ifndef MGS_RASTER_Q_BREAK
+#define MGS_RASTER_Q_BREAK 0        // one wave per 8x8 block: leave the batch at the entry that closes the block's last pixel
+#endif
+#ifndef MGS_RASTER_LIVE_BITS
+#define MGS_RASTER_LIVE_BITS 1      // one wave per tile: a quadrant whose last pixel closes is skipped for the rest of the batch
+#endif
 // Kernels of 3 and 4 channels keep "finished" in lane masks (PixelState above) and run the SAFE blend as the
 // hand-written body below.
 template <int CHT>
@@ -135,8 +141,12 @@ constexpr bool kMasks = MGS_RASTER_CMPX != 0 && (CHT == 3 || CHT == 4);
 // leave `alive`).  15 vector instructions per 64 pairs -- 12 FMA-class, two compares, one v_exp: 45 cycles by
 // scripts/ubench/valu_issue.hip; the round-3 form with the sign of T as the flag had two selects more (16, 51 cycles).
 // gfx940+ needs one wait state after a transcendental before its result is read.
-template <int CHT, bool TRACK_LAST>
-__device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, unsigned long long& alive, const PixelPoly& pp,
+// LIVE_BIT >= 0 (one wave per tile): bit LIVE_BIT of `live` is cleared the moment the quadrant's last pixel closes, so
+// that the rest of the batch skips the quadrant (the caller ands every entry's quadrant mask with `live`: scalar
+// instructions only; re-deriving the live quadrants with ballots every 8 / 16 / 32 entries was a loss in round 3).
+template <int CHT, bool TRACK_LAST, int LIVE_BIT = -1>
+__device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, unsigned long long& alive, unsigned& live,
+                                                     const PixelPoly& pp,
                                                      float q0, float q1, float q2, float A, float B, float C,
                                                      const float* feat, int idx) {
   static_assert(CHT == 3 || CHT == 4, "hand-written blend: 3 or 4 channels");
@@ -169,14 +179,19 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, unsign
       "v_mov_b32 %[last], %[idx]\n"
       ".endif\n"
       "s_xor_b64 vcc, vcc, %[acc]\n"                   // counted but not accumulated: the pixels this Gaussian closes
-      "s_andn2_b64 %[alive], %[alive], vcc\n"
+      "s_andn2_b64 %[alive], %[alive], vcc\n"          // (SCC = some pixel of the quadrant is still open)
+      ".if %[livebit] >= 0\n"
+      "s_cselect_b32 vcc_lo, -1, %[clr]\n"
+      "s_and_b32 %[live], %[live], vcc_lo\n"
+      ".endif\n"
       "s_mov_b64 exec, -1\n"
-      : [dx] "=&v"(dx), [t0] "=&v"(t0), [t1] "=&v"(t1), [acc] "=&s"(acc), [alive] "+s"(alive),
+      : [dx] "=&v"(dx), [t0] "=&v"(t0), [t1] "=&v"(t1), [acc] "=&s"(acc), [alive] "+s"(alive), [live] "+s"(live),
         [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3), [last] "+v"(px.last)
       : [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [x] "v"(pp.x), [y] "v"(pp.y), [xx] "v"(pp.xx), [xy] "v"(pp.xy),
         [yy] "v"(pp.yy), [A] "v"(A), [B] "v"(B), [C] "v"(C),
         [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
-        [four] "n"(CHT == 4 ? 1 : 0), [track] "n"(TRACK_LAST ? 1 : 0), [idx] "v"(idx)
+        [four] "n"(CHT == 4 ? 1 : 0), [track] "n"(TRACK_LAST ? 1 : 0), [idx] "v"(idx), [livebit] "n"(LIVE_BIT),
+        [clr] "n"(LIVE_BIT >= 0 ? ~(1 << LIVE_BIT) : -1)
       : "vcc", "scc");            // (s_xor / s_andn2 write SCC: the loop counter's compare must not straddle the body)
   if (CHT == 4) px.C[CHT - 1] = c3;
 }
@@ -335,20 +350,27 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
         if (4 * f + 2 < CHT) feat[4 * f + 2] = ef[f].z;
         if (4 * f + 3 < CHT) feat[4 * f + 3] = ef[f].w;
       }
-      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z));
+      // (kMasks: `live` loses a quadrant's bit the moment its last pixel closes, blend_pixel_safe_asm)
+      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(g1.z)) & (kMasks<CHT> ? live : 0xfu);
       const int idx = __float_as_int(g1.w);
       MGS_STAT(2, __popc(m));
       // (measured and rejected, profiles/r3/00_experiments.md: one straight-line body per quadrant SET behind a
       //  switch on the mask, 268-278 us against 197; the live quadrants re-derived every 8 / 16 / 32 entries, +2 %)
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
+      auto quad = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
         if (m & (1u << k)) {
           if constexpr (kMasks<CHT> && SAFE)
-            blend_pixel_safe_asm<CHT, TRACK_LAST>(st[k], alive[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, idx);
+            blend_pixel_safe_asm<CHT, TRACK_LAST, MGS_RASTER_LIVE_BITS ? k : -1>(st[k], alive[k], live, pq[k], g0.x, g0.y, g0.z,
+                                                                                g0.w, g1.x, g1.y, feat, idx);
           else
             blend_pixel<CHT, TRACK_LAST, SAFE, kMasks<CHT>>(st[k], alive[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x,
                                                              g3.y, feat, idx);
         }
+      };
+      quad(std::integral_constant<int, 0>{});
+      quad(std::integral_constant<int, 1>{});
+      quad(std::integral_constant<int, 2>{});
+      quad(std::integral_constant<int, 3>{});
     };
     auto walk = [&](auto safe_tag) {
       constexpr bool SAFE = decltype(safe_tag)::value;
@@ -566,6 +588,9 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
         if (j0 && (kMasks<CHT> ? alive : ballot(st.T > 0.f)) == 0ull) break;
         const int j1 = min(j0 + kChunk, count);
       for (int j = j0; j < j1; ++j) {
+#if MGS_RASTER_Q_BREAK
+        if (kMasks<CHT> && alive == 0ull) break;     // (a scalar compare: the block's last pixel closed)
+#endif
         const QueueEntry<CHT>& e = queue[j];
         float4 g0, g1, ef0;
         if constexpr (CHT <= 4) lds_read_3f4(&e.geo0, &e.geo1, &e.feat[0], g0, g1, ef0);
@@ -580,7 +605,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
           if (4 * f + 3 < CHT) feat[4 * f + 3] = v.w;
         }
         if constexpr (kMasks<CHT> && SAFE) {
-          blend_pixel_safe_asm<CHT, TRACK_LAST>(st, alive, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
+          unsigned unused = 0;
+          blend_pixel_safe_asm<CHT, TRACK_LAST>(st, alive, unused, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
         } else {
           float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
           if constexpr (!SAFE) g3 = e.geo3;

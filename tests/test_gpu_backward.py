@@ -165,7 +165,8 @@ def test_rasterize_absgrad():
                                         flat, absgrad=True)
     render.sum().backward()
     assert hasattr(a_m2d, "absgrad")
-    assert torch.all(a_m2d.absgrad + 1e-6 >= a_m2d.grad.abs())
+    # |sum| <= sum |.| up to rounding (signed sums: tile-centred moments; absolute ones: per pixel)
+    assert torch.all(a_m2d.absgrad * (1 + 2e-5) + 2e-6 >= a_m2d.grad.abs()), float((a_m2d.grad.abs() - a_m2d.absgrad).max())
 
 
 @pytest.mark.parametrize("deg,mode,aa", [(0, "RGB", False), (3, "RGB", False), (2, "RGB+ED", False),
