@@ -122,16 +122,64 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, unsigned long l
 #ifndef MGS_RASTER_CMPX
 #define MGS_RASTER_CMPX 1
 #endif
+#ifndef MGS_RASTER_MASKS
+#define MGS_RASTER_MASKS 1          // 0: the sign of T is the "finished" flag in every kernel (measurement)
+#endif
 #ifndef MGS_RASTER_Q_BREAK
 #define MGS_RASTER_Q_BREAK 0        // one wave per 8x8 block: leave the batch at the entry that closes the block's last pixel
 #endif
 #ifndef MGS_RASTER_LIVE_BITS
 #define MGS_RASTER_LIVE_BITS 1      // one wave per tile: a quadrant whose last pixel closes is skipped for the rest of the batch
 #endif
+// Measurement only (MGS_RASTER_MASKS=0, profiles/r3/00_experiments.md): the SAFE body with the sign of T as the
+// "finished" flag -- 16 vector instructions, two of them selects, no scalar bookkeeping.
+template <int CHT, bool TRACK_LAST>
+__device__ __forceinline__ void blend_pixel_safe_asm_sign(PixelState<CHT>& px, const PixelPoly& pp, float q0, float q1,
+                                                     float q2, float A, float B, float C, const float* feat, int idx) {
+  static_assert(CHT == 3 || CHT == 4, "hand-written blend: 3 or 4 channels");
+  float dx, t0, t1;               // dx: the weight w, t0: T (1 - alpha), t1: exponent, then alpha
+  const float amin = kAlphaMin, tstop = kTStop;
+  float c3 = CHT == 4 ? px.C[CHT - 1] : 0.f;
+  const float f3 = CHT == 4 ? feat[CHT - 1] : 0.f;
+  asm volatile(
+      "v_fma_f32 %[t1], %[q1], %[x], %[q0]\n"          // pair_power_poly, same order
+      "v_fmac_f32 %[t1], %[q2], %[y]\n"
+      "v_fmac_f32 %[t1], %[A], %[xx]\n"
+      "v_fmac_f32 %[t1], %[B], %[xy]\n"
+      "v_fmac_f32 %[t1], %[C], %[yy]\n"
+      "v_exp_f32 %[t1], %[t1]\n"
+      "s_nop 0\n"
+      "v_cmpx_le_f32 vcc, %[amin], %[t1]\n"
+      "v_fma_f32 %[t0], -%[t1], %[T], %[T]\n"
+      "v_mul_f32 %[dx], %[t1], %[T]\n"
+      "v_cmp_lt_f32 vcc, %[tstop], %[t0]\n"
+      "s_nop 1\n"
+      "v_cndmask_b32 %[dx], 0, %[dx], vcc\n"
+      "v_cndmask_b32_e64 %[T], -|%[T]|, %[t0], vcc\n"
+      "v_fmac_f32 %[c0], %[dx], %[f0]\n"
+      "v_fmac_f32 %[c1], %[dx], %[f1]\n"
+      "v_fmac_f32 %[c2], %[dx], %[f2]\n"
+      ".if %[four]\n"
+      "v_fmac_f32 %[c3], %[dx], %[f3]\n"
+      ".endif\n"
+      ".if %[track]\n"
+      "v_cndmask_b32 %[last], %[last], %[idx], vcc\n"     // EXEC = valid lanes, VCC = accumulated
+      ".endif\n"
+      "s_mov_b64 exec, -1\n"
+      : [dx] "=&v"(dx), [t0] "=&v"(t0), [t1] "=&v"(t1),
+        [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3), [last] "+v"(px.last)
+      : [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [x] "v"(pp.x), [y] "v"(pp.y), [xx] "v"(pp.xx), [xy] "v"(pp.xy),
+        [yy] "v"(pp.yy), [A] "v"(A), [B] "v"(B), [C] "v"(C),
+        [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
+        [four] "n"(CHT == 4 ? 1 : 0), [track] "n"(TRACK_LAST ? 1 : 0), [idx] "v"(idx)
+      : "vcc");
+  if (CHT == 4) px.C[CHT - 1] = c3;
+}
+
 // Kernels of 3 and 4 channels keep "finished" in lane masks (PixelState above) and run the SAFE blend as the
 // hand-written body below.
 template <int CHT>
-constexpr bool kMasks = MGS_RASTER_CMPX != 0 && (CHT == 3 || CHT == 4);
+constexpr bool kMasks = MGS_RASTER_MASKS != 0 && MGS_RASTER_CMPX != 0 && (CHT == 3 || CHT == 4);
 
 // The SAFE blend (3 or 4 channels; inference and, with one more move for last_ids, training) as hand-written gfx950
 // code: the same arithmetic in the same order as blend_pixel<CHT, ., true> -- bit-identical pixels -- under an EXEC that
@@ -362,6 +410,8 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
           if constexpr (kMasks<CHT> && SAFE)
             blend_pixel_safe_asm<CHT, TRACK_LAST, MGS_RASTER_LIVE_BITS ? k : -1>(st[k], alive[k], live, pq[k], g0.x, g0.y, g0.z,
                                                                                 g0.w, g1.x, g1.y, feat, idx);
+          else if constexpr (!MGS_RASTER_MASKS && MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4))
+            blend_pixel_safe_asm_sign<CHT, TRACK_LAST>(st[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, idx);
           else
             blend_pixel<CHT, TRACK_LAST, SAFE, kMasks<CHT>>(st[k], alive[k], pq[k], g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g3.x,
                                                              g3.y, feat, idx);
@@ -607,6 +657,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
         if constexpr (kMasks<CHT> && SAFE) {
           unsigned unused = 0;
           blend_pixel_safe_asm<CHT, TRACK_LAST>(st, alive, unused, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
+        } else if constexpr (!MGS_RASTER_MASKS && MGS_RASTER_CMPX && SAFE && (CHT == 3 || CHT == 4)) {
+          blend_pixel_safe_asm_sign<CHT, TRACK_LAST>(st, pp, g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, feat, __float_as_int(g1.w));
         } else {
           float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
           if constexpr (!SAFE) g3 = e.geo3;

@@ -34,7 +34,7 @@ enum Kind {
   K_MIN, K_MAX, K_MED3, K_CMP_VCC, K_CMP_SGPR, K_CNDMASK_VCC, K_CNDMASK_SGPR, K_AND, K_OR, K_XOR, K_MOV,
   K_ADD_U32, K_LSHL, K_CVT, K_EXP, K_RCP, K_LOG, K_DPP_MOV, K_DPP_ADD, K_PK_FMA, K_PK_MUL, K_PK_ADD,
   K_MAX3, K_MIN3, K_LDEXP, K_FRACT, K_BFE, K_MAD_U24, K_MUL_LEGACY, K_SUBREV, K_MAC_MIX_MIN,
-  K_MIX_FMA_CMP, K_MIX_FMA_CND, K_MIX_FMA_EXP, K_BLEND_NOW, K_BLEND_CLAMP, K_COUNT
+  K_MIX_FMA_CMP, K_MIX_FMA_CND, K_MIX_FMA_EXP, K_BLEND_NOW, K_BLEND_CLAMP, K_BLEND_R3, K_BLEND_MASK, K_COUNT
 };
 static const char* kNames[] = {
   "v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_fmac_f32 (VOP2)", "v_mul_f32 clamp (VOP3)",
@@ -45,7 +45,9 @@ static const char* kNames[] = {
   "v_add_f32 dpp", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_max3_f32", "v_min3_f32",
   "v_ldexp_f32", "v_fract_f32", "v_bfe_u32", "v_mad_u32_u24", "v_mul_legacy_f32", "v_subrev_f32",
   "mix: 4 fma + 4 min", "mix: 6 fma + 2 cmp", "mix: 6 fma + 2 cndmask", "mix: 7 fma + 1 exp",
-  "blend body as shipped (13 fma-class, 7 cmp/sel/min, 1 exp)", "blend body, clamp/step form (18 fma-class, 1 exp, 2 other)"
+  "blend body as shipped (13 fma-class, 7 cmp/sel/min, 1 exp)", "blend body, clamp/step form (18 fma-class, 1 exp, 2 other)",
+  "round-3 blend, 4 ch, sign of T as the flag (11 fma-class, 1 cmpx, 1 cmp, 2 cndmask, 1 exp)",
+  "round-3 blend, 4 ch, lane masks (12 fma-class, 2 cmpx, 1 exp; 4 salu)"
 };
 
 __device__ __forceinline__ unsigned long long shader_clock() { return __builtin_amdgcn_s_memtime(); }
@@ -132,6 +134,31 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* times,
           "v_fma_f32 %1, v23, %8, %1\n v_fma_f32 %2, v23, %9, %2\n v_fma_f32 %3, v23, %8, %3\n"
           "v_cndmask_b32_e64 %0, -|%0|, v22, vcc" OPERANDS : "vcc", "v20", "v21", "v22", "v23", "v24");)
     }
+    if constexpr (KIND == K_BLEND_R3) {
+      // raster_fwd.hip blend_pixel_safe_asm before the lane masks: a0 = T, a1..a4 = C, a5 / a6 the pixel offsets;
+      // the compares are unsigned "0 <= x" (always true: EXEC stays full, the worst case for the issue rate)
+      REP8(asm volatile(
+          "v_fma_f32 v20, %8, %5, %9\n v_fmac_f32 v20, %8, %6\n v_fmac_f32 v20, %9, %5\n v_fmac_f32 v20, %9, %6\n"
+          "v_fmac_f32 v20, %8, %5\n v_exp_f32 v20, v20\n s_nop 0\n v_cmpx_le_u32 vcc, 0, v20\n"
+          "v_fma_f32 v21, -v20, %0, %0\n v_mul_f32 v22, v20, %0\n v_cmp_le_u32 vcc, 0, v21\n s_nop 1\n"
+          "v_cndmask_b32 v22, 0, v22, vcc\n v_cndmask_b32_e64 %0, -|%0|, v21, vcc\n"
+          "v_fmac_f32 %1, v22, %8\n v_fmac_f32 %2, v22, %9\n v_fmac_f32 %3, v22, %8\n v_fmac_f32 %4, v22, %9\n"
+          "s_mov_b64 exec, -1" OPERANDS : "vcc", "v20", "v21", "v22");)
+    }
+    if constexpr (KIND == K_BLEND_MASK) {
+      // ... with the finished pixels in a lane mask (s[20:21], all ones here): EXEC narrowed three times, no select
+      asm volatile("s_mov_b64 s[20:21], -1" ::: "s20", "s21");
+      REP8(asm volatile(
+          "s_mov_b64 exec, s[20:21]\n"
+          "v_fma_f32 v20, %8, %5, %9\n v_fmac_f32 v20, %8, %6\n v_fmac_f32 v20, %9, %5\n v_fmac_f32 v20, %9, %6\n"
+          "v_fmac_f32 v20, %8, %5\n v_exp_f32 v20, v20\n s_nop 0\n v_cmpx_le_u32 vcc, 0, v20\n"
+          "v_fma_f32 v21, -v20, %0, %0\n v_mul_f32 v22, v20, %0\n v_cmpx_le_u32_e64 s[22:23], 0, v21\n"
+          "v_mov_b32 %0, v21\n"
+          "v_fmac_f32 %1, v22, %8\n v_fmac_f32 %2, v22, %9\n v_fmac_f32 %3, v22, %8\n v_fmac_f32 %4, v22, %9\n"
+          "s_xor_b64 vcc, vcc, s[22:23]\n s_andn2_b64 s[20:21], s[20:21], vcc\n"
+          "s_cselect_b32 vcc_lo, -1, -2\n s_and_b32 s24, s24, vcc_lo\n"
+          "s_mov_b64 exec, -1" OPERANDS : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "v20", "v21", "v22");)
+    }
   }
   const unsigned long long t1 = shader_clock(), r1 = real_clock();
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y;
@@ -145,6 +172,8 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* times,
 static int insts_per_iter(int kind) {
   if (kind == K_BLEND_NOW) return 8 * 21;       // VALU only (the s_and is extra)
   if (kind == K_BLEND_CLAMP) return 8 * 20;
+  if (kind == K_BLEND_R3) return 8 * 16;
+  if (kind == K_BLEND_MASK) return 8 * 15;
   return 64;
 }
 
@@ -185,7 +214,7 @@ void sweep(float* d, unsigned long long* dt, bool all) {
 template <int K0>
 void all_kinds(float* d, unsigned long long* dt) {
   if constexpr (K0 < K_COUNT) {
-    sweep<K0>(d, dt, K0 == K_FMA || K0 == K_MIN || K0 == K_CMP_VCC || K0 == K_EXP || K0 == K_BLEND_NOW || K0 == K_BLEND_CLAMP);
+    sweep<K0>(d, dt, K0 == K_FMA || K0 == K_MIN || K0 == K_CMP_VCC || K0 == K_EXP || K0 == K_BLEND_NOW || K0 == K_BLEND_CLAMP || K0 == K_BLEND_R3 || K0 == K_BLEND_MASK);
     all_kinds<K0 + 1>(d, dt);
   }
 }
@@ -196,6 +225,8 @@ int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "blend")) {      // only the two blend bodies
     sweep<K_BLEND_NOW>(d, dt, true);
     sweep<K_BLEND_CLAMP>(d, dt, true);
+    sweep<K_BLEND_R3>(d, dt, true);
+    sweep<K_BLEND_MASK>(d, dt, true);
     return 0;
   }
   all_kinds<0>(d, dt);
