@@ -20,13 +20,13 @@
 namespace mgs {
 namespace {
 
-template <int CHT>
+template <int CHT, bool WIDE>
 struct BwdEntry {
   float4 geo0;                       // q0, q1, q2 of the exponent's polynomial about the tile centre (raster_common.h), A
   float4 geo1;                       // B, C, quadrant mask (bits), list index (bits); A = -0.5 log2e a, B = -log2e b, C = -0.5 log2e c
   float4 feat[(CHT + 3) / 4];
   float4 geo2;                       // record slot / Gaussian id (bits), mean - tile centre (x, y), L = log2(opacity)
-  float4 geo3;                       // conic a, b, c (absgrad and the atomic path only)
+  float4 geo3[WIDE ? 1 : 0];         // conic a, b, c: absgrad and the atomic path only (64 bytes per entry without it at 4 channels)
 };
 
 template <int CHT>
@@ -150,7 +150,12 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 #define MGS_RASTER_BWD_WG_WAVES 1      // independent tiles (waves) per workgroup; 2 / 4 measured slower (564 / 554 vs 537 us)
 #endif
 #ifndef MGS_RASTER_BWD_MIN_WAVES
-#define MGS_RASTER_BWD_MIN_WAVES 1     // min waves per SIMD asked of the register allocator
+// min waves per SIMD asked of the register allocator for the record kernels of up to 4 channels without absgrad.
+// 5 = at most 96 VGPRs (113 when left free: 4 waves), 28 bytes spilled outside the walk; the kernel's LDS (64-byte queue
+// entries, ten rows of reduction buffer: 6.5 KB per wave) allows 24 waves per CU.  Measured with dynamic-LDS caps:
+// 3 waves per SIMD 544 us, 4 waves 474-484, 5 waves 468-475 (memset + backward + reduce); 6 waves (80 VGPRs) spill: 694.
+// The round-3 first pass tried 96 VGPRs with 9 KB of LDS per wave -- 17 waves per CU at most, so only the spills showed.
+#define MGS_RASTER_BWD_MIN_WAVES 5
 #endif
 // HALF (record path only; measured and NOT the default): a wave owns HALF a tile -- two 8x8 blocks side by
 // side, two pixels per lane -- and the pair's record slot is doubled (slot * 2 + half): twice the waves, each
@@ -158,6 +163,9 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 // that reach both halves.  618 -> 724 us for the whole backward at config 2: the extra reductions and the
 // doubled slots of the reduce cost more than the finer schedule returns (what paid in the forward, where a
 // block's result needs no cross-lane sum, does not pay here).
+#ifndef MGS_RASTER_BWD_LDS_PAD
+#define MGS_RASTER_BWD_LDS_PAD 0       // bytes of unused dynamic LDS per workgroup: caps the waves per CU (occupancy experiments)
+#endif
 #ifndef MGS_RASTER_BWD_HALF
 #define MGS_RASTER_BWD_HALF 0
 #endif
@@ -176,7 +184,7 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 __device__ unsigned long long g_bwd_times[4 * 16384];
 #endif
 template <int CHT, bool ABSGRAD, bool RECORDS, bool HALF = false>
-__global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WAVES) void raster_bwd_kernel(
+__global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS && !ABSGRAD && !HALF) ? MGS_RASTER_BWD_MIN_WAVES : 1) void raster_bwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
@@ -189,9 +197,12 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     const int4* __restrict__ pair_info, float* __restrict__ records,
     uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ expected_render,
     const int32_t* __restrict__ tile_order) {
-  __shared__ BwdEntry<CHT> queues[MGS_RASTER_BWD_WG_WAVES][kQueue];
-  __shared__ float reds[MGS_RASTER_BWD_WG_WAVES][RECORDS ? 16 : 1][64];  // wave-private transpose buffer of the record reduction
-  BwdEntry<CHT>* queue = queues[threadIdx.x >> 6];
+  constexpr bool WIDE = ABSGRAD || !RECORDS;
+  constexpr int NVR = 6 + CHT + (ABSGRAD ? 2 : 0);      // values reduced over the wave per list entry
+  constexpr int kRedRows = !RECORDS ? 1 : (NVR > 8 && NVR <= 16) ? NVR : 8;
+  __shared__ BwdEntry<CHT, WIDE> queues[MGS_RASTER_BWD_WG_WAVES][kQueue];
+  __shared__ float reds[MGS_RASTER_BWD_WG_WAVES][kRedRows][64];  // wave-private transpose buffer of the record reduction
+  BwdEntry<CHT, WIDE>* queue = queues[threadIdx.x >> 6];
   float (*red)[64] = reds[threadIdx.x >> 6];
   static_assert(!HALF || RECORDS, "half tiles exist on the record path only");
   constexpr int NQ = HALF ? 2 : 4;                 // 8x8 blocks per wave
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
 #endif
     const bool all_safe = ballot(qmask != 0u && !(sigma_sign_is_safe(ca, cb, cc) && op <= kSafeOpacity)) == 0ull;
     if (qmask != 0u) {
-      BwdEntry<CHT>& e = queue[mask_rank(keep)];
+      BwdEntry<CHT, WIDE>& e = queue[mask_rank(keep)];
       constexpr float kLog2e = 1.4426950408889634f;
       const float sA = -0.5f * kLog2e * ca, sB = -kLog2e * cb, sC = -0.5f * kLog2e * cc, L = __log2f(op);
       const float m_x = xy.x - (tile_x + 8.f), m_y = xy.y - (tile_y + 8.f);
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
         gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
       }
       e.geo2 = make_float4(__int_as_float(gid), m_x, m_y, L);
-      e.geo3 = make_float4(ca, cb, cc, 0.f);
+      if constexpr (WIDE) e.geo3[0] = make_float4(ca, cb, cc, 0.f);
       float f[((CHT + 3) / 4) * 4];
 #pragma unroll
       for (int c = 0; c < ((CHT + 3) / 4) * 4; ++c)
@@ -374,10 +385,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, MGS_RASTER_BWD_MIN_WA
     auto walk = [&](auto safe_tag) {
     constexpr bool SAFE = decltype(safe_tag)::value;
     for (int j = count - 1; j >= 0; --j) {
-      const BwdEntry<CHT>& e = queue[j];
+      const BwdEntry<CHT, WIDE>& e = queue[j];
       const float4 g0 = e.geo0, g1 = e.geo1, g2 = e.geo2;
       float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ABSGRAD || !RECORDS) g3 = e.geo3;
+      if constexpr (WIDE) g3 = e.geo3[0];
       float feat[CHT];
 #pragma unroll
       for (int f = 0; f < (CHT + 3) / 4; ++f) {
@@ -758,7 +769,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   }
   const int n_units = order ? (n_tiles + 3) / 4 * 4 : n_tiles * (int)kSlots;
 #define MGS_RD_LAUNCH(C, A)                                                                     \
-  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf>), dim3(div_up(n_units, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), 0, s, means2d,   \
+  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf>), dim3(div_up(n_units, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), MGS_RASTER_BWD_LDS_PAD, s, means2d,   \
                      conics, feats, opacities, reinterpret_cast<const float4*>(splats),        \
                      background, channels, width, height, tile_w,                              \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
