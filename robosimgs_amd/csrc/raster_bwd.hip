@@ -32,8 +32,9 @@ struct BwdEntry {
 template <int CHT>
 struct BwdPixel {
   float T;            // transmittance in front of the Gaussian being processed
-  float tfv;          // T_final * d loss / d alpha_out (minus the background term)
-  float bv;           // (colour accumulated BEHIND the current Gaussian) . v_c
+  float bv;           // (colour accumulated BEHIND the current Gaussian) . v_c  -  T_final * d loss / d alpha_out (with the
+                      // background term): both only ever appear as this difference times 1 / (1 - alpha), so the walk
+                      // starts bv at minus the second term instead of keeping it in a register of its own
   float v_c[CHT];     // d loss / d render
   int last;
 };
@@ -86,8 +87,7 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   float fv = feat[0] * px.v_c[0];
 #pragma unroll
   for (int c = 1; c < CHT; ++c) fv = fmaf(feat[c], px.v_c[c], fv);
-  float v_alpha = fmaf(fv, px.T, px.tfv * ra);
-  v_alpha = fmaf(-px.bv, ra, v_alpha);
+  float v_alpha = fmaf(-px.bv, ra, fv * px.T);
   asm volatile("" : "+v"(px.bv), "+v"(v_alpha));   // bv is updated in place AFTER its last use (the compiler formed
   px.bv = fmaf(fv, fac, px.bv);                    // the new value early in a temporary and copied it back)
 #pragma unroll
@@ -234,7 +234,6 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
     const bool inside = x < width && y < height;
     const size_t p = inside ? (size_t)y * width + x : 0;
     st[k].T = inside ? 1.0f - alphas[p] : 1.f;           // starts at the pixel's final transmittance
-    st[k].bv = 0.f;
     st[k].last = inside ? last_ids[p] : -1;
     float va = (inside && v_alphas) ? v_alphas[p] : 0.f;      // v_alphas == nullptr: no loss term on alpha
 #pragma unroll
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
 #pragma unroll
     for (int c = 0; c < CHT; ++c)
       if (background && c < channels) va -= background[c] * st[k].v_c[c];
-    st[k].tfv = st[k].T * va;
+    st[k].bv = -(st[k].T * va);
     hi = max(hi, st[k].last);
   }
   // wave-wide maximum of the last contributing index
@@ -301,13 +300,12 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
     //  it -- two v_mov 0, two v_mov_dpp and two adds instead of two v_add_f32_dpp)
     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(t0), "+v"(t1));
+    // (uniform record base + the lane's 32-bit position: the store takes the base from SGPRs instead of a 64-bit
+    //  address per lane kept across the walk)
+    float* rec = records + rslot * RSP;
     if ((lane & 7) == 0) {
-      const int p0 = rec_pos((int)(lane >> 3));
-      if (p0 >= 0) records[rslot * RSP + p0] = t0;
-      if (v1 < NV) {
-        const int p1 = rec_pos(v1);
-        if (p1 >= 0) records[rslot * RSP + p1] = t1;
-      }
+      rec[lane >> 3] = t0;
+      if (v1 < NV) rec[(unsigned)v1] = t1;
     }
     if (lane == 0) flags[rslot] = 1;
   };
