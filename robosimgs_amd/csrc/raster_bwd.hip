@@ -104,7 +104,7 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
     gg.a_x += fabsf(fmaf(cb, q, ca * p));
     gg.a_y += fabsf(fmaf(cc, q, cb * p));
   }
-  return valid;
+  return true;        // wave-uniform: some lane of the quadrant took the Gaussian (the caller keeps it in an SGPR)
 }
 
 // Moments of v_sigma about the tile centre -> sums about the Gaussian's mean, m = mean - tile centre:
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
         red_finish(pend_slot, pa0, pb0, pa1, pb1);
         pend = false;
       }
-      if (ballot(any) == 0ull) continue;
+      if (!any) continue;          // (uniform: no lane of any quadrant took the Gaussian -- nothing to reduce)
       if constexpr (RECORDS) {
         // overflowed tile lists (status word set by the binning): slot bases run up to the true
         // n_isect, the workspace only to the capacity -- nothing is written past it
