@@ -2,13 +2,13 @@
 //
 // Same geometry as the forward (raster_common.h): one wave64 per 16x16 tile, four pixels per
 // lane, the tile's list walked BACK TO FRONT in batches of 64 with the same exact quadrant
-// cull and ballot-compacted wave-private LDS queue.  Per Gaussian each lane sums the
-// contributions of its (up to) four pixels and the wave reduces the 6 + channels partial sums.
-// Two ways out:
-//   * records (mgs_rasterize_bwd_det, the render path's default): a reduce-scatter butterfly
-//     leaves the totals in 8 lanes that store one record per (tile, Gaussian) pair;
-//     reduce_records_kernel then sums each Gaussian's contiguous slots.  No atomics,
-//     bit-reproducible.
+// cull and ballot-compacted wave-private LDS queue.  Per Gaussian each lane sums, over its (up to) four pixels, the
+// six moments of d loss / d sigma about the tile centre and the colour gradients (GaussGrad), and the wave reduces those
+// 6 + channels partial sums.  Two ways out:
+//   * records (mgs_rasterize_bwd_det, the render path's default): the sums go through a wave-private LDS transpose
+//     (eight lanes finish one value each) and are stored as one record of `record_floats` floats per (tile, Gaussian)
+//     pair; reduce_records_kernel turns every record into the pair's gradients (the slot tells the tile, hence the
+//     mean's offset from its centre) and sums each Gaussian's contiguous slots.  No atomics, bit-reproducible.
 //   * atomics (mgs_rasterize_bwd, for externally supplied tile lists): plain DPP reduction to
 //     lane 63, one hardware float atomic per component.  Scattered device atomics sustain only
 //     ~25-30 G/s on MI355X, which made this variant 1.38 ms against 0.78 ms for the records.
