@@ -38,8 +38,9 @@ extern "C" {
 
 /* Bumped whenever a parameter list changes: a caller built against another header must not load this
  * library (robosimgs_amd/_lib.py asserts mgs_version() == the MGS_VERSION it was written for).
- * 100 round 1; 200 round 2 (seed / splats / tile_group_order arguments); 300 round 3. */
-#define MGS_VERSION 300
+ * 100 round 1; 200 round 2 (seed / splats / tile_group_order arguments); 300 round 3; 400 round 4 (forward
+ * checkpoints + segmented backward, batched training entry points, debug hooks out of the production build). */
+#define MGS_VERSION 400
 
 #define MGS_OK 0
 #define MGS_ERR_INVALID_ARGUMENT (-1)
@@ -236,13 +237,22 @@ int mgs_isect_offset_encode(uint32_t n_isect, const int64_t *isect_ids, int n_ca
  *   without a second pass over the frame.  MGS_RASTER_LATENCY: one wave per 8x8 block instead of
  *   one per tile (same pixels, shorter launch when the GPU is not shared with other frames).
  *   tile_group_order (nullable): from mgs_isect_tiles; tiles are then started longest lists first.
+ *   checkpoints (nullable; needs last_ids, i.e. the training variant) with checkpoint_interval S (a power of two
+ *   >= 64): every S list entries the kernel stores each pixel's state in front of the next entry -- T and the
+ *   accumulated channels, (1 + channels) floats per pixel -- for mgs_rasterize_bwd_det, which then walks a tile's
+ *   list as independent segments of S entries instead of as one serial job per tile.
+ *   checkpoints[mgs_raster_checkpoint_floats(...)] is written only where some pixel is still open.
  * ----------------------------------------------------------------------------------- */
 int mgs_rasterize_fwd(int n, const float *means2d, const float *conics, const float *feats,
                       const float *opacities, const float *splats, const float *background,
                       int channels, int width, int height, int tile_w, int tile_h,
                       const int32_t *tile_offsets, const int32_t *flatten_ids,
                       const int32_t *tile_group_order, int flags,
-                      float *render, float *alphas, int32_t *last_ids, mgs_stream_t stream);
+                      float *render, float *alphas, int32_t *last_ids, float *checkpoints,
+                      int checkpoint_interval, mgs_stream_t stream);
+/* Floats of the `checkpoints` buffer for lists of up to `isect_capacity` entries (host arithmetic, no GPU work). */
+size_t mgs_raster_checkpoint_floats(uint32_t isect_capacity, int tile_w, int tile_h, int channels,
+                                    int checkpoint_interval);
 
 /*   v_render[H,W,channels], v_alphas[H,W] incoming; v_means2d[N,2] v_conics[N,3]
  *   v_feats[N,channels] v_opacities[N] are ACCUMULATED into with float atomics
@@ -270,6 +280,11 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
  *   cotangents of the un-normalised blend: no pass over the frame in between.
  *   tile_group_order (nullable): from mgs_isect_tiles; when NULL the call computes the order itself.
  *   v_alphas (nullable here): NULL = the loss does not depend on the alpha output (no zero frame needed).
+ *   checkpoints + checkpoint_interval + render_out (nullable together; <= 4 channels): what mgs_rasterize_fwd wrote
+ *   for these lists, and its render[H,W,channels] (== expected_render in "ED" mode).  The launch then has one unit of
+ *   work per SEGMENT of checkpoint_interval list entries: a segment behind which the list goes on starts from the
+ *   forward's checkpoint (its T; colour behind = final - checkpoint).  Same records and slots; against the whole-list
+ *   walk the gradients differ by rounding only (<= ~1e-6 relative), and stay bit-reproducible run to run.
  */
 int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, const float *feats,
                           const float *opacities, const float *splats, const float *background,
@@ -278,7 +293,8 @@ int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, cons
                           const float *alphas, const int32_t *last_ids, const float *v_render,
                           const float *v_alphas, const float *expected_render,
                           const int32_t *pair_info, const int32_t *tile_group_order,
-                          uint32_t isect_capacity, float *v_means2d, float *v_means2d_abs,
+                          uint32_t isect_capacity, const float *render_out, const float *checkpoints,
+                          int checkpoint_interval, float *v_means2d, float *v_means2d_abs,
                           float *v_conics, float *v_feats, float *v_opacities, void *workspace,
                           size_t *workspace_bytes, mgs_stream_t stream);
 

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgs.so")
 
 MGS_STATUS_ISECT_OVERFLOW = 1
-MGS_VERSION = 300          # include/mgs.h this binding was written against (parameter lists change with it)
+MGS_VERSION = 400          # include/mgs.h this binding was written against (parameter lists change with it)
 
 
 class MgsError(RuntimeError):
@@ -51,7 +51,8 @@ def _load() -> ctypes.CDLL:
         "mgs_isect_tiles": ([i, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
         "mgs_render_frames": ([i, p, p, p, p, i, i, p, i, p, p, i, i, f, f, f, f, i, i, i, p, u32, p, p, p, p, p, POINTER(c_size_t), p], c_int),
-        "mgs_rasterize_fwd": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, i, p, p, p, p], c_int),
+        "mgs_rasterize_fwd": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, i, p, p, p, p, i, p], c_int),
+        "mgs_raster_checkpoint_floats": ([u32, i, i, i, i], c_size_t),
         "mgs_rasterize_bwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_composite_over": ([i, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_points_project": ([i, p, p, p, p, p, p], c_int),
@@ -62,7 +63,7 @@ def _load() -> ctypes.CDLL:
         "mgs_transform_gaussians": ([i, p, p, p, i, i, p, p, i, p, p, p, p, p, p, p], c_int),
         "mgs_l1_loss_fwd": ([c_size_t, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_l1_loss_bwd": ([c_size_t, p, p, p, p, p], c_int),
-        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, u32, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, u32, p, p, i, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch
@@ -90,7 +91,8 @@ EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_debug_set_raster_cull", 
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
            "mgs_rasterize_bwd_det", "mgs_composite_over", "mgs_points_project",
            "mgs_points_depth_map", "mgs_points_sample_mask", "mgs_l1_loss_fwd", "mgs_l1_loss_bwd",
-           "mgs_transform_gaussians", "mgs_frame_to_u8", "mgs_frame_to_dataset", "mgs_render_frames"]
+           "mgs_transform_gaussians", "mgs_frame_to_u8", "mgs_frame_to_dataset", "mgs_render_frames",
+           "mgs_raster_checkpoint_floats"]
 
 
 def check(rc: int, what: str) -> None:

@@ -82,7 +82,7 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
     if (rc) return rc;
     rc = mgs_rasterize_fwd(n, nullptr, nullptr, nullptr, nullptr, splats, backgrounds ? backgrounds + (size_t)channels * c : nullptr,
                            channels, width, height, tile_w, tile_h, offsets, flatten, order, flags,
-                           render + n_px * channels * c, alphas + n_px * c, nullptr, stream);
+                           render + n_px * channels * c, alphas + n_px * c, nullptr, nullptr, 0, stream);
     if (rc) return rc;
   }
   return MGS_OK;

@@ -12,6 +12,7 @@
 //   * atomics (mgs_rasterize_bwd, for externally supplied tile lists): plain DPP reduction to
 //     lane 63, one hardware float atomic per component.  Scattered device atomics sustain only
 //     ~25-30 G/s on MI355X, which made this variant 1.38 ms against 0.78 ms for the records.
+#include <algorithm>
 #include <type_traits>
 
 #include "raster_common.h"
@@ -66,10 +67,10 @@ struct GaussGrad {
 // below zero and an opacity <= kSafeOpacity, so the sigma test and the 0.999 clamp are dead -- alpha = ov, nothing is
 // ever clamped, one select serves a_eff and ov_eff.  Same values bit for bit, six vector instructions less.
 template <int CHT, bool ABSGRAD, bool SAFE = false>
-__device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, const PixelPoly& pp,
+__device__ __forceinline__ void grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg, const PixelPoly& pp,
                                            float mx, float my, float ca, float cb,
                                            float cc, float A, float B, float C, float q0, float q1, float q2,
-                                           const float* feat, int idx) {
+                                           const float* feat, int idx, int& any) {
   // mx, my: the mean's offset from the tile centre; pp: the pixel's (raster_common.h)
   // the forward's own evaluation (raster_fwd.hip blend_pixel, raster_common.h pair_power_poly), bit for bit:
   // ov = opacity * exp(-sigma) as one exp2 of the exponent's polynomial about the tile centre
@@ -77,7 +78,9 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
   float alpha = SAFE ? ov : fminf(kAlphaMax, ov);
   bool valid = idx <= px.last && alpha >= kAlphaMin;
   if (!SAFE) valid = valid && pair_power_sign(mx - pp.x, my - pp.y, A, B, C) <= 0.f;
-  if (ballot(valid) == 0ull) return false;
+  if (ballot(valid) == 0ull) return;
+  any = 1;        // (wave-uniform, set on the taken side of a scalar branch: one s_mov.  As a returned bool the compiler
+                  //  rebuilt it from the lane mask with a v_cndmask, a v_cmp and two scalar instructions per quadrant body)
   float a_eff = valid ? alpha : 0.f;                       // 0 => T, bv and v_f stay untouched
   bool grad_geo = valid && ov <= kAlphaMax;                // alpha not clamped: sigma/opacity get grads
   float ov_eff = SAFE ? a_eff : (grad_geo ? ov : 0.f);
@@ -104,7 +107,6 @@ __device__ __forceinline__ bool grad_pixel(BwdPixel<CHT>& px, GaussGrad<CHT>& gg
     gg.a_x += fabsf(fmaf(cb, q, ca * p));
     gg.a_y += fabsf(fmaf(cc, q, cb * p));
   }
-  return true;        // wave-uniform: some lane of the quadrant took the Gaussian (the caller keeps it in an SGPR)
 }
 
 // Moments of v_sigma about the tile centre -> sums about the Gaussian's mean, m = mean - tile centre:
@@ -181,10 +183,36 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 #define MGS_RASTER_BWD_ORDER 1         // launch the tiles by falling list length (tile_order_kernel): 623 -> 572 us
 #endif
 #ifdef MGS_RASTER_BWD_TIMING          // measurement build (scripts/dbg/bwd_timeline.py): per tile {start, end} on the 100 MHz clock, entries, pairs
-__device__ unsigned long long g_bwd_times[4 * 16384];
+__device__ unsigned long long g_bwd_times[5 * 65536];   // per unit: enter, walk begins, end, entries, pairs
 #endif
-template <int CHT, bool ABSGRAD, bool RECORDS, bool HALF = false>
-__global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS && !ABSGRAD && !HALF) ? MGS_RASTER_BWD_MIN_WAVES : 1) void raster_bwd_kernel(
+// SPLIT (record path, <= 4 channels): a unit of the launch is one SEGMENT of a tile's list (raster_common.h:
+// checkpoints), found through seg_table; a segment that has a successor some pixel reaches starts those pixels from the
+// forward's checkpoint -- T as the forward had it, colour behind = final - checkpoint -- instead of from the end of the
+// list.  Every list entry lies in exactly one segment and the batches are those of the whole walk, so records, slots
+// and the reduce are unchanged; only the first T and bv of a front segment differ from the whole walk's (by rounding:
+// the forward's T is the exact product, the whole walk's a chain of v_rcp_f32).  Why: a tile used to be one wave's
+// serial job, 8,160 jobs of 200-560 evaluated pairs are two uneven rounds of the wave slots, and the last fifth of
+// the launch ran at under one wave per SIMD.
+// Tables of the segmented launch (unit_table_kernel below): 64 counters, the whole segments, the partial ones by class.
+constexpr int kUnitClasses = 32;
+struct UnitTables {
+  uint32_t* counts;      // [0] whole segments, [1 + c] partial segments of class c
+  int4* whole;           // {tile, segment, the list's start, the end of the tile's walk (its largest last_id)}
+  int4* part;            // [class][n_tiles]
+};
+__host__ __device__ inline size_t unit_tables_bytes(int n_tiles, int shift, uint32_t capacity) {
+  return 256 + (ckpt_units(capacity, n_tiles, shift) + (size_t)kUnitClasses * n_tiles) * sizeof(int4);
+}
+__device__ __forceinline__ UnitTables unit_tables(const int32_t* base, int n_tiles, int shift, uint32_t capacity) {
+  UnitTables u;
+  u.counts = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(base));
+  u.whole = reinterpret_cast<int4*>(const_cast<int32_t*>(base) + 64);
+  u.part = u.whole + ckpt_units(capacity, n_tiles, shift);
+  return u;
+}
+
+template <int CHT, bool ABSGRAD, bool RECORDS, bool HALF = false, bool SPLIT = false>
+__device__ __forceinline__ void raster_bwd_unit(const int unit,
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
     const float4* __restrict__ splats, const float* __restrict__ background, int channels,
@@ -196,7 +224,8 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
     float* __restrict__ v_feats, float* __restrict__ v_opacities,
     const int4* __restrict__ pair_info, float* __restrict__ records,
     uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ expected_render,
-    const int32_t* __restrict__ tile_order) {
+    const int32_t* __restrict__ tile_order, const float* __restrict__ ckpt, int ckpt_shift,
+    const int32_t* __restrict__ seg_table, const float* __restrict__ render_out) {
   constexpr bool WIDE = ABSGRAD || !RECORDS;
   constexpr int NVR = 6 + CHT + (ABSGRAD ? 2 : 0);      // values reduced over the wave per list entry
   constexpr int kRedRows = !RECORDS ? 1 : (NVR > 8 && NVR <= 16) ? NVR : 8;
@@ -205,17 +234,47 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
   BwdEntry<CHT, WIDE>* queue = queues[threadIdx.x >> 6];
   float (*red)[64] = reds[threadIdx.x >> 6];
   static_assert(!HALF || RECORDS, "half tiles exist on the record path only");
+  static_assert(!SPLIT || (RECORDS && !HALF && CHT <= 4), "segments exist on the record path of up to 4 channels");
   constexpr int NQ = HALF ? 2 : 4;                 // 8x8 blocks per wave
-  const int unit = blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6);
+#ifdef MGS_RASTER_BWD_TIMING
+  const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime();
+#endif
   // tile_order: groups of four tiles by falling list length (tile_order.h), so that the longest walks start first
-  const int tile = HALF ? (unit >> 1 < n_tiles ? unit >> 1 : -1) : tile_of_unit(unit, n_tiles, tile_order);
+  int tile, seg = 0, seg_start = 0, seg_hi = 0;
+  if constexpr (SPLIT) {
+    // the launch is sized by the capacity; the tables (unit_table_kernel) list the segments some pixel reaches: whole
+    // segments first, then every tile's last, partly walked one by falling length class
+    const UnitTables ut = unit_tables(seg_table, n_tiles, ckpt_shift, capacity);
+    uint32_t cnt[1 + kUnitClasses];                   // (wave-uniform: 33 SGPRs from three scalar loads, no dependent chain)
+#pragma unroll
+    for (int i = 0; i <= kUnitClasses; ++i) cnt[i] = ut.counts[i];
+    const int4 e_whole = ut.whole[unit];              // (in flight with the counts: two thirds of the units are whole segments)
+    int r = unit - (int)cnt[0], cls = -1, at = 0;
+#pragma unroll
+    for (int c = 0; c < kUnitClasses; ++c) {
+      const int n = (int)cnt[1 + c];
+      if (cls < 0 && r >= 0 && r < n) { cls = c; at = r; }
+      if (r >= 0) r -= n;
+    }
+    if (r >= 0 && cls < 0) return;                    // past the last unit (the launch is sized by the capacity)
+    const int4 e = cls < 0 ? e_whole : ut.part[(size_t)cls * n_tiles + at];
+    tile = e.x;
+    seg = e.y;
+    seg_start = e.z;
+    seg_hi = e.w;
+  } else {
+    tile = HALF ? (unit >> 1 < n_tiles ? unit >> 1 : -1) : tile_of_unit(unit, n_tiles, tile_order);
+  }
   const int half = HALF ? unit & 1 : 0;
   if (tile < 0) return;
   const unsigned lane = threadIdx.x & 63u;
   const int tx = tile % tile_w, ty = tile / tile_w;
   const float tile_x = (float)(tx * 16), tile_y = (float)(ty * 16);
-  const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  const int start = SPLIT ? seg_start : tile_offsets[tile], end = SPLIT ? seg_hi + 1 : tile_offsets[tile + 1];
   if (end <= start) return;
+  // SPLIT: this unit's segment [lo, nxt) of the list (the table entry carries the list's start and the end of the walk)
+  const int lo = SPLIT ? start + (seg << ckpt_shift) : start;
+  const int nxt = SPLIT ? lo + (1 << ckpt_shift) : end;
   // (also consumes `capacity` up here: a scalar load still outstanding at the head of the walk would turn every
   //  LDS wait inside it into a wait for everything -- scalar loads return out of order)
   if (RECORDS && capacity == 0u) return;
@@ -228,26 +287,68 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
 
   BwdPixel<CHT> st[NQ];
   int hi = -1;
+  bool has_next = false;           // (wave-uniform) some pixel's list goes on behind this segment: checkpoints apply
+  const float* cp = nullptr;
+  if constexpr (SPLIT) {
+    hi = seg_hi;                     // where the tile's walk ends (the forward left it in the checkpoint header)
+    if (hi < lo) return;             // (the table lists no such unit)
+    has_next = hi >= nxt;
+    cp = ckpt + ckpt_header_floats(n_tiles) + ckpt_unit(start, tile, seg + 1, ckpt_shift) * (size_t)(1 + channels) * 256 + lane;
+    hi = min(hi, nxt - 1);           // this unit walks [lo, min(hi, nxt - 1)]
+  }
+  // the frame's values of this lane's pixels: every load is issued before the first use (one round trip, not one per
+  // quadrant: a segment's prologue is paid three to five times per tile)
+  bool inside[NQ];
+  float px_alpha[NQ], px_va[NQ], px_fin[NQ][CHT], px_ck[NQ][CHT + 1];
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     const int x = ix + 8 * (k & 1), y = iy + 8 * (k >> 1);
-    const bool inside = x < width && y < height;
-    const size_t p = inside ? (size_t)y * width + x : 0;
-    st[k].T = inside ? 1.0f - alphas[p] : 1.f;           // starts at the pixel's final transmittance
-    st[k].last = inside ? last_ids[p] : -1;
-    float va = (inside && v_alphas) ? v_alphas[p] : 0.f;      // v_alphas == nullptr: no loss term on alpha
+    inside[k] = x < width && y < height;
+    const size_t p = inside[k] ? (size_t)y * width + x : 0;
+    px_alpha[k] = inside[k] ? alphas[p] : 0.f;
+    st[k].last = inside[k] ? last_ids[p] : -1;
+    px_va[k] = (inside[k] && v_alphas) ? v_alphas[p] : 0.f;      // v_alphas == nullptr: no loss term on alpha
+    if (CHT == 4 && channels == 4) {           // (16-byte rows)
+      const float4 v = inside[k] ? reinterpret_cast<const float4*>(v_render)[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+      st[k].v_c[0] = v.x; st[k].v_c[1 % CHT] = v.y; st[k].v_c[2 % CHT] = v.z; st[k].v_c[3 % CHT] = v.w;
+    } else {
 #pragma unroll
-    for (int c = 0; c < CHT; ++c)
-      st[k].v_c[c] = (inside && c < channels) ? v_render[p * channels + c] : 0.f;
-    if (expected_render && inside) {
+      for (int c = 0; c < CHT; ++c)
+        st[k].v_c[c] = (inside[k] && c < channels) ? v_render[p * channels + c] : 0.f;
+    }
+    // the forward's frame: "ED" needs its last channel, a segment with a successor all of it
+    const float* frame = SPLIT ? (has_next ? render_out : expected_render) : expected_render;
+#pragma unroll
+    for (int c = 0; c < CHT; ++c) px_fin[k][c] = 0.f;
+    if (frame && inside[k]) {
+      if (CHT == 4 && channels == 4) {
+        const float4 v = reinterpret_cast<const float4*>(frame)[p];
+        px_fin[k][0] = v.x; px_fin[k][1 % CHT] = v.y; px_fin[k][2 % CHT] = v.z; px_fin[k][3 % CHT] = v.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < CHT; ++c)
+          if (c < channels && (SPLIT ? (has_next || c == channels - 1) : c == channels - 1)) px_fin[k][c] = frame[p * channels + c];
+      }
+    }
+    if constexpr (SPLIT) {
+      // (unconditional per lane: the buffer exists for every unit; what a finished block never wrote is not used)
+#pragma unroll
+      for (int c = 0; c <= CHT; ++c) px_ck[k][c] = (has_next && c <= channels) ? cp[256 * c + 64 * k] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    st[k].T = 1.0f - px_alpha[k];                        // starts at the pixel's final transmittance (1 outside the image)
+    float va = px_va[k];
+    if (expected_render && inside[k]) {
       // the forward divided the last channel by max(alpha, 1e-10) ("ED"): ED = D / a, so
       // dL/dD = v_ED / a and dL/dalpha -= v_ED ED / a (where a > 1e-10)
-      const float a = alphas[p], inv = 1.0f / fmaxf(a, 1e-10f);
+      const float a = px_alpha[k], inv = 1.0f / fmaxf(a, 1e-10f);
 #pragma unroll
       for (int c = 0; c < CHT; ++c)
         if (c == channels - 1) {
           const float v_ed = st[k].v_c[c];
-          if (a > 1e-10f) va -= v_ed * expected_render[p * channels + c] * inv;
+          if (a > 1e-10f) va -= v_ed * px_fin[k][c] * inv;
           st[k].v_c[c] = v_ed * inv;
         }
     }
@@ -255,13 +356,35 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
     for (int c = 0; c < CHT; ++c)
       if (background && c < channels) va -= background[c] * st[k].v_c[c];
     st[k].bv = -(st[k].T * va);
-    hi = max(hi, st[k].last);
-  }
-  // wave-wide maximum of the last contributing index
+    if constexpr (SPLIT) {
+      // a pixel whose last contributor lies in or past the next segment starts from the forward's state in front of
+      // that segment: T as stored; colour behind = final - accumulated so far.  The final sums are taken back out of
+      // the frame: render = C + T_final * background, last channel times 1 / max(alpha, 1e-10) in "ED" mode.
+      if (has_next && st[k].last >= nxt) {
+        const float a = px_alpha[k], t_final = st[k].T;
+        float behind = 0.f;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) hi = max(hi, __shfl_xor(hi, d));
-  hi = min(hi, end - 1);
-  if (hi < start) return;
+        for (int c = 0; c < CHT; ++c)
+          if (c < channels) {
+            float fin = px_fin[k][c];
+            if (expected_render && c == channels - 1) fin *= fmaxf(a, 1e-10f);
+            if (background) fin = fmaf(-t_final, background[c], fin);
+            behind = fmaf(fin - px_ck[k][1 + c], st[k].v_c[c], behind);
+          }
+        st[k].bv += behind;
+        st[k].T = px_ck[k][0];
+      }
+    } else {
+      hi = max(hi, st[k].last);
+    }
+  }
+  if constexpr (!SPLIT) {
+    // wave-wide maximum of the last contributing index
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hi = max(hi, __shfl_xor(hi, d));
+    hi = min(hi, end - 1);
+    if (hi < start) return;
+  }
 #ifdef MGS_RASTER_BWD_TIMING
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
   unsigned long long n_walked = 0, n_pairs = 0;
@@ -312,7 +435,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
   bool pend = false;            // PIPE: an entry's partial sums are parked in `red`, its record not yet stored
   size_t pend_slot = 0;
 
-  for (int q = (hi - start) / kQueue; q >= 0; --q) {
+  for (int q = (hi - start) / kQueue; q >= (lo - start) / kQueue; --q) {
     const int b = start + q * kQueue;
     // quadrants that still have a pixel with something left at or above this batch
     unsigned live = 0;
@@ -352,7 +475,7 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
     n_walked += (unsigned long long)min(64, hi - b + 1);
     n_pairs += (unsigned long long)count;
 #endif
-    const bool all_safe = ballot(qmask != 0u && !(sigma_sign_is_safe(ca, cb, cc) && op <= kSafeOpacity)) == 0ull;
+    const bool all_safe = ballot(qmask != 0u && !entry_is_safe(ca, cb, cc, op)) == 0ull;
     if (qmask != 0u) {
       BwdEntry<CHT, WIDE>& e = queue[mask_rank(keep)];
       constexpr float kLog2e = 1.4426950408889634f;
@@ -408,12 +531,12 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
       gg.s = gg.s_x = gg.s_y = gg.s_xx = gg.s_xy = gg.s_yy = gg.a_x = gg.a_y = 0.f;
 #pragma unroll
       for (int c = 0; c < CHT; ++c) gg.v_f[c] = 0.f;
-      bool any = false;
+      int any = 0;
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         if (m & (1u << k))
-          any |= grad_pixel<CHT, ABSGRAD, SAFE>(st[k], gg, pq[k], g2.y, g2.z, g3.x, g3.y, g3.z, g0.w, g1.x, g1.y,
-                                                g0.x, g0.y, g0.z, feat, gi);
+          grad_pixel<CHT, ABSGRAD, SAFE>(st[k], gg, pq[k], g2.y, g2.z, g3.x, g3.y, g3.z, g0.w, g1.x, g1.y,
+                                         g0.x, g0.y, g0.z, feat, gi, any);
       }
       if (PIPE && pend) {
         red_finish(pend_slot, pa0, pb0, pa1, pb1);
@@ -541,13 +664,83 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
     red_finish(pend_slot, a0, b0, a1, b1);
   }
 #ifdef MGS_RASTER_BWD_TIMING
-  if (lane == 0 && tile < 16384) {
-    g_bwd_times[4 * tile + 0] = t_begin;
-    g_bwd_times[4 * tile + 1] = __builtin_amdgcn_s_memrealtime();
-    g_bwd_times[4 * tile + 2] = n_walked;
-    g_bwd_times[4 * tile + 3] = n_pairs;
+  if (lane == 0 && unit < 65536) {
+    g_bwd_times[5 * unit + 0] = t_enter;
+    g_bwd_times[5 * unit + 1] = t_begin;
+    g_bwd_times[5 * unit + 2] = __builtin_amdgcn_s_memrealtime();
+    g_bwd_times[5 * unit + 3] = n_walked;
+    g_bwd_times[5 * unit + 4] = n_pairs;
   }
 #endif
+}
+
+template <int CHT, bool ABSGRAD, bool RECORDS, bool HALF = false, bool SPLIT = false>
+__global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS && !ABSGRAD && !HALF) ? MGS_RASTER_BWD_MIN_WAVES : 1) void raster_bwd_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ feats, const float* __restrict__ opacities,
+    const float4* __restrict__ splats, const float* __restrict__ background, int channels,
+    int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
+    const float* __restrict__ v_alphas, float* __restrict__ v_means2d,
+    float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
+    float* __restrict__ v_feats, float* __restrict__ v_opacities,
+    const int4* __restrict__ pair_info, float* __restrict__ records,
+    uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ expected_render,
+    const int32_t* __restrict__ tile_order, const float* __restrict__ ckpt, int ckpt_shift,
+    const int32_t* __restrict__ seg_table, const float* __restrict__ render_out) {
+#define MGS_RB_ARGS means2d, conics, feats, opacities, splats, background, channels, width, height, tile_w, n_tiles, \
+    tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_feats,    \
+    v_opacities, pair_info, records, flags, capacity, expected_render, tile_order, ckpt, ckpt_shift, seg_table, render_out
+  raster_bwd_unit<CHT, ABSGRAD, RECORDS, HALF, SPLIT>(blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6), MGS_RB_ARGS);
+#undef MGS_RB_ARGS
+}
+
+// SPLIT: the units of the segmented launch, one thread per tile: the segments some pixel of the tile reaches (the forward
+// left the end of the tile's walk in the checkpoint header).  WHOLE segments go to one table (a cursor per workgroup
+// scan), every tile's last, partly walked segment to the table of its length class (32 classes, longest first); the
+// raster's unit u is whole[u] or, past those, the (u - n_whole)-th partial one counted through the classes.  All
+// whole segments cost about the same, so with the short ones at the end of the launch the chip drains in the time of
+// a short unit instead of a whole one (a unit is one wave's serial job; scripts/dbg/bwd_timeline.py).
+// counts[0] = whole segments, counts[1 + c] = partial segments of class c: zeroed by the caller's memset.
+__global__ __launch_bounds__(256) void unit_table_kernel(int n_tiles, const int32_t* __restrict__ tile_offsets,
+                                                         const int32_t* __restrict__ tile_hi, int shift, uint32_t capacity,
+                                                         int32_t* __restrict__ tables) {
+  __shared__ uint32_t wave_tot[4], base;
+  const UnitTables ut = unit_tables(tables, n_tiles, shift, capacity);
+  const int tile = blockIdx.x * 256 + threadIdx.x, t = threadIdx.x;
+  int n_seg = 0, last_len = 0, u_start = 0, u_hi = 0;
+  if (tile < n_tiles) {
+    const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+    const int4 h4 = reinterpret_cast<const int4*>(tile_hi)[tile];
+    const int hi = min(max(max(h4.x, h4.y), max(h4.z, h4.w)), end - 1);
+    u_start = start;
+    u_hi = hi;
+    if (hi >= start) {
+      n_seg = ((hi - start) >> shift) + 1;
+      last_len = ((hi - start) & ((1 << shift) - 1)) + 1;
+    }
+  }
+  const uint32_t mine = n_seg > 0 ? (uint32_t)(n_seg - 1) : 0u;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d);
+    if ((t & 63) >= d) incl += up;
+  }
+  if ((t & 63) == 63) wave_tot[t >> 6] = incl;
+  __syncthreads();
+  uint32_t at = incl - mine;
+  for (int w = 0; w < (t >> 6); ++w) at += wave_tot[w];
+  if (t == 255) base = atomicAdd(&ut.counts[0], at + mine);
+  __syncthreads();
+  at += base;
+  for (int sg = 0; sg + 1 < n_seg; ++sg) ut.whole[at + sg] = make_int4(tile, sg, u_start, u_hi);
+  if (n_seg > 0) {
+    const int c = ((1 << shift) - last_len) * kUnitClasses >> shift;          // 0 = the longest
+    const uint32_t pos = atomicAdd(&ut.counts[1 + c], 1u);
+    ut.part[(size_t)c * n_tiles + pos] = make_int4(tile, n_seg - 1, u_start, u_hi);
+  }
 }
 
 // Sum the records of each Gaussian's slots (its tile rectangle, emit order) into the outputs.  A record holds the
@@ -642,7 +835,7 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   }
   if (cnt > 0) {   // apply the Gaussian's conic once, here; opacity * d/d opacity = -sum v_sigma
     finish_geo(ca, cb, cc, acc[0], acc[1], acc[2], acc[4]);
-    acc[5] = -acc[5] / op;
+    acc[5] = op > 0.f ? -acc[5] / op : 0.f;     // (an opacity of exactly 0 owns slots under classic tile bounds: s is 0 there, not 0 / 0)
   }
 #if MGS_REDUCE_EXP == 3      // measurement: (nearly) no stores
   if (acc[0] != 12345.f) return;
@@ -664,8 +857,13 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
 using namespace mgs;
 
 #ifdef MGS_RASTER_BWD_TIMING
-extern "C" int mgs_debug_bwd_times(unsigned long long* host, int n_words) {
+extern "C" int mgs_debug_bwd_times(unsigned long long* host, int n_words) {      // copies the stamps out and clears them
   hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_times), (size_t)n_words * 8);
+  if (e == hipSuccess) {
+    void* dev = nullptr;
+    e = hipGetSymbolAddress(&dev, HIP_SYMBOL(g_bwd_times));
+    if (e == hipSuccess) e = hipMemset(dev, 0, sizeof(g_bwd_times));
+  }
   return e == hipSuccess ? 0 : (int)e;
 }
 #endif
@@ -695,7 +893,7 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities,                 \
                      (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr, 0u, (const float*)nullptr, \
-                     (const int32_t*)nullptr)
+                     (const int32_t*)nullptr, (const float*)nullptr, 0, (const int32_t*)nullptr, (const float*)nullptr)
 #define MGS_RB(C) if (v_means2d_abs) MGS_RB_LAUNCH(C, true); else MGS_RB_LAUNCH(C, false)
   if (channels == 1) { MGS_RB(1); }
   else if (channels == 2) { MGS_RB(2); }
@@ -719,7 +917,8 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                                      const float* v_render, const float* v_alphas,
                                      const float* expected_render,
                                      const int32_t* pair_info, const int32_t* tile_group_order,
-                                     uint32_t isect_capacity,
+                                     uint32_t isect_capacity, const float* render_out,
+                                     const float* checkpoints, int checkpoint_interval,
                                      float* v_means2d, float* v_means2d_abs, float* v_conics,
                                      float* v_feats, float* v_opacities, void* workspace,
                                      size_t* workspace_bytes, mgs_stream_t stream) {
@@ -734,7 +933,22 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   constexpr size_t kSlots = kHalf ? 2 : 1;
   const size_t rec_bytes = align_up(cap * kSlots * rs * sizeof(float), 256);
   const size_t flag_bytes = align_up(cap * kSlots, 256);
-  const size_t need = rec_bytes + flag_bytes + align_up((size_t)tile_w * tile_h * sizeof(int32_t), 256);
+  // segmented walk (checkpoints from mgs_rasterize_fwd): up to 4 channels, whole tiles
+  int ckpt_shift = 0;
+  const bool split = checkpoints != nullptr && channels <= 4 && !kHalf;
+  if (checkpoints) {
+    MGS_REQUIRE(checkpoint_interval >= 64 && (checkpoint_interval & (checkpoint_interval - 1)) == 0,
+                "rasterize_bwd_det: checkpoint_interval %d is not a power of two >= 64", checkpoint_interval);
+    MGS_REQUIRE(render_out, "rasterize_bwd_det: checkpoints need render_out (the forward's frame)");
+    MGS_REQUIRE(!expected_render || expected_render == render_out, "rasterize_bwd_det: expected_render and render_out are the same frame");
+    while ((1 << ckpt_shift) < checkpoint_interval) ++ckpt_shift;
+  }
+  const size_t n_seg_units = checkpoints ? ckpt_units((uint32_t)cap, tile_w * tile_h, ckpt_shift) : 0;
+  // behind the flags: the launch order of the whole-tile walk, or the unit tables of the segmented one (their 64
+  // counters first: zeroed together with the flags)
+  const size_t order_bytes = align_up(std::max((size_t)tile_w * tile_h * sizeof(int32_t),
+                                               checkpoints ? unit_tables_bytes(tile_w * tile_h, ckpt_shift, (uint32_t)cap) : 0), 256);
+  const size_t need = rec_bytes + flag_bytes + order_bytes;
   if (!workspace) {
     *workspace_bytes = need;
     return MGS_OK;
@@ -745,6 +959,9 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   if (n == 0) return MGS_OK;
   MGS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15u) == 0, "rasterize_bwd_det: workspace must be 16-byte aligned");
   MGS_REQUIRE(!splats || channels <= 4, "rasterize_bwd_det: packed splats carry at most 4 channels");
+  MGS_REQUIRE(channels != 4 || (((reinterpret_cast<uintptr_t>(v_render) | reinterpret_cast<uintptr_t>(expected_render) |
+                                  reinterpret_cast<uintptr_t>(render_out)) & 15u) == 0),
+              "rasterize_bwd_det: 4-channel frames (v_render, expected_render, render_out) must be 16-byte aligned");
   MGS_REQUIRE((splats || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
                   alphas && last_ids && v_render && pair_info && v_means2d && v_conics &&
                   v_feats && v_opacities, "rasterize_bwd_det: null pointer");
@@ -752,11 +969,16 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   hipStream_t s = (hipStream_t)stream;
   float* records = static_cast<float*>(workspace);
   uint8_t* flags = static_cast<uint8_t*>(workspace) + rec_bytes;
-  hipError_t e = hipMemsetAsync(flags, 0, cap * kSlots, s);
+  hipError_t e = hipMemsetAsync(flags, 0, flag_bytes + (split ? 256 : 0), s);
   if (e != hipSuccess) return set_error((int)e, "rasterize_bwd_det: memset: %s", hipGetErrorString(e));
   const int4* info = reinterpret_cast<const int4*>(pair_info);
   const int32_t* order = nullptr;
-  if (!kHalf && MGS_RASTER_BWD_ORDER) {
+  int32_t* seg_table = nullptr;
+  if (split) {
+    seg_table = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes);
+    hipLaunchKernelGGL(unit_table_kernel, dim3(div_up(n_tiles, 256)), dim3(256), 0, s, n_tiles, tile_offsets,
+                       reinterpret_cast<const int32_t*>(checkpoints), ckpt_shift, (uint32_t)cap, seg_table);
+  } else if (!kHalf && MGS_RASTER_BWD_ORDER) {
     order = tile_group_order;
     if (!order) {       // the caller's lists came without one (mgs_isect_tiles writes it): compute it here
       int32_t* mine = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes);
@@ -765,15 +987,17 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
       order = mine;
     }
   }
-  const int n_units = order ? (n_tiles + 3) / 4 * 4 : n_tiles * (int)kSlots;
-#define MGS_RD_LAUNCH(C, A)                                                                     \
-  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf>), dim3(div_up(n_units, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), MGS_RASTER_BWD_LDS_PAD, s, means2d,   \
+  const int n_units = split ? (int)n_seg_units : order ? (n_tiles + 3) / 4 * 4 : n_tiles * (int)kSlots;
+#define MGS_RD_RASTER(C, A, SP)                                                                 \
+  hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf, SP>), dim3(div_up(n_units, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), MGS_RASTER_BWD_LDS_PAD, s, means2d,   \
                      conics, feats, opacities, reinterpret_cast<const float4*>(splats),        \
                      background, channels, width, height, tile_w,                              \
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
                      (float*)nullptr, info, records, flags, (uint32_t)cap, expected_render,    \
-                     (const int32_t*)order);                                                   \
+                     (const int32_t*)order, checkpoints, ckpt_shift, (const int32_t*)seg_table, render_out)
+#define MGS_RD_LAUNCH(C, A)                                                                     \
+  if (split) MGS_RD_RASTER(C, A, ((C) <= 4 && !kHalf)); else MGS_RD_RASTER(C, A, false);        \
   hipLaunchKernelGGL((reduce_records_kernel<C, A, (int)kSlots>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
                      info, records, flags, (uint32_t)cap, means2d, conics, opacities,          \
                      reinterpret_cast<const float4*>(splats),                                  \
@@ -788,5 +1012,6 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   else { MGS_RD(32) }
 #undef MGS_RD
 #undef MGS_RD_LAUNCH
+#undef MGS_RD_RASTER
   return check_launch("rasterize_bwd_det");
 }

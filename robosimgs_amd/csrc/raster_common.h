@@ -128,6 +128,33 @@ __device__ __forceinline__ float pair_power_poly(const PixelPoly& p, float q0, f
 // Batches whose queued Gaussians all have a well conditioned conic AND an opacity <= kSafeOpacity are walked
 // without the sigma >= 0 test and without the 0.999 clamp: exp2(power + L) <= opacity (1 + 2^-22) < 0.999.
 constexpr float kSafeOpacity = 0.998f;
+// The bound above holds for the polynomial about the tile centre while its absolute error ~2^-24 |A| m^2 (m <= ~11 px)
+// stays far below 2^-10: conics of the default eps2d = 0.3 have a, c <= 3.4.  A caller with a tiny eps2d can hand over
+// conics of 1e3 and more; those take the clamped, sign-tested body (a + c <= 8 is always true at eps2d >= 0.25).
+constexpr float kSafeConicTrace = 8.0f;
+__device__ __forceinline__ bool entry_is_safe(float a, float b, float c, float op) {
+  return sigma_sign_is_safe(a, b, c) && op <= kSafeOpacity && a + c <= kSafeConicTrace;
+}
+
+// ---- forward checkpoints for the segmented backward ---------------------------------------------------------
+// A tile's list is cut into SEGMENTS of S = 1 << shift entries (S a multiple of the 64-entry batch, aligned to the
+// list's start, so the batches -- and with them every queue and every per-entry value -- are those of the unsegmented
+// walk).  The training forward stores, at the first batch of every segment s >= 1 that some pixel of the block still
+// reaches, the per-pixel state in front of that batch -- T and the accumulated channels -- and the backward then walks
+// every segment as an independent unit of work: a segment that has a successor starts from the successor's
+// checkpoint (T as stored; colour behind = final - checkpoint) instead of from the far end of the list.
+// Unit of (tile t, segment s) = (start_t >> shift) + t + s: injective (floor((a + L) / S) - floor(a / S) >=
+// ceil(L / S) - 1), bounded by (capacity >> shift) + n_tiles, and needs no prefix sum over the tiles.
+// Layout: checkpoints[unit][1 + channels][256] floats, pixel k * 64 + lane of the tile (quadrant k, raster_common.h),
+// behind a header of 4 int32 per tile: the largest last_id of each of the tile's four 8x8 blocks (-1: not written by
+// this forward schedule) -- where the backward's walk of the tile ends, known before any pixel is loaded.
+__host__ __device__ constexpr size_t ckpt_units(uint32_t capacity, int n_tiles, int shift) {
+  return ((size_t)capacity >> shift) + (size_t)n_tiles + 1;
+}
+__host__ __device__ constexpr size_t ckpt_header_floats(int n_tiles) { return ((size_t)n_tiles * 4 + 255) / 256 * 256; }
+__device__ __forceinline__ size_t ckpt_unit(int start, int tile, int seg, int shift) {
+  return (size_t)(start >> shift) + (size_t)tile + (size_t)seg;
+}
 
 // A queue entry part is read from LDS as ONE ds_read_b128: an empty asm that "uses" all four lanes of the register
 // tuple keeps the compiler from narrowing the load to the components the caller happens to touch (it split a 16-byte

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
     float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last, int opts,
-    const int32_t* __restrict__ group_order) {
+    const int32_t* __restrict__ group_order, float* __restrict__ ckpt, int ckpt_shift) {
   constexpr int kWgWaves = TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES;
   __shared__ QueueEntry<CHT> queues[kWgWaves][kQueue + 1];
   QueueEntry<CHT>* queue = queues[threadIdx.x >> 6];
@@ -335,6 +335,19 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     for (int k = 0; k < 4; ++k)
       if ((kMasks<CHT> ? alive[k] : ballot(st[k].T > 0.f)) != 0ull) live |= 1u << k;
     if (live == 0) break;
+    if constexpr (TRACK_LAST) {
+      // first batch of a segment (raster_common.h: checkpoints): the state in front of it, for the segmented backward
+      if (ckpt && b != start && ((b - start) & ((1 << ckpt_shift) - 1)) == 0) {
+        float* cp = ckpt + ckpt_header_floats(n_tiles) + ckpt_unit(start, tile, (b - start) >> ckpt_shift, ckpt_shift) * (size_t)(1 + channels) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          cp[64 * k] = fabsf(st[k].T);
+#pragma unroll
+          for (int c = 0; c < CHT; ++c)
+            if (c < channels) cp[256 * (1 + c) + 64 * k] = st[k].C[c];
+        }
+      }
+    }
 
     // take the prefetched batch, start the next one
 #if MGS_RASTER_NO_PREFETCH
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     // every queued Gaussian of this batch has a well conditioned conic and an opacity <= 0.999 (nearly
     // always): the sigma >= 0 test and the 0.999 clamp are dead for the whole batch and the walk below runs
     // without them (raster_common.h: sigma_sign_is_safe) -- two compare / min class instructions less per 64 pairs
-    const bool all_safe = ballot(qmask != 0u && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
+    const bool all_safe = ballot(qmask != 0u && !entry_is_safe(c_ca, c_cb, c_cc, c_op)) == 0ull;
     const int count = __popcll(keep);
     MGS_STAT(0, __popcll(ballot(c_ok)));
     MGS_STAT(1, count);
@@ -479,6 +492,14 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
       for (int i = 0; i < 7; ++i) atomicAdd(&g_raster_stats[i], stat[i]);
   }
 #endif
+  if constexpr (TRACK_LAST) {
+    if (ckpt) {       // where the backward's walk of this tile ends (header of the checkpoint buffer)
+      int h = max(max(st[0].last, st[1].last), max(st[2].last, st[3].last));
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) h = max(h, __shfl_xor(h, d));
+      if (lane < 4) reinterpret_cast<int32_t*>(ckpt)[4 * tile + lane] = lane == 0 ? h : -1;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int x = ix + 8 * (k & 1), y = iy + 8 * (k >> 1);
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
     float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last,
-    const int32_t* __restrict__ group_order) {
+    const int32_t* __restrict__ group_order, float* __restrict__ ckpt, int ckpt_shift) {
   __shared__ QueueEntry<CHT> queues[4][kQueue];
 #ifdef MGS_RASTER_Q_VGPR_CLOBBER
   // occupancy experiment: naming a high VGPR raises the kernel's register allocation (and lowers its
@@ -577,6 +598,18 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
 
   for (int b = start; b < end; b += kQueue) {
     if ((kMasks<CHT> ? alive : ballot(st.T > 0.f)) == 0ull) break;          // every pixel of the block is finished
+    if constexpr (TRACK_LAST) {
+      // first batch of a segment (raster_common.h: checkpoints): this block's state in front of it.  A block that is
+      // finished by then stores nothing: none of its pixels has a last_id in or past the segment, and the backward
+      // takes a checkpoint only for pixels that do.
+      if (ckpt && b != start && ((b - start) & ((1 << ckpt_shift) - 1)) == 0) {
+        float* cp = ckpt + ckpt_header_floats(n_tiles) + ckpt_unit(start, tile, (b - start) >> ckpt_shift, ckpt_shift) * (size_t)(1 + channels) * 256 + 64 * k + lane;
+        cp[0] = fabsf(st.T);
+#pragma unroll
+        for (int c = 0; c < CHT; ++c)
+          if (c < channels) cp[256 * (1 + c)] = st.C[c];
+      }
+    }
     const int c_idx = r_idx;
     const bool c_ok = r_ok;
     const float2 c_xy = r_xy;
@@ -606,7 +639,7 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
     }
     const unsigned long long keep = ballot(keep_me);
     const int count = __popcll(keep);
-    const bool all_safe = ballot(keep_me && !(sigma_sign_is_safe(c_ca, c_cb, c_cc) && c_op <= kSafeOpacity)) == 0ull;
+    const bool all_safe = ballot(keep_me && !entry_is_safe(c_ca, c_cb, c_cc, c_op)) == 0ull;
     if (keep_me) {
       QueueEntry<CHT>& e = queue[mask_rank(keep)];
       const float sA = -0.5f * kLog2e * c_ca, sB = -kLog2e * c_cb, sC = -0.5f * kLog2e * c_cc;
@@ -672,6 +705,14 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
     __builtin_amdgcn_wave_barrier();
   }
 
+  if constexpr (TRACK_LAST) {
+    if (ckpt) {       // where the backward's walk of this block ends (header of the checkpoint buffer)
+      int h = inside ? st.last : -1;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) h = max(h, __shfl_xor(h, d));
+      if (lane == 0) reinterpret_cast<int32_t*>(ckpt)[4 * tile + k] = h;
+    }
+  }
   if (inside) {
     const size_t p = (size_t)iy * width + ix;
     const float alpha = 1.0f - fabsf(st.T);
@@ -716,12 +757,22 @@ extern "C" int mgs_debug_read_raster_stats(unsigned long long* out8) {
 }
 #endif
 
+extern "C" size_t mgs_raster_checkpoint_floats(uint32_t isect_capacity, int tile_w, int tile_h, int channels,
+                                               int checkpoint_interval) {
+  if (checkpoint_interval < 64 || (checkpoint_interval & (checkpoint_interval - 1)) || tile_w <= 0 || tile_h <= 0 || channels < 1)
+    return 0;
+  int shift = 0;
+  while ((1 << shift) < checkpoint_interval) ++shift;
+  return ckpt_header_floats(tile_w * tile_h) + ckpt_units(isect_capacity, tile_w * tile_h, shift) * (size_t)(1 + channels) * 256;
+}
+
 extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conics,
                                  const float* feats, const float* opacities, const float* splats,
                                  const float* background, int channels, int width, int height,
                                  int tile_w, int tile_h, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, const int32_t* tile_group_order, int flags,
-                                 float* render, float* alphas, int32_t* last_ids, mgs_stream_t stream) {
+                                 float* render, float* alphas, int32_t* last_ids, float* checkpoints,
+                                 int checkpoint_interval, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_fwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
@@ -729,6 +780,13 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   MGS_REQUIRE(!splats || channels <= 4, "rasterize_fwd: packed splats carry at most 4 channels");
   MGS_REQUIRE((n == 0 || splats || (means2d && conics && feats && opacities)) && tile_offsets &&
                   flatten_ids && render && alphas, "rasterize_fwd: null pointer");
+  int ckpt_shift = 0;
+  if (checkpoints) {
+    MGS_REQUIRE(last_ids, "rasterize_fwd: checkpoints are written by the training variant (last_ids given)");
+    MGS_REQUIRE(checkpoint_interval >= 64 && (checkpoint_interval & (checkpoint_interval - 1)) == 0,
+                "rasterize_fwd: checkpoint_interval %d is not a power of two >= 64", checkpoint_interval);
+    while ((1 << ckpt_shift) < checkpoint_interval) ++ckpt_shift;
+  }
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
   const bool per_block = (g_raster_opts & 4) || ((g_raster_opts & 2) && (flags & MGS_RASTER_LATENCY));
@@ -741,12 +799,12 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
                      feats, opacities, reinterpret_cast<const float4*>(splats), background,     \
                      channels, width, height, tile_w, n_tiles,                                 \
                      tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull,            \
-                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, g_raster_opts, tile_group_order)
+                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, g_raster_opts, tile_group_order, checkpoints, ckpt_shift)
 #define MGS_RQ_LAUNCH_T(C, T)                                                                  \
   hipLaunchKernelGGL((raster_fwd_q_kernel<C, T>), dim3(n_units), dim3(256), (size_t)(g_raster_opts >> 8) * 1024, s, means2d, conics, feats,  \
                      opacities, reinterpret_cast<const float4*>(splats), background, channels, width,      \
                      height, tile_w, n_tiles, tile_offsets, flatten_ids, render, alphas, last_ids,         \
-                     g_raster_cull, (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, tile_group_order)
+                     g_raster_cull, (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, tile_group_order, checkpoints, ckpt_shift)
 #define MGS_RF_LAUNCH(C) do {                                                                      \
     if (per_block && (C) <= 4) { if (last_ids) MGS_RQ_LAUNCH_T(C, true); else MGS_RQ_LAUNCH_T(C, false); } \
     else if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)

@@ -183,16 +183,27 @@ def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, vie
     return render, alphas, n_isect, status
 
 
+def checkpoint_buffer(capacity: int, tile_w: int, tile_h: int, channels: int, interval: int, device) -> Tensor:
+    """The buffer rasterize_fwd_raw(checkpoints=...) writes for lists of up to `capacity` entries."""
+    n = _lib.lib().mgs_raster_checkpoint_floats(int(capacity), tile_w, tile_h, channels, int(interval))
+    if n == 0:
+        raise ValueError(f"checkpoint interval {interval} is not a power of two >= 64")
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                       tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None,
-                      expected_last=False, latency=False, group_order=None, channels=None):
+                      expected_last=False, latency=False, group_order=None, channels=None,
+                      checkpoints=None, checkpoint_interval=0):
     """out = (render, alphas, last_ids|None) to write into existing buffers.  With `splats` (<= 4 channels)
     means2d / conics / feats / opacities are not read and may be None; give `channels` then.  track_last=False (or
     last_ids None) is the inference variant: no last_ids, one select less per pair.
     expected_last: the last channel leaves divided by max(alpha, 1e-10) ("ED" modes).
     latency: MGS_RASTER_LATENCY -- one wave per 8x8 block; faster when the launch has the GPU to itself
     (a single frame, a training step), slower in total work when several frames are in flight.
-    group_order: TileLists.group_order -- the tiles are then started longest lists first."""
+    group_order: TileLists.group_order -- the tiles are then started longest lists first.
+    checkpoints (checkpoint_buffer(...)) + checkpoint_interval: the training variant also stores every pixel's state
+    every `checkpoint_interval` list entries, for rasterize_bwd_det_raw(checkpoints=...)."""
     src = means2d if means2d is not None else splats
     n = src.shape[0]
     ch = int(channels) if channels is not None else feats.shape[-1]
@@ -208,7 +219,8 @@ def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, heig
                                        ptr(splats), ptr(background), ch, width, height, tile_w, tile_h,
                                        ptr(tile_offsets), ptr(flatten_ids), ptr(group_order),
                                        int(bool(expected_last)) | (2 if latency else 0),
-                                       ptr(render), ptr(alphas), ptr(last_ids), stream_handle()),
+                                       ptr(render), ptr(alphas), ptr(last_ids), ptr(checkpoints),
+                                       int(checkpoint_interval), stream_handle()),
           "mgs_rasterize_fwd")
     return render, alphas, last_ids
 
@@ -239,10 +251,12 @@ def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, heig
 
 def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                           tile_h, tl: "TileLists", alphas, last_ids, v_render, v_alphas,
-                          absgrad=False, splats=None, canary_bytes=0, expected_render=None):
+                          absgrad=False, splats=None, canary_bytes=0, expected_render=None,
+                          render_out=None, checkpoints=None, checkpoint_interval=0):
     """Atomic-free, bit-reproducible raster backward (needs tl.pair_info from the binning).
     Returns freshly written (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None).
     expected_render: the forward's frame when it ran with expected_last (the kernel undoes the divide).
+    checkpoints + checkpoint_interval + render_out (the forward's frame): the segmented walk (include/mgs.h).
     canary_bytes (tests): that many 0xA5 bytes are kept behind the workspace the library asked for
     and returned as a sixth value, so a test can see that nothing was written past the workspace."""
     n = means2d.shape[0]
@@ -259,6 +273,7 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
             ch, width, height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
             ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(expected_render), ptr(tl.pair_info),
             ptr(getattr(tl, "group_order", None)), tl.capacity,
+            ptr(render_out), ptr(checkpoints), int(checkpoint_interval),
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det(size query)")

@@ -57,7 +57,7 @@ class _RenderSH(torch.autograd.Function):
     def forward(ctx, means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds,
                 width, height, sh_degree, eps2d, near_plane, far_plane, radius_clip,
                 antialiased, with_depth, isect_capacity, absgrad, meta_out, tight, expected_depth,
-                latency, lean):
+                latency, lean, segment):
         C = viewmats.shape[0]
         dev = means.device
         tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
@@ -98,23 +98,28 @@ class _RenderSH(torch.autograd.Function):
                                      want_pair_info=training, want_tile_ids=not lean,
                                      conics=conics if tight else None,
                                      opacities=opac if tight else None, seed=seed)
+            # training: the forward leaves per-pixel checkpoints every `segment` list entries, so that the backward
+            # can walk a tile's list as independent segments (include/mgs.h: mgs_rasterize_fwd)
+            ckpt = ops.checkpoint_buffer(cap, tile_w, tile_h, ch, segment, dev) if (training and segment) else None
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,
                                   out=(render[c], alphas[c], last_ids[c] if training else None),
                                   splats=splats, expected_last=expected_depth, latency=latency,
-                                  group_order=tl.group_order, channels=ch)
-            per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl, splats))
+                                  group_order=tl.group_order, channels=ch, checkpoints=ckpt,
+                                  checkpoint_interval=segment if ckpt is not None else 0)
+            per_cam.append((radii, means2d, depths, conics, opac_aa, feats, tl, splats, ckpt))
         ctx.per_cam = per_cam
         # "RGB+ED": the kernel's epilogue divided the depth channel by max(alpha, 1e-10); the
         # backward undoes that with the saved frame (an OUTPUT: it must go through
         # save_for_backward -- parked on ctx it forms a reference cycle that crashes HIP graph capture)
         ctx.expected_depth = bool(expected_depth)
         ctx.channels = ch
+        ctx.segment = int(segment) if training else 0
         ctx.set_materialize_grads(False)       # an unused output's cotangent arrives as None, not as a zero frame
         ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks,
                               backgrounds, alphas, last_ids,
-                              render if (expected_depth and training) else None)
+                              render if ((expected_depth or segment) and training) else None)
         ctx.cfg = (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth,
                    absgrad)
         meta_out["per_cam"] = per_cam
@@ -145,13 +150,15 @@ class _RenderSH(torch.autograd.Function):
         v_viewmats = torch.zeros_like(viewmats) if ctx.needs_input_grad[5] else None
         L = _lib.lib()
         for c in range(C):
-            radii, means2d, depths, conics, opac_aa, feats, tl, splats = ctx.per_cam[c]
+            radii, means2d, depths, conics, opac_aa, feats, tl, splats, ckpt = ctx.per_cam[c]
             opac = opac_aa if antialiased else opacities
             bg = backgrounds[c] if backgrounds is not None else None
             v_means2d, v_conics, v_feats, v_opac, v_abs = ops.rasterize_bwd_det_raw(
                 means2d, conics, feats, opac, bg, width, height, tile_w, tile_h, tl, alphas[c],
                 last_ids[c], v_render[c], v_alphas[c] if v_alphas is not None else None, absgrad, splats=splats,
-                expected_render=render_out[c] if ctx.expected_depth else None)
+                expected_render=render_out[c] if ctx.expected_depth else None,
+                render_out=render_out[c] if ckpt is not None else None, checkpoints=ckpt,
+                checkpoint_interval=ctx.segment if ckpt is not None else 0)
             # screen-space gradients for densification strategies (gsplat exposes them through
             # means2d.grad / means2d.absgrad; here they are published in the meta dict)
             ctx.meta_out.setdefault("means2d_grad", [None] * C)[c] = v_means2d
@@ -184,7 +191,7 @@ class _RenderSH(torch.autograd.Function):
                 v_render = torch.cat([v_render[..., :-1],
                                       (v_render[..., -1] / alphas.clamp(min=1e-10)).unsqueeze(-1)], dim=-1)
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 16
+        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 17
 
 
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
@@ -197,8 +204,14 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                   isect_capacity: Optional[int] = None,
                   tile_bounds: str = "tight",
                   raster_schedule: str = "latency",
-                  lean_meta: bool = False) -> Tuple[Tensor, Tensor, Dict]:
+                  lean_meta: bool = False,
+                  backward_segment: int = 256) -> Tuple[Tensor, Tensor, Dict]:
     """Render N Gaussians from C cameras.
+
+    backward_segment (SH path, when gradients are wanted): list entries per unit of work of the backward raster
+    (a power of two >= 64; 0 = one unit per tile, the whole-list walk).  The training forward stores per-pixel
+    checkpoints at that interval ((1 + channels) * 1 KB per tile and segment) and the backward walks the segments
+    independently: no tile is one wave's serial job any more.  Gradients equal the whole-list walk's up to rounding.
 
     lean_meta (SH path, isect_capacity given, no gradients): all C cameras go through ONE C call
     (mgs_render_frames) whose frames keep only what their own kernels read; meta then holds n_isects and
@@ -231,6 +244,8 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
         raise NotImplementedError(f"tile_size must be {TILE_SIZE}")
     if tile_bounds not in ("tight", "classic"):
         raise ValueError(f"tile_bounds {tile_bounds!r} not in ('tight', 'classic')")
+    if backward_segment and (backward_segment < 64 or backward_segment & (backward_segment - 1)):
+        raise ValueError(f"backward_segment {backward_segment} is not 0 or a power of two >= 64")
     if raster_schedule not in ("latency", "throughput"):
         raise ValueError(f"raster_schedule {raster_schedule!r} not in ('latency', 'throughput')")
     require_device(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
@@ -273,7 +288,7 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store,
             tile_bounds == "tight", render_mode in ("RGB+ED", "ED"), raster_schedule == "latency",
-            bool(lean_meta))
+            bool(lean_meta), int(backward_segment))
         if depth_only_via_sh:
             render = render[..., 3:4]
         if "lean" in store:             # inference frames through mgs_render_frames: counts and status only

@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "mgs.h")
 def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    decls = re.findall(r"\b(?:int|void|const char \*)\s*\*?\s*(mgs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+    decls = re.findall(r"\b(?:int|void|size_t|const char \*)\s*\*?\s*(mgs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
     return {name: 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
             for name, args in decls}
 
@@ -23,7 +23,7 @@ def _declared():
 def test_header_symbols_are_exported_and_bound():
     from robosimgs_amd import _lib
     decl = _declared()
-    assert len(decl) == 26, sorted(decl)
+    assert len(decl) == 27, sorted(decl)
     assert sorted(decl) == sorted(_lib.EXPORTS)
     L = _lib.lib()
     for name, nargs in decl.items():
@@ -55,7 +55,7 @@ def test_library_is_gfx950_only_and_links_no_torch():
 def test_argument_errors_are_reported_without_a_gpu():
     from robosimgs_amd import _lib
     L = _lib.lib()
-    rc = L.mgs_rasterize_fwd(1, None, None, None, None, None, None, 99, 16, 16, 1, 1, None, None, None, 0, None, None, None, None)
+    rc = L.mgs_rasterize_fwd(1, None, None, None, None, None, None, 99, 16, 16, 1, 1, None, None, None, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"channels" in L.mgs_last_error_string()
     rc = L.mgs_sh_fwd(4, 7, 16, None, None, None, None, None)
     assert rc == -1 and b"degree" in L.mgs_last_error_string()
