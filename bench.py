@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--bwd-steps", type=int, default=30)
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step region until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (5 M Gaussians at 3840x2160)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-reorder", action="store_true",
                     help="FrameRenderer keeps the scene in the order it is given (default: its own Morton-ordered copy)")
@@ -550,10 +551,22 @@ def main():
                     "algorithmic bytes price the classic lists (n_isect), the stage bins the tightened ones"}
 
         # ---- training-step variant (configs[2]): forward + L1 + backward ------------------
+        std = (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3)
         try:
             result["fwd_bwd"] = bench_fwd_bwd(a, t_given, vm, K, W, H, deg, cap, dev)      # a trainer's own order
+            result["fwd_bwd"]["scene_order"] = "as given"
+            result["fwd_bwd"]["roofline"] = bwd_roofline(t_given, vm, K, W, H, deg, cap, n_isect, std)
         except Exception as e:  # keep the headline line even if this leg fails
             result["fwd_bwd"] = {"error": repr(e)[:200]}
+
+        # ---- configs[4]: 5 M Gaussians at 3840x2160 (HBM-pressure / tile-overflow stress), per stage ----------
+        if not a.no_stress:
+            try:
+                del radii, m2d, depths, con, feats, splats, tl, tl_b, out, seed
+                torch.cuda.empty_cache()
+                result["stress_4k"] = stress_4k(dev, deg, n_fl)
+            except Exception as e:
+                result["stress_4k"] = {"error": repr(e)[:200]}
 
         # ---- CPU baseline: the oracle's C++/OpenMP port on this box's host cores -----------
         if world == 1 and not a.no_cpu_baseline:
@@ -589,12 +602,14 @@ def pmc_traffic(kernel_key, standard_workload):
 
 
 # Issue cost of the blend's instruction mix, SIMD-cycles per wave64 vector instruction (scripts/ubench/valu_issue.hip,
-# DESIGN.md 4.0): the round-3 body is 11 fma-class at 2.4, 4 compare / select-class at 4.1 and one v_exp at 8.15 =
-# 51 cycles per 16 (round 2: 65 per 21)
-VALU_ISSUE_FLOOR = 51.0 / 16.0
+# DESIGN.md 4.0): the shipped lane-mask body (raster_fwd.hip: blend_pixel_safe_asm) is 12 fma-class at 2.4, 2 compares
+# at 4.1 and one v_exp at 8.15 = 45 cycles per 15 instructions
+VALU_ISSUE_FLOOR = 45.0 / 15.0
+# the backward's quadrant body (raster_bwd.hip: grad_pixel, SAFE): 24 fma-class, 2 compares + 1 select, v_exp + v_rcp
+VALU_ISSUE_FLOOR_BWD = (24 * 2.4 + 3 * 4.1 + 2 * 8.15) / 29.0
 
 
-def pmc_valu(kernel_name, standard_workload):
+def pmc_valu(kernel_name, standard_workload, stage_prefix="raster_inf", floor=None):
     """What bounds the raster for real: vector instructions per launch and SIMD-cycles per instruction from the
     same PMC record (SQ_INSTS_VALU; GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 x 1024 SIMDs), against the issue
     cost of the blend's instruction mix.  Printed under the same build-stamp rule as `traffic`."""
@@ -606,13 +621,14 @@ def pmc_valu(kernel_name, standard_workload):
         from robosimgs_amd.csrc import build as hip_build
         if rec.get("stamp") != hip_build.current_stamp():
             return None
-        row = next(v for k, v in rec["raw"].items() if kernel_name in k and k.startswith("raster_inf"))
+        row = next(v for k, v in rec["raw"].items() if kernel_name in k and k.startswith(stage_prefix))
         insts, gui = float(row["SQ_INSTS_VALU"]), float(row["GRBM_GUI_ACTIVE"])
         cyc = gui / 8.0 * 1024.0 / insts
+        floor = VALU_ISSUE_FLOOR if floor is None else floor
         return {"bound": "valu-issue", "instructions_per_launch": int(insts),
                 "simd_cycles_per_instruction": round(cyc, 2),
-                "issue_floor_cycles_per_instruction": round(VALU_ISSUE_FLOOR, 2),
-                "frac_of_issue_bound": round(VALU_ISSUE_FLOOR / cyc, 3),
+                "issue_floor_cycles_per_instruction": round(floor, 2),
+                "frac_of_issue_bound": round(floor / cyc, 3),
                 "note": "the floor is the blend loop's mix; fetch, cull and queue instructions are mostly of the cheaper "
                         "class, so a kernel at the bound can read slightly above 1",
                 "source": "rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE in the run that took `traffic` "
@@ -670,6 +686,155 @@ def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
     return {"workload": f"configs[2]: forward ({MODE}) + L1 loss to U(0,1) target (seed 1) + backward",
             "ms_per_step": round(dt * 1e3, 4), "steps_per_s": round(1.0 / dt, 2),
             "steps": a.bwd_steps, "regions": len(times), "launch": mode}
+
+
+def bwd_roofline(t, vm, K, W, H, deg, cap, n_isect, standard_workload, segment=256, reps=30):
+    """Roofline of the training step's dominant kernel, raster_bwd_kernel<4, ...> in the form the step runs it (the
+    segmented walk from the forward's checkpoints, 4 channels, "ED" cotangent), timed with HIP events on the stream:
+    mgs_rasterize_bwd_det(MGS_RASTER_BWD_RECORDS_ONLY) = the flag memset (4.7 MB), the unit table (one thread per tile)
+    and the raster kernel -- no reduce.  Algorithmic bytes: SURVEY.md 8(d), n_isect * (44 + 36) + n_px * (24 + 20)."""
+    tile_w, tile_h = -(-W // 16), -(-H // 16)
+    radii, m2d, depths, con, _, feats, splats, seed = ops.project_color_fwd_raw(
+        t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0,
+        False, True, want_splats=True, bin_seed="tight")
+    tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False, want_pair_info=True,
+                             seed=seed)
+    ck = ops.checkpoint_buffer(cap, tile_w, tile_h, 4, segment, m2d.device)
+    render, alphas, last = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h, tl.tile_offsets,
+                                                 tl.flatten_ids, splats=splats, expected_last=True, latency=True,
+                                                 group_order=tl.group_order, channels=4, checkpoints=ck,
+                                                 checkpoint_interval=segment)
+    gen = torch.Generator(m2d.device).manual_seed(1)
+    v_r = torch.sign(render - torch.rand(H, W, 4, device=m2d.device, generator=gen)) / float(render.numel())   # the L1 cotangent
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = {}
+    for only in (True, False):
+        def run():
+            return ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h, tl, alphas, last,
+                                             v_r, None, splats=splats, expected_render=render, render_out=render,
+                                             checkpoints=ck, checkpoint_interval=segment, records_only=only)
+        for _ in range(3):
+            run()
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        times[only] = e0.elapsed_time(e1) / reps
+    n_px = W * H
+    algo = n_isect * (44 + 36) + n_px * (24 + 20)
+    ms = times[True]
+    traffic, note = pmc_traffic("raster_bwd", standard_workload)
+    return {"kernel": "raster_bwd_kernel<4, false, true, false, true> (records, segments of %d list entries)" % segment,
+            "bound": "hbm", "achieved": round(algo / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": note,
+            "algorithmic_bytes": algo, "kernel_ms": round(ms, 4),
+            "kernel_ms_covers": "flag memset + unit table + raster_bwd_kernel (mgs_rasterize_bwd_det with "
+                                "MGS_RASTER_BWD_RECORDS_ONLY); the rocprofv3 rows under profiles/ give the kernel alone",
+            "with_reduce_ms": round(times[False], 4),
+            "valu": pmc_valu("raster_bwd_kernel<4, false, true", standard_workload, "raster_bwd_split", VALU_ISSUE_FLOOR_BWD),
+            "note": "VALU-issue-bound like the forward (DESIGN.md 4.4): ~107 vector instructions per evaluated (tile, "
+                    "Gaussian) pair; the HBM fraction is reported as the contract asks"}
+
+
+def stress_4k(dev, deg, n_fl, frames=20):
+    """BASELINE configs[4]: 5 M Gaussians (mu = ln 0.008, seed 0), SH degree 3, 3840x2160, theta = 0.3, RGB+ED.  Per-stage
+    HIP-event times of the inference-frame form (median of `frames` eager frames), each against its SURVEY.md 8(d) bytes
+    (classic n_isect, as BASELINE.md section 3 prices them: 4.8 GB, 0.60 ms at 8 TB/s), and frames/s through FrameRenderer."""
+    from robosimgs_amd import FrameRenderer
+    n, mu, W, H = 5_000_000, 0.008, 3840, 2160
+    scene = synthetic_scene(n, math.log(mu), deg, seed=0)
+    t = scene.to_torch(dev, deg)
+    del scene
+    cam = camera_ring(1, W, H, thetas=[0.3])[0]
+    vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)
+    K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)
+    tw, th = -(-W // 16), -(-H // 16)
+    n_px, n_tiles = W * H, tw * th
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def frame(cap, bounds, rec=None, lean=True):
+        e0 = ev()
+        radii, m2d, dep, con, _, feats, splats, seed = ops.project_color_fwd_raw(
+            t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False,
+            True, want_splats=True, bin_seed=bounds, lean=lean)
+        e1 = ev()
+        tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, cap, want_tiles_per_gauss=False, seed=seed, want_tile_ids=False)
+        e2 = ev()
+        ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids,
+                              splats=splats, track_last=False, expected_last=True, latency=True, group_order=tl.group_order,
+                              channels=4)
+        e3 = ev()
+        if rec is not None:
+            rec.append((e0, e1, e2, e3))
+        return tl, radii
+
+    tl, radii = frame(48_000_000, "classic", lean=False)
+    torch.cuda.synchronize()
+    n_isect, n_vis = int(tl.n_isect), int((radii > 0).sum())
+    assert int(tl.status) == 0
+    tl, _ = frame(48_000_000, "tight")
+    n_binned = int(tl.n_isect)
+    lens = (tl.tile_offsets[1:] - tl.tile_offsets[:-1])
+    lmax, lmean = int(lens.max()), float(lens.float().mean())
+    del tl, radii
+    cap = int(n_binned * 1.15) + 4096
+    rec = []
+    for _ in range(3):
+        frame(cap, "tight")
+    for _ in range(frames):
+        frame(cap, "tight", rec)
+    torch.cuda.synchronize()
+    ts = np.array([[x[i].elapsed_time(x[i + 1]) for i in range(3)] for x in rec])
+    med = np.median(ts, 0)
+    bytes_ = {"project": n * (44 + 12 * (deg + 1) ** 2) + n_vis * 48,
+              "binning": n_vis * 20 + n_isect * 44 + n_tiles * 4,
+              "raster": n_isect * 44 + n_px * 24 + n_tiles * 8}
+    stages = {}
+    for i, k in enumerate(("project", "binning", "raster")):
+        stages[k] = {"ms": round(float(med[i]), 4), "algorithmic_bytes": bytes_[k],
+                     "frac": round(bytes_[k] / (med[i] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    total_ms = float(np.median(ts.sum(1)))
+    total_bytes = sum(bytes_.values())
+    # throughput: the same frames through FrameRenderer (one HIP graph per slot, Morton-ordered resident copy)
+    fr = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap)
+    cam_dev = FrameRenderer.pack_camera(vm, K)
+    tickets = []
+
+    def push():
+        if len(tickets) == n_fl:
+            tk = tickets.pop(0)
+            fr.fetch(tk, check=False)
+            fr.release(tk)
+        tickets.append(fr.submit(cam_dev))
+    for _ in range(6):
+        push()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3 * frames):
+        push()
+    while tickets:
+        tk = tickets.pop(0)
+        fr.fetch(tk, check=False)
+        fr.release(tk)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (3 * frames)
+    status = max(int(s_["meta"]["isect_status"].max().item()) for s_ in fr._slots)
+    return {"workload": f"configs[4]: {n} Gaussians, SH degree {deg}, {W}x{H} forward render ({MODE}), theta = 0.3",
+            "n_visible": n_vis, "n_isect": n_isect, "n_isect_binned": n_binned, "tiles": n_tiles,
+            "list_length_mean": round(lmean, 1), "list_length_max": lmax, "stages": stages,
+            "frame_ms_eager_stages": round(total_ms, 4),
+            "frame_algorithmic_bytes": total_bytes,
+            "frame_frac_of_hbm_roofline": round(total_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "floor_ms_at_8TBs": round(total_bytes / 8e12 * 1e3, 4),
+            "frames_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 4), "frames_in_flight": n_fl,
+            "frames_timed": 3 * frames, "isect_overflow": bool(status),
+            "timing": f"stages: median of {frames} eager frames, HIP events between the three C-ABI calls; frames/s: "
+                      f"{3 * frames} graph replays through FrameRenderer after 6 warm-up frames"}
 
 
 def cpu_baseline(scene, cam, W, H, deg, budget_s):

@@ -56,6 +56,16 @@ extern "C" {
                                       instructions -- for single frames and training steps, not for
                                       several frames in flight; same pixels bit for bit */
 
+/* mgs_render_frames flags: the two above, and */
+#define MGS_FRAMES_CLASSIC_BOUNDS 4 /* bin into gsplat's classic mean +- radius tile rectangles instead of the tightened
+                                       ones: same pixels bit for bit, but n_isect / the overflow status then count the
+                                       classic lists (a caller that sized its capacity with them) */
+
+/* mgs_rasterize_bwd_det flags */
+#define MGS_RASTER_BWD_RECORDS_ONLY 1 /* stop after the raster kernel: the workspace then holds one record and one flag
+                                         per (tile, Gaussian) slot and the v_* outputs are not touched (measurement
+                                         of the raster kernel alone; a consumer that sums the records itself) */
+
 #define MGS_TILE_SIZE 16
 #define MGS_MAX_CHANNELS 32
 
@@ -64,16 +74,19 @@ typedef void *mgs_stream_t; /* hipStream_t */
 int mgs_version(void);
 /* Thread-local, human-readable description of the last non-zero return value. */
 const char *mgs_last_error_string(void);
-/* Test hook (process-global, not for production): 0 disables the raster forward's exact
- * per-quadrant cull so that tests can prove the cull never changes a pixel. */
+#ifdef MGS_DEBUG_HOOKS
+/* Test and measurement hooks: compiled into libmgs_debug.so ONLY (-DMGS_DEBUG_HOOKS; tests/ and scripts/ load that
+ * build).  They are process-global state, which the shipped libmgs.so does not have.
+ * mgs_debug_set_raster_cull: 0 disables the raster forward's exact per-quadrant cull (tests prove it never changes a
+ *   pixel).  mgs_debug_set_raster_opts: scheduling of the raster forward; bit 0 = issue priority by tile-list length,
+ *   bit 1 = honour MGS_RASTER_LATENCY, bit 2 = force the per-block kernel, bits 8.. = KiB of padding LDS (default 3);
+ *   never changes a pixel.  mgs_debug_set_sort_opts: bit 0 = one-sweep (decoupled look-back) radix passes, bit 2 =
+ *   radix partition by tile where the direct path applies, bit 3 = counters per 2^(bits 4..6) tiles (default 0);
+ *   same lists bit for bit. */
 void mgs_debug_set_raster_cull(int enabled);
-/* Measurement hook (process-global): scheduling options of the raster forward; bit 0 = issue
- * priority by tile-list length, bit 1 = honour MGS_RASTER_LATENCY, bit 2 = force the per-block
- * kernel, bits 8.. = KiB of padding LDS (default 3).  Never changes a pixel. */
 void mgs_debug_set_raster_opts(int opts);
-/* Measurement hook (process-global): bit 0 = one-sweep (decoupled look-back) radix passes for the tile
- * sort instead of histogram + row scan + scatter (default 0).  Same lists bit for bit. */
 void mgs_debug_set_sort_opts(int opts);
+#endif
 
 /* -------------------------------------------------------------------------------------
  * Projection  (gsplat `fully_fused_projection` forward, packed=False, one camera)
@@ -199,8 +212,8 @@ int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const flo
 /* -------------------------------------------------------------------------------------
  * A batch of inference frames in ONE call (gsplat `rasterization(...)` for C cameras, no gradients):
  * per camera mgs_project_color_fwd -> mgs_isect_tiles -> mgs_rasterize_fwd in their inference-frame form
- * (packed records + binning seed, tightened tile rectangles, no per-Gaussian outputs), enqueued back to back
- * on `stream`.  viewmats[C,4,4], Ks[C,3,3]; channels 3 (RGB) or 4 (RGB + camera-space depth as the last
+ * (packed records + binning seed, tightened tile rectangles unless MGS_FRAMES_CLASSIC_BOUNDS, no per-Gaussian
+ * outputs), enqueued back to back on `stream`.  viewmats[C,4,4], Ks[C,3,3]; channels 3 (RGB) or 4 (RGB + camera-space depth as the last
  * channel); flags as mgs_rasterize_fwd (MGS_RASTER_EXPECTED_LAST turns that channel into "ED");
  * backgrounds[C,channels] nullable; antialiased != 0 = rasterize_mode "antialiased".
  * out: render[C,H,W,channels], alphas[C,H,W], n_isect[C], status[C] (as mgs_isect_tiles, per camera).
@@ -284,7 +297,10 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
  *   for these lists, and its render[H,W,channels] (== expected_render in "ED" mode).  The launch then has one unit of
  *   work per SEGMENT of checkpoint_interval list entries: a segment behind which the list goes on starts from the
  *   forward's checkpoint (its T; colour behind = final - checkpoint).  Same records and slots; against the whole-list
- *   walk the gradients differ by rounding only (<= ~1e-6 relative), and stay bit-reproducible run to run.
+ *   walk the gradients differ by rounding only -- measured against fp64 the segmented walk is the closer one, it
+ *   restarts from the forward's exact T -- and stay bit-reproducible run to run.
+ *   flags: MGS_RASTER_BWD_RECORDS_ONLY.  4-channel frames (v_render, expected_render, render_out) must be 16-byte
+ *   aligned (rows are read as one 16-byte piece).
  */
 int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, const float *feats,
                           const float *opacities, const float *splats, const float *background,
@@ -294,7 +310,7 @@ int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, cons
                           const float *v_alphas, const float *expected_render,
                           const int32_t *pair_info, const int32_t *tile_group_order,
                           uint32_t isect_capacity, const float *render_out, const float *checkpoints,
-                          int checkpoint_interval, float *v_means2d, float *v_means2d_abs,
+                          int checkpoint_interval, int flags, float *v_means2d, float *v_means2d_abs,
                           float *v_conics, float *v_feats, float *v_opacities, void *workspace,
                           size_t *workspace_bytes, mgs_stream_t stream);
 

@@ -14,6 +14,9 @@ import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgs.so")
+# the same sources built with -DMGS_DEBUG_HOOKS: the only build that has the process-global mgs_debug_set_* knobs
+DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libmgs_debug.so")
+DEBUG_HOOKS = ["mgs_debug_set_raster_cull", "mgs_debug_set_raster_opts", "mgs_debug_set_sort_opts"]
 
 MGS_STATUS_ISECT_OVERFLOW = 1
 MGS_VERSION = 400          # include/mgs.h this binding was written against (parameter lists change with it)
@@ -23,7 +26,8 @@ class MgsError(RuntimeError):
     pass
 
 
-def _load() -> ctypes.CDLL:
+def _load(path: str = None, hooks: bool = False) -> ctypes.CDLL:
+    LIB_PATH = path or globals()["LIB_PATH"]
     if not os.path.exists(LIB_PATH):
         raise MgsError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
@@ -39,9 +43,6 @@ def _load() -> ctypes.CDLL:
     sig = {
         "mgs_version": ([], c_int),
         "mgs_last_error_string": ([], c_char_p),
-        "mgs_debug_set_raster_cull": ([i], None),
-        "mgs_debug_set_raster_opts": ([i], None),
-        "mgs_debug_set_sort_opts": ([i], None),
         "mgs_projection_fwd": ([i, p, p, p, p, p, i, i, f, f, f, f, p, p, p, p, p, p], c_int),
         "mgs_projection_bwd": ([i, p, p, p, p, p, i, i, f, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
         "mgs_sh_fwd": ([i, i, i, p, p, p, p, p], c_int),
@@ -63,30 +64,60 @@ def _load() -> ctypes.CDLL:
         "mgs_transform_gaussians": ([i, p, p, p, i, i, p, p, i, p, p, p, p, p, p, p], c_int),
         "mgs_l1_loss_fwd": ([c_size_t, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_l1_loss_bwd": ([c_size_t, p, p, p, p, p], c_int),
-        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, u32, p, p, i, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, u32, p, p, i, i, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch
         fn.argtypes = argtypes
         fn.restype = restype
-    if os.environ.get("MGS_SORT_OPTS"):            # measurement knob: one-sweep radix passes (same lists)
-        lib.mgs_debug_set_sort_opts(int(os.environ["MGS_SORT_OPTS"], 0))
-    if os.environ.get("MGS_RASTER_OPTS"):          # measurement knob (scripts/, profiles/): never changes a pixel
-        lib.mgs_debug_set_raster_opts(int(os.environ["MGS_RASTER_OPTS"], 0))
+    if hooks:
+        for name in DEBUG_HOOKS:
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = [c_int], None
+        if os.environ.get("MGS_SORT_OPTS"):            # measurement knob: one-sweep radix passes (same lists)
+            lib.mgs_debug_set_sort_opts(int(os.environ["MGS_SORT_OPTS"], 0))
+        if os.environ.get("MGS_RASTER_OPTS"):          # measurement knob (scripts/, profiles/): never changes a pixel
+            lib.mgs_debug_set_raster_opts(int(os.environ["MGS_RASTER_OPTS"], 0))
     return lib
 
 
 _lib = None
+_debug = None
 
 
 def lib() -> ctypes.CDLL:
+    """The library every op calls: libmgs.so, which has no process-global state.  MGS_USE_DEBUG_LIB=1 in the
+    environment (measurement scripts that set MGS_SORT_OPTS / MGS_RASTER_OPTS) makes it libmgs_debug.so instead."""
     global _lib
     if _lib is None:
-        _lib = _load()
+        _lib = debug_lib() if os.environ.get("MGS_USE_DEBUG_LIB") else _load()
     return _lib
 
 
-EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_debug_set_raster_cull", "mgs_debug_set_raster_opts", "mgs_debug_set_sort_opts", "mgs_projection_fwd", "mgs_projection_bwd",
+def debug_lib() -> ctypes.CDLL:
+    """libmgs_debug.so: the same sources with -DMGS_DEBUG_HOOKS, the only build that has mgs_debug_set_*."""
+    global _debug
+    if _debug is None:
+        _debug = _load(DEBUG_LIB_PATH, hooks=True)
+    return _debug
+
+
+class use_debug_lib:
+    """with use_debug_lib() as L: every op inside goes through libmgs_debug.so (tests of the hooks, A/B scripts)."""
+
+    def __enter__(self):
+        global _lib
+        self._saved = _lib
+        _lib = debug_lib()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_projection_fwd", "mgs_projection_bwd",
            "mgs_sh_fwd", "mgs_sh_bwd", "mgs_project_color_fwd", "mgs_project_color_bwd",
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
            "mgs_rasterize_bwd_det", "mgs_composite_over", "mgs_points_project",

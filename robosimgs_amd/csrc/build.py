@@ -15,6 +15,10 @@ SOURCES = ["api.hip", "projection.hip", "sort.hip", "binning.hip", "tile_sort.hi
 HEADERS = ["mgs_common.h", "mgs_math.h", "raster_common.h", "sh_staging.h", "tile_rect.h", "tile_order.h",
            "../../include/mgs.h"]
 LIB = os.path.join(HERE, "libmgs.so")
+# The same sources with -DMGS_DEBUG_HOOKS: the process-global test / measurement knobs (mgs_debug_set_*) exist in this
+# build only; tests and A/B scripts load it (robosimgs_amd._lib.use_debug_lib), the product never does.
+DEBUG_LIB = os.path.join(HERE, "libmgs_debug.so")
+HOOK_SOURCES = ["raster_fwd.hip", "sort.hip"]          # the translation units MGS_DEBUG_HOOKS changes
 OBJ_DIR = os.path.join(HERE, "build")
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent f32 adds/multiplies into v_pk_*_f32, which on
 # gfx950 buys no throughput and costs v_mov shuffles: raster fwd 299 -> 260 us, bwd 920 -> 725 us.
@@ -89,16 +93,18 @@ def current_stamp() -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     stamp_file = os.path.join(OBJ_DIR, "stamp")
     stamp = _stamp()
-    if (not force and os.path.exists(LIB) and os.path.exists(stamp_file)
+    if (not force and os.path.exists(LIB) and os.path.exists(DEBUG_LIB) and os.path.exists(stamp_file)
             and open(stamp_file).read() == stamp):
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
 
-    def compile_one(src: str) -> str:
-        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *PER_SOURCE_FLAGS.get(src, []), "-c", os.path.join(HERE, src), "-o", obj]
+    def compile_one(job) -> str:
+        src, hooks = job
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".dbg.o" if hooks else ".o"))
+        cmd = [hipcc, *FLAGS, *PER_SOURCE_FLAGS.get(src, []), *(["-DMGS_DEBUG_HOOKS"] if hooks else []), "-c",
+               os.path.join(HERE, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -108,12 +114,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
+    jobs = [(s_, False) for s_ in srcs] + [(s_, True) for s_ in srcs if s_ in HOOK_SOURCES]
     with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(compile_one, srcs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stderr}")
+        objs = dict(zip(jobs, ex.map(compile_one, jobs)))
+    for lib, hooks in ((LIB, False), (DEBUG_LIB, True)):
+        use = [objs[(s_, hooks and s_ in HOOK_SOURCES)] for s_ in srcs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *use, "-o", lib]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return LIB

@@ -73,7 +73,8 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
     rc = mgs_project_color_fwd(n, means, quats, scales, opacities, sh_degree, coeff_stride, sh_coeffs,
                                viewmats + 16 * (size_t)c, Ks + 9 * (size_t)c, width, height, eps2d, near_plane, far_plane,
                                radius_clip, nullptr, nullptr, depths, nullptr, opac_aa, channels, nullptr, splats,
-                               1 /* tight tile bounds: same pixels, shorter lists */, bin_info, bin_sums, stream);
+                               (flags & MGS_FRAMES_CLASSIC_BOUNDS) ? 0 : 1 /* tight tile bounds: same pixels, shorter lists */,
+                               bin_info, bin_sums, stream);
     if (rc) return rc;
     size_t iw = ws.isect_bytes;
     rc = mgs_isect_tiles(n, nullptr, nullptr, depths, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
@@ -81,7 +82,8 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
                          status + c, bin_info, bin_sums, w + ws.isect, &iw, stream);
     if (rc) return rc;
     rc = mgs_rasterize_fwd(n, nullptr, nullptr, nullptr, nullptr, splats, backgrounds ? backgrounds + (size_t)channels * c : nullptr,
-                           channels, width, height, tile_w, tile_h, offsets, flatten, order, flags,
+                           channels, width, height, tile_w, tile_h, offsets, flatten, order,
+                           flags & (MGS_RASTER_EXPECTED_LAST | MGS_RASTER_LATENCY),
                            render + n_px * channels * c, alphas + n_px * c, nullptr, nullptr, 0, stream);
     if (rc) return rc;
   }

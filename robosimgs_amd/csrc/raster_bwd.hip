@@ -918,7 +918,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                                      const float* expected_render,
                                      const int32_t* pair_info, const int32_t* tile_group_order,
                                      uint32_t isect_capacity, const float* render_out,
-                                     const float* checkpoints, int checkpoint_interval,
+                                     const float* checkpoints, int checkpoint_interval, int call_flags,
                                      float* v_means2d, float* v_means2d_abs, float* v_conics,
                                      float* v_feats, float* v_opacities, void* workspace,
                                      size_t* workspace_bytes, mgs_stream_t stream) {
@@ -962,9 +962,10 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   MGS_REQUIRE(channels != 4 || (((reinterpret_cast<uintptr_t>(v_render) | reinterpret_cast<uintptr_t>(expected_render) |
                                   reinterpret_cast<uintptr_t>(render_out)) & 15u) == 0),
               "rasterize_bwd_det: 4-channel frames (v_render, expected_render, render_out) must be 16-byte aligned");
+  const bool records_only = (call_flags & MGS_RASTER_BWD_RECORDS_ONLY) != 0;
   MGS_REQUIRE((splats || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
-                  alphas && last_ids && v_render && pair_info && v_means2d && v_conics &&
-                  v_feats && v_opacities, "rasterize_bwd_det: null pointer");
+                  alphas && last_ids && v_render && pair_info &&
+                  (records_only || (v_means2d && v_conics && v_feats && v_opacities)), "rasterize_bwd_det: null pointer");
   const int n_tiles = tile_w * tile_h;
   hipStream_t s = (hipStream_t)stream;
   float* records = static_cast<float*>(workspace);
@@ -998,6 +999,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                      (const int32_t*)order, checkpoints, ckpt_shift, (const int32_t*)seg_table, render_out)
 #define MGS_RD_LAUNCH(C, A)                                                                     \
   if (split) MGS_RD_RASTER(C, A, ((C) <= 4 && !kHalf)); else MGS_RD_RASTER(C, A, false);        \
+  if (!records_only)                                                                            \
   hipLaunchKernelGGL((reduce_records_kernel<C, A, (int)kSlots>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
                      info, records, flags, (uint32_t)cap, means2d, conics, opacities,          \
                      reinterpret_cast<const float4*>(splats),                                  \

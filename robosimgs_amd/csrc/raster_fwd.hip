@@ -736,16 +736,27 @@ using namespace mgs;
 
 // Test hook: 0 disables the exact quadrant cull (every listed Gaussian is evaluated against every
 // live quadrant).  The image must not change; tests/test_gpu_forward.py checks that bit for bit.
+// Both knobs exist in libmgs_debug.so only (-DMGS_DEBUG_HOOKS; tests and A/B scripts load that build): the shipped
+// libmgs.so has no process-global state -- two renderers in one process cannot race on a knob (include/mgs.h:
+// "stateless and re-entrant").
+#ifdef MGS_DEBUG_HOOKS
 static int g_raster_cull = 1;
 extern "C" void mgs_debug_set_raster_cull(int enabled) { g_raster_cull = enabled; }
+#else
+static constexpr int g_raster_cull = 1;
+#endif
 // Scheduling knobs for A/B measurements (scripts/raster_ab.py); they never change a pixel.
 //   bit 0: issue priority by tile-list length in the one-wave-per-tile kernel (default on)
 //   bit 1: honour MGS_RASTER_LATENCY (one wave per 8x8 block, raster_fwd_q_kernel, <= 4 channels); default on
 //   bit 2: use that kernel whatever the flags say
 //   bit 3: ignore tile_group_order (index-order launch); bit 4: ignore it in the one-wave-per-tile inference kernel only
 //   bits 8..: KiB of unused dynamic LDS per workgroup of that kernel (caps its occupancy: experiments)
+#ifdef MGS_DEBUG_HOOKS
 static int g_raster_opts = 3;
 extern "C" void mgs_debug_set_raster_opts(int opts) { g_raster_opts = opts; }
+#else
+static constexpr int g_raster_opts = 3;
+#endif
 
 #ifdef MGS_RASTER_STATS
 // instrumented build only: copy the counters out (synchronous) and zero them

@@ -409,8 +409,12 @@ __global__ __launch_bounds__(kThreads) void onesweep_scatter_kernel(
 // passes: key bits split as evenly as possible into digits of at most 8 bits
 int radix_sort_passes(int key_bits) { return (key_bits + 7) / 8; }
 
+#ifdef MGS_DEBUG_HOOKS       // libmgs_debug.so only: the shipped library keeps no process-global state
 static int g_sort_opts = 0;
 extern "C" void mgs_debug_set_sort_opts(int opts) { g_sort_opts = opts; }
+#else
+static constexpr int g_sort_opts = 0;
+#endif
 int sort_opts() { return g_sort_opts; }
 
 size_t radix_sort_temp_bytes(uint32_t capacity) {

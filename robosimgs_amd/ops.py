@@ -154,10 +154,11 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height,
                       eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth, capacity,
-                      backgrounds=None, expected_last=False, latency=False, out=None):
+                      backgrounds=None, expected_last=False, latency=False, out=None, tight=True):
     """mgs_render_frames: C inference frames in one C call (no per-Gaussian outputs, scratch reused from camera to
     camera).  viewmats [C,4,4], Ks [C,3,3], backgrounds [C,ch] or None.  Returns (render [C,H,W,ch], alphas [C,H,W],
-    n_isects [C] i32, isect_status [C] i32); out = (render, alphas) to write into existing buffers."""
+    n_isects [C] i32, isect_status [C] i32); out = (render, alphas) to write into existing buffers.
+    tight=False: gsplat's classic tile rectangles (MGS_FRAMES_CLASSIC_BOUNDS; same pixels, classic counts)."""
     dev = means.device
     C, n = viewmats.shape[0], means.shape[0]
     ch = 4 if with_depth else 3
@@ -172,7 +173,8 @@ def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, vie
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), int(sh_degree), sh_coeffs.shape[1], ptr(sh_coeffs),
             C, ptr(viewmats), ptr(Ks), int(width), int(height), eps2d, near_plane, far_plane, radius_clip,
-            int(bool(antialiased)), ch, int(bool(expected_last)) | (2 if latency else 0), ptr(backgrounds),
+            int(bool(antialiased)), ch, int(bool(expected_last)) | (2 if latency else 0) | (0 if tight else 4),
+            ptr(backgrounds),
             int(capacity), ptr(render), ptr(alphas), ptr(n_isect), ptr(status)]
     check(L.mgs_render_frames(*args, None, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames(size query)")
     ws = _workspace(nbytes.value + 256, dev)
@@ -252,11 +254,12 @@ def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, heig
 def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                           tile_h, tl: "TileLists", alphas, last_ids, v_render, v_alphas,
                           absgrad=False, splats=None, canary_bytes=0, expected_render=None,
-                          render_out=None, checkpoints=None, checkpoint_interval=0):
+                          render_out=None, checkpoints=None, checkpoint_interval=0, records_only=False):
     """Atomic-free, bit-reproducible raster backward (needs tl.pair_info from the binning).
     Returns freshly written (v_means2d, v_conics, v_feats, v_opacities, v_means2d_abs|None).
     expected_render: the forward's frame when it ran with expected_last (the kernel undoes the divide).
     checkpoints + checkpoint_interval + render_out (the forward's frame): the segmented walk (include/mgs.h).
+    records_only: stop after the raster kernel (MGS_RASTER_BWD_RECORDS_ONLY; the returned tensors are not written).
     canary_bytes (tests): that many 0xA5 bytes are kept behind the workspace the library asked for
     and returned as a sixth value, so a test can see that nothing was written past the workspace."""
     n = means2d.shape[0]
@@ -273,7 +276,7 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
             ch, width, height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
             ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(expected_render), ptr(tl.pair_info),
             ptr(getattr(tl, "group_order", None)), tl.capacity,
-            ptr(render_out), ptr(checkpoints), int(checkpoint_interval),
+            ptr(render_out), ptr(checkpoints), int(checkpoint_interval), int(bool(records_only)),
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det(size query)")

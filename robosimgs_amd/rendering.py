@@ -78,7 +78,7 @@ class _RenderSH(torch.autograd.Function):
             _, _, n_isects, status = ops.render_frames_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d,
                 near_plane, far_plane, radius_clip, antialiased, with_depth, isect_capacity, backgrounds=backgrounds,
-                expected_last=expected_depth, latency=latency, out=(render, alphas))
+                expected_last=expected_depth, latency=latency, out=(render, alphas), tight=tight)
             meta_out["lean"] = dict(n_isects=n_isects, isect_status=status)
             ctx.set_materialize_grads(False)
             return render, alphas.unsqueeze(-1)

@@ -3,16 +3,16 @@
 # prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (kernel trace only), FETCH_SIZE doubled
 # (gfx950 tallies 128-byte requests at 64 B), both in KiB.  Writes profiles/pmc_traffic.json keyed to the
 # build stamp of libmgs.so; bench.py prints `roofline.traffic` only when the stamp matches.
-#   gpurun -- bash scripts/pmc_traffic.sh        (results also under gpurun_out/pmc_r3/)
+#   gpurun -- bash scripts/pmc_traffic.sh        (results also under gpurun_out/pmc_r4/)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/pmc_r3
+OUT=$REPO/gpurun_out/pmc_r4
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for stage in raster_inf raster_inf_q raster_bwd_det project binning; do
+for stage in raster_inf raster_inf_q raster_bwd_split project binning; do
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
     tag=$(echo $ctr | cut -d' ' -f1)
     rm -rf $OUT/${stage}_$tag
-    timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${stage}_$tag -o pmc -- python $REPO/scripts/run_stage.py $stage 3 > /dev/null 2>&1
+    SEG=256 timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${stage}_$tag -o pmc -- python $REPO/scripts/run_stage.py $stage 3 > /dev/null 2>&1
   done
 done
 python - <<PY
@@ -27,8 +27,8 @@ def agg(d):
             a[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return a
 rec = {"stamp": hip_build.current_stamp(), "workload": "configs[1]: 1M Gaussians, SH 3, 1920x1080, tight lists, 4 channels (RGB+ED)", "kernels": {}, "raw": {}}
-pick = {"raster_inf": ("raster_fwd", "raster_fwd_kernel<4, false>"), "raster_inf_q": ("raster_fwd_q", "raster_fwd_q_kernel<4, false>"), "raster_bwd_det": ("raster_bwd", "raster_bwd_kernel"), "project": ("project", "project_color_fwd_kernel")}
-for stage in ("raster_inf", "raster_inf_q", "raster_bwd_det", "project", "binning"):
+pick = {"raster_inf": ("raster_fwd", "raster_fwd_kernel<4, false>"), "raster_inf_q": ("raster_fwd_q", "raster_fwd_q_kernel<4, false>"), "raster_bwd_split": ("raster_bwd", "raster_bwd_kernel"), "project": ("project", "project_color_fwd_kernel")}
+for stage in ("raster_inf", "raster_inf_q", "raster_bwd_split", "project", "binning"):
     F, Wr, S = agg(stage + "_FETCH_SIZE"), agg(stage + "_WRITE_SIZE"), agg(stage + "_SQ_INSTS_VALU")
     for k in set(F) | set(Wr) | set(S):
         if "mgs" not in k: continue
@@ -44,6 +44,6 @@ for stage in ("raster_inf", "raster_inf_q", "raster_bwd_det", "project", "binnin
 json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(rec["kernels"], indent=1))
 for k, v in rec["raw"].items():
-    if k.startswith("raster_inf") and "kernel<4, false>" in k or k.startswith("raster_bwd_det:") and "raster_bwd" in k:
+    if k.startswith("raster_inf") and "kernel<4, false>" in k or k.startswith("raster_bwd_split:") and "raster_bwd" in k:
         print(k[:60], {a: (round(b) if b else b) for a, b in v.items()})
 PY

@@ -20,6 +20,7 @@ tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 el
 lens = (tl.tile_offsets[1:] - tl.tile_offsets[:-1]).float()
 print("n_isect", int(tl.n_isect), "tile list length: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (lens.mean(), lens.median(), lens.quantile(0.9), lens.quantile(0.99), lens.max()))
 ref = None
+os.environ["MGS_USE_DEBUG_LIB"] = "1"      # the scheduling knobs exist in libmgs_debug.so only
 L = _lib.lib()
 for track in (False, True):
     for o in opts_list:

@@ -45,13 +45,13 @@ for _ in range(reps):
     elif stage == "raster_bwd_det":
         ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl, out[1], out[2], vr, va, splats=splats)
     elif stage == "raster_bwd_split":    # segmented walk (forward checkpoints), SEG entries per unit
-        SEG = int(os.environ.get("SEG", 128))
+        SEG = int(os.environ.get("SEG", 256))
         if "ck" not in globals():
             ck = ops.checkpoint_buffer(CAP, tw, th, CH, SEG, dev)
             out_s = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats,
-                                          latency=True, group_order=tl.group_order, channels=CH, checkpoints=ck, checkpoint_interval=SEG)
+                                          latency=True, expected_last=CH == 4, group_order=tl.group_order, channels=CH, checkpoints=ck, checkpoint_interval=SEG)
         ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl, out_s[1], out_s[2], vr, va, splats=splats,
-                                  render_out=out_s[0], checkpoints=ck, checkpoint_interval=SEG)
+                                  expected_render=out_s[0] if CH == 4 else None, render_out=out_s[0], checkpoints=ck, checkpoint_interval=SEG)
     elif stage == "train":
         from robosimgs_amd.rendering import rasterization
         ps = {k: t[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}

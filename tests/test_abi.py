@@ -12,9 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "mgs.h")
 
 
-def _declared():
+def _declared(hooks=False):
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    dbg = re.search(r"#ifdef MGS_DEBUG_HOOKS(.*?)#endif", src, flags=re.S)
+    src = dbg.group(1) if hooks else src.replace(dbg.group(0), "")
     decls = re.findall(r"\b(?:int|void|size_t|const char \*)\s*\*?\s*(mgs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S)
     return {name: 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
             for name, args in decls}
@@ -23,7 +25,7 @@ def _declared():
 def test_header_symbols_are_exported_and_bound():
     from robosimgs_amd import _lib
     decl = _declared()
-    assert len(decl) == 27, sorted(decl)
+    assert len(decl) == 24, sorted(decl)
     assert sorted(decl) == sorted(_lib.EXPORTS)
     L = _lib.lib()
     for name, nargs in decl.items():
@@ -33,6 +35,22 @@ def test_header_symbols_are_exported_and_bound():
     declared = int(re.search(r"#define\s+MGS_VERSION\s+(\d+)", header).group(1))
     assert L.mgs_version() == declared == _lib.MGS_VERSION      # header, library and binding agree
     assert isinstance(L.mgs_last_error_string(), bytes)
+
+
+def test_shipped_library_has_no_debug_hooks_and_the_debug_build_has_them():
+    """include/mgs.h: "stateless and re-entrant".  The process-global knobs (mgs_debug_set_*) are declared under
+    MGS_DEBUG_HOOKS and compiled into libmgs_debug.so only."""
+    from robosimgs_amd import _lib
+    hooks = _declared(hooks=True)
+    assert sorted(hooks) == sorted(_lib.DEBUG_HOOKS) and len(hooks) == 3
+    nm = lambda path: subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    shipped, debug = nm(_lib.LIB_PATH), nm(_lib.DEBUG_LIB_PATH)
+    assert "mgs_debug" not in shipped
+    for name in hooks:
+        assert name in debug
+    for name in _declared():
+        assert name in shipped and name in debug
+    assert _lib.debug_lib().mgs_version() == _lib.lib().mgs_version()
 
 
 def test_library_is_gfx950_only_and_links_no_torch():

@@ -375,15 +375,21 @@ def test_quadrant_cull_never_changes_a_pixel(ops, aniso):
     g.opacity_logits[::7] = rng.uniform(-6.5, -5.0, size=len(g.opacity_logits[::7]))   # around 1/255
     t, radii, means2d, depths, conics, feats, tl, tw, th = _raster_inputs(ops, g, cam, 208, 144, 1)
     for latency in (False, True):          # both raster kernels carry the cull
-        try:
-            _lib.lib().mgs_debug_set_raster_cull(1)
-            a = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
-                                      tl.tile_offsets, tl.flatten_ids, latency=latency)
-            _lib.lib().mgs_debug_set_raster_cull(0)
-            b = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
-                                      tl.tile_offsets, tl.flatten_ids, latency=latency)
-        finally:
-            _lib.lib().mgs_debug_set_raster_cull(1)
+        # (the knob is process-global state: it exists in libmgs_debug.so only, the shipped library has none)
+        with _lib.use_debug_lib() as dbg:
+            try:
+                dbg.mgs_debug_set_raster_cull(1)
+                a = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
+                                          tl.tile_offsets, tl.flatten_ids, latency=latency)
+                dbg.mgs_debug_set_raster_cull(0)
+                b = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
+                                          tl.tile_offsets, tl.flatten_ids, latency=latency)
+            finally:
+                dbg.mgs_debug_set_raster_cull(1)
+        # the shipped library renders the same bits as the debug build with the cull on
+        c = ops.rasterize_fwd_raw(means2d, conics, feats, t["opacities"], None, 208, 144, tw, th,
+                                  tl.tile_offsets, tl.flatten_ids, latency=latency)
+        assert all(torch.equal(x, y) for x, y in zip(a, c))
         assert float(a[1].max()) > 0.5
         for x, y, name in zip(a, b, ("render", "alphas", "last_ids")):
             assert torch.equal(x, y), f"{name}: cull changed {int((x != y).sum())} values (latency={latency})"
@@ -475,7 +481,8 @@ def test_partition_variants_give_identical_lists(ops, seed):
     args = (_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), tw, th)
     r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, tw, th, dtype=np.float32)
     total = len(r_flat)
-    lib = _lib.lib()
+    _dbg = _lib.use_debug_lib()
+    lib = _dbg.__enter__()          # the partition knob lives in libmgs_debug.so only
     try:
         for opts in (4, 0x08, 0x18, 0x28, 0x38, 0x48, 0):
             lib.mgs_debug_set_sort_opts(opts)
@@ -499,6 +506,11 @@ def test_partition_variants_give_identical_lists(ops, seed):
             assert off.min() >= 0 and off.max() <= cap and np.all(np.diff(off) >= 0), hex(opts)
     finally:
         lib.mgs_debug_set_sort_opts(0)
+        _dbg.__exit__(None, None, None)
+    # ... and the shipped library (no knob) gives the same lists
+    tl = ops.isect_tiles_raw(*args, total + 5, want_pair_info=True, want_isect_ids=True, want_tiles_per_gauss=True)
+    np.testing.assert_array_equal(tl.flatten_ids[:total].cpu().numpy(), r_flat)
+    np.testing.assert_array_equal(tl.pair_info.cpu().numpy(), slots)
 
 
 @pytest.mark.parametrize("w,h", [(200, 120), (96, 80), (1000, 40)])
@@ -509,7 +521,8 @@ def test_tile_group_order_is_a_schedule_not_a_result(ops, w, h):
     of four)."""
     from robosimgs_amd import _lib
     g, cam = _scene(6000, 0.1, 1, w, h)
-    lib = _lib.lib()
+    _dbg = _lib.use_debug_lib()
+    lib = _dbg.__enter__()
     try:
         frames = []
         for opts in (0, 4):
@@ -534,6 +547,7 @@ def test_tile_group_order_is_a_schedule_not_a_result(ops, w, h):
                 assert torch.equal(f[2], frames[1][2])
     finally:
         lib.mgs_debug_set_sort_opts(0)
+        _dbg.__exit__(None, None, None)
 
 
 @pytest.mark.parametrize("tw,th", [(1023, 58), (1023, 59), (1000, 131)])

@@ -176,6 +176,14 @@ def test_batched_cameras_through_one_call_equal_the_per_camera_frames():
         assert c1.shape == (5, 208, 336, c0.shape[-1]) and torch.equal(c0, c1) and torch.equal(a0, a1), (mode, aa)
         assert torch.equal(m0["n_isects"], m1["n_isects"]) and m1["isect_status"].shape == (5,)
         check_isect_status(m1)
+        # tile_bounds="classic" reaches the batched call too (MGS_FRAMES_CLASSIC_BOUNDS): gsplat's counts, the same pixels
+        with torch.no_grad():
+            c2, a2, m2 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, 336, 208,
+                                       tile_bounds="classic", **kw)
+            c3, a3, m3 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, 336, 208,
+                                       tile_bounds="classic", lean_meta=True, **kw)
+        assert torch.equal(c3, c0) and torch.equal(a3, a0)
+        assert torch.equal(m3["n_isects"], m2["n_isects"]) and bool((m3["n_isects"] > m1["n_isects"]).all())
     with torch.no_grad():
         _, _, m2 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, 336, 208,
                                  sh_degree=2, isect_capacity=64, lean_meta=True)
