@@ -64,7 +64,8 @@ def render(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height
 def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height, sh_degree,
                with_depth=False, background=None, eps2d=0.3, near_plane=0.01, far_plane=1e10,
                radius_clip=0.0, n_threads=0, margins=True, v_render=None, v_alpha=None,
-               want_projected=False, flip_eps=None, want_touched=False):
+               want_projected=False, flip_eps=None, want_touched=False, want_budget=False,
+               thresholds=None):
     """The frame in fp64 arithmetic on the fp32 inputs the GPU gets (the full-size reference
     answer).  Returns (render[H,W,ch] f32, alpha[H,W] f32, info).  info carries
       margins [4,H,W], edge_mask [H,W] bool, n_edge_gaussians        (margins=True; feed
@@ -73,9 +74,14 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
           decisions within eps of flipping are worth; feed oracle.gs_oracle_np.check_frame)
       touched [N] bool   (want_touched, with margins and flip_eps): Gaussians that reach alpha >= 0.5/255 at a
           could-flip pixel -- the only rows of a gradient that may differ from the oracle's by more than rounding
+      budget [N,4] f64   (want_budget, with want_touched and v_render): per Gaussian, how far its rows of the blend's
+          gradient (means2d, conics, feats, opacity -- one bound per row, valid for each component) can move when the
+          near-flip decisions at the could-flip pixels it reaches go the other way (gs_cpu.cpp: Extras::budget)
       g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opacities [N]  f64: the blend's backward
           (A.2 step 10) for upstream v_render [H,W,ch] / v_alpha [H,W]
-      means2d, conics, feats, radii as projected by the oracle          (want_projected=True)."""
+      means2d, conics, feats, radii as projected by the oracle          (want_projected=True).
+    thresholds = (a, t): the blend tests alpha >= a / 255 and stops at T' <= t * 1e-4 (default 1, 1) -- a test moves
+    them by less than the gate's eps to produce real flips and nothing else."""
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     means, quats, scales, opacities, sh = f(means), f(quats), f(scales), f(opacities), f(sh_coeffs)
     vm, Km = f(viewmat), f(K)
@@ -93,7 +99,10 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
     fe = (np.array([flip_eps["alpha"], flip_eps["T"], flip_eps["sigma"], flip_eps.get("depth", 0.0)], np.float32)
           if fw is not None else None)
     want_projected = want_projected or fw is not None        # feat_max comes from the projected features
-    tch = np.zeros(n, np.uint8) if (want_touched and fw is not None) else None
+    tch = np.zeros(n, np.uint8) if ((want_touched or want_budget) and fw is not None) else None
+    if want_budget and (tch is None or v_render is None):
+        raise ValueError("want_budget needs margins, flip_eps and v_render")
+    bud = np.zeros((n, 4), np.float64) if want_budget else None
     bwd = v_render is not None
     vr = f(v_render).reshape(height, width, ch) if bwd else None
     va = f(v_alpha if v_alpha is not None else np.zeros((height, width))).reshape(height, width) if bwd else None
@@ -105,7 +114,8 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
         n, p(means), p(quats), p(scales), p(opacities), int(sh_degree), sh.shape[1], p(sh), p(vm),
         p(Km), int(width), int(height), cf(eps2d), cf(near_plane), cf(far_plane), cf(radius_clip),
         ch, p(bg), int(n_threads), p(out), p(alpha), p(counters), p(marg), p(edge), p(n_edge),
-        p(vr), p(va), p(gm), p(gc), p(gf), p(go), p(om), p(oc), p(of_), p(orad), p(fw), p(fe), p(tch))
+        p(vr), p(va), p(gm), p(gc), p(gf), p(go), p(om), p(oc), p(of_), p(orad), p(fw), p(fe), p(tch), p(bud),
+        p(np.array(thresholds, np.float32)) if thresholds is not None else None)
     info = {"n_isect": int(n_isect), "n_vis": int(counters[0]), "pair_evals": int(counters[1])}
     if margins:
         info.update(margins=marg, edge_mask=edge.astype(bool), n_edge_gaussians=int(n_edge[0]))
@@ -113,6 +123,8 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
             vis = orad > 0
             if tch is not None:
                 info["touched"] = tch.astype(bool)
+            if bud is not None:
+                info["budget"] = bud
             info.update(flip_weight=fw, feat_max=(np.abs(of_[vis]).max(axis=0) if vis.any() else np.zeros(ch)))
     if bwd:
         info.update(g_means2d=gm, g_conics=gc, g_feats=gf, g_opacities=go)

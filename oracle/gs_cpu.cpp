@@ -165,6 +165,23 @@ struct Extras {            // optional outputs of the double build (all may be n
   // colour behind for every Gaussian blended there: only these rows of the gradient may differ from the
   // oracle's by more than rounding.
   uint8_t* touched = nullptr;
+  // budget [N,4] (needs touched's inputs and v_render / v_alpha): per Gaussian, how far its rows of the blend's
+  // gradient {means2d, conics, feats, opacity} can move when the near-flip decisions at the could-flip pixels it
+  // reaches go the other way.  At such a pixel p the decisions within flip_eps are worth flip_weight[p] as a blend
+  // weight; toggling one of them changes, for every Gaussian g blended at p (alpha_g >= 0.5/255),
+  //   T_g or the colour behind g, hence  d loss / d alpha_g  by at most  A = flip_weight[p] (sum_c 2 max|f_c| |v_c| + |v_alpha'|) / (1 - alpha_g)
+  //   (v_alpha' carries the background term), and g's own weight alpha_g T_g by at most flip_weight[p];
+  // g's OWN toggle (its alpha or sigma test within eps) removes its whole term: |d loss / d alpha_g| <= T_g (...) with
+  // T_g <= flip_weight[p] / alpha_g.  Summed over the pixels:
+  //   opacity  vis A  (own: A / opacity)      means2d  ov A max|conic d|  (own: A max|conic d|)
+  //   conics   ov A max(dx^2 / 2, |dx dy|, dy^2 / 2)  (own: without ov)      feats  flip_weight[p] max_c |v_c| / (1 - alpha_g)
+  // A test then demands |got - ref| <= rounding tolerance + 1.5 budget on EVERY row: a gradient that is wrong on the
+  // Gaussians near a threshold by more than the threshold can explain no longer passes.
+  double* budget = nullptr;
+  // thresholds {alpha >= thr[0] / 255, stop at T' <= thr[1] * 1e-4}; null = {1, 1}.  Moving a threshold by less than the
+  // gate's eps flips exactly the decisions the margins call "could flip" and changes nothing else: how a test produces
+  // REAL flips to hold the flip weight and the gradient budget against (tests/test_oracle_cpu.py).
+  const float* thresholds = nullptr;
   // backward of the blend (A.2 step 10), fp64 accumulation
   const float* v_render = nullptr; // [H,W,ch]
   const float* v_alpha = nullptr;  // [H,W]
@@ -296,6 +313,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
 
   const bool want_margins = ex.margins != nullptr;
   const bool want_bwd = ex.v_render != nullptr;
+  const double thr_alpha = (ex.thresholds ? (double)ex.thresholds[0] : 1.0) / 255.0, thr_T = (ex.thresholds ? (double)ex.thresholds[1] : 1.0) * 1e-4;
   const size_t n_px = (size_t)width * height;
   const float inf = std::numeric_limits<float>::infinity();
   if (want_margins) std::fill(ex.margins, ex.margins + 4 * n_px, inf);
@@ -346,7 +364,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
             if (toggle) { fw += (double)(alpha * Tr); loose += (double)alpha; }
           }
           if (sigma < 0) continue;
-          if (alpha < F(1.0 / 255.0)) continue;
+          if (alpha < F(thr_alpha)) continue;
           if (want_margins) {      // consecutive contributors whose depths are within rounding of a tie may swap
             if (z_prev > 0) {
               const F mz = (s.depth - z_prev) / s.depth;
@@ -356,7 +374,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
             z_prev = s.depth;
             wt_prev = (double)(alpha * Tr);
           }
-          if (nT <= F(1e-4)) break;
+          if (nT <= F(thr_T)) break;
           F wgt = alpha * Tr;
           for (int c = 0; c < channels; ++c) C[c] += wgt * feat[(size_t)g * channels + c];
           Tr = nT;
@@ -408,6 +426,14 @@ long long render_impl(int n, const float* means, const float* quats, const float
   }
   if (want_margins && want_edges && ex.touched && ex.flip_eps) {
     std::memset(ex.touched, 0, (size_t)n);
+    const bool want_budget = ex.budget != nullptr && ex.v_render != nullptr && ex.flip_weight != nullptr;
+    double fmax[4] = {0, 0, 0, 0};
+    if (want_budget) {
+      std::fill(ex.budget, ex.budget + 4 * (size_t)n, 0.0);
+      for (int g = 0; g < n; ++g)
+        if (sp[g].radius > 0)
+          for (int c = 0; c < channels; ++c) fmax[c] = std::max(fmax[c], std::abs((double)feat[(size_t)g * channels + c]));
+    }
 #pragma omp parallel for schedule(dynamic, 16)
     for (long long t = 0; t < (long long)tw * th; ++t) {
       const int tx = (int)(t % tw), ty = (int)(t / tw);
@@ -418,12 +444,48 @@ long long render_impl(int n, const float* means, const float* quats, const float
                                   ex.margins[2 * n_px + p] < ex.flip_eps[2] || ex.margins[3 * n_px + p] < ex.flip_eps[3];
           if (!could_flip) continue;
           const F fx = px + F(0.5), fy = py + F(0.5);
+          double vabs = 0, vmax = 0, fwp = 0;
+          if (want_budget) {
+            fwp = (double)ex.flip_weight[p];
+            double va = ex.v_alpha ? std::abs((double)ex.v_alpha[p]) : 0.0;
+            for (int c = 0; c < channels; ++c) {
+              const double vc = std::abs((double)ex.v_render[p * channels + c]);
+              vabs += 2.0 * fmax[c] * vc;
+              vmax = std::max(vmax, vc);
+              if (background) va += std::abs((double)background[c]) * vc;
+            }
+            vabs += va;
+          }
           for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
             const int g = ids[perm[i]];
             const Splat<F>& s = sp[g];
             F dx = s.mx - fx, dy = s.my - fy;
             F sigma = F(0.5) * (s.ca * dx * dx + s.cc * dy * dy) + s.cb * dx * dy;
-            if (s.opac * std::exp(-sigma) >= F(0.5 / 255.0)) ex.touched[g] = 1;     // (benign race: all writers store 1)
+            const F vis = std::exp(-sigma), ov = s.opac * vis;
+            if (ov >= F(0.5 / 255.0)) {
+              ex.touched[g] = 1;     // (benign race: all writers store 1)
+              if (want_budget && fwp > 0) {
+                // g's OWN decision at p within eps of flipping (alpha or sigma test): its whole term at this pixel comes or
+                // goes -- |d loss / d alpha_g| <= T_g vabs with T_g <= flip_weight / alpha_g (its alpha_g T_g is in the
+                // weight), so the factors are flip_weight vabs x {geometry, 1 / opacity}, not ov times that
+                const double S_abs = 0.5 * (std::abs((double)s.ca) * dx * dx + std::abs((double)s.cc) * dy * dy) + std::abs((double)(s.cb * dx * dy));
+                const bool self = std::abs((double)ov * 255.0 - 1.0) < (double)ex.flip_eps[0] ||
+                                  (S_abs > 0 && std::abs((double)sigma) / S_abs < (double)ex.flip_eps[2]);
+                const double ra = 1.0 / (1.0 - std::min(0.999, (double)ov)), A = fwp * vabs * ra;
+                const double bs = (self ? 1.0 : (double)ov) * A, bo = self ? A / std::max(1e-30, (double)s.opac) : (double)vis * A;
+                const double gm = std::max(std::abs((double)(s.ca * dx + s.cb * dy)), std::abs((double)(s.cb * dx + s.cc * dy)));
+                const double gc = std::max(std::max(0.5 * (double)(dx * dx), std::abs((double)(dx * dy))), 0.5 * (double)(dy * dy));
+                double* b = ex.budget + 4 * (size_t)g;
+#pragma omp atomic
+                b[0] += bs * gm;
+#pragma omp atomic
+                b[1] += bs * gc;
+#pragma omp atomic
+                b[2] += fwp * vmax * ra;
+#pragma omp atomic
+                b[3] += bo;
+              }
+            }
           }
         }
     }
@@ -463,7 +525,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
             const double sigma = 0.5 * ((double)s.ca * dx * dx + (double)s.cc * dy * dy) + (double)s.cb * dx * dy;
             const double vis = std::exp(-sigma), ov = (double)s.opac * vis;
             const double alpha = std::min(0.999, ov);
-            if (sigma < 0 || alpha < 1.0 / 255.0) continue;
+            if (sigma < 0 || alpha < thr_alpha) continue;
             any = true;
             const double ra = 1.0 / (1.0 - alpha);
             Tcur[k] *= ra;
@@ -530,7 +592,8 @@ extern "C" long long gs_cpu_render(int n, const float* means, const float* quats
 }
 
 // The same frame in fp64 (inputs are the fp32 arrays the GPU gets).  Optional outputs (null to skip):
-// margins [4,H,W] + edge_mask [H,W] + n_edge (+ flip_weight [H,W] for the thresholds flip_eps[4], see Extras); blend backward given v_render [H,W,ch] / v_alpha [H,W]
+// margins [4,H,W] + edge_mask [H,W] + n_edge (+ flip_weight [H,W] for the thresholds flip_eps[4], touched [N] and, with the
+// cotangents, budget [N,4]: see Extras); blend backward given v_render [H,W,ch] / v_alpha [H,W]
 // into g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opac [N]; the projected quantities
 // o_means2d / o_conics / o_feats / o_radii.
 extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* quats,
@@ -544,9 +607,12 @@ extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* q
                                        const float* v_alpha, double* g_means2d, double* g_conics,
                                        double* g_feats, double* g_opac, double* o_means2d,
                                        double* o_conics, double* o_feats, int32_t* o_radii,
-                                       float* flip_weight, const float* flip_eps, uint8_t* touched) {
+                                       float* flip_weight, const float* flip_eps, uint8_t* touched,
+                                       double* budget, const float* thresholds) {
   Extras ex;
+  ex.thresholds = thresholds;
   ex.touched = touched;
+  ex.budget = budget;
   ex.margins = margins; ex.edge_mask = edge_mask; ex.n_edge = n_edge;
   ex.flip_weight = flip_weight; ex.flip_eps = flip_eps;
   ex.v_render = v_render; ex.v_alpha = v_alpha;

@@ -162,6 +162,8 @@ class _RenderSH(torch.autograd.Function):
             # screen-space gradients for densification strategies (gsplat exposes them through
             # means2d.grad / means2d.absgrad; here they are published in the meta dict)
             ctx.meta_out.setdefault("means2d_grad", [None] * C)[c] = v_means2d
+            # (all four blend-stage gradients, for tests that gate the raster backward on its own)
+            ctx.meta_out.setdefault("blend_grads", [None] * C)[c] = (v_means2d, v_conics, v_feats, v_opac)
             if absgrad:
                 ctx.meta_out.setdefault("means2d_absgrad", [None] * C)[c] = v_abs
             check(L.mgs_project_color_bwd(

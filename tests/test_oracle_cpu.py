@@ -96,3 +96,64 @@ def test_thread_count_does_not_change_the_image():
     a, _, _ = cpu_ref.render(*args, n_threads=1)
     b, _, _ = cpu_ref.render(*args, n_threads=8)
     np.testing.assert_array_equal(a, b)
+
+
+def _blend_grads(g, cam, W, H, deg, w_img, w_a, thresholds=None, want_budget=False):
+    vm, K = cam.viewmat().astype(np.float32), cam.K.astype(np.float32)
+    img, al, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs,
+                                       vm, K, W, H, deg, with_depth=True, v_render=w_img, v_alpha=w_a,
+                                       flip_eps=O.EPS_PATH_GRAD, want_touched=True, want_budget=want_budget, n_threads=4,
+                                       thresholds=thresholds)
+    info["image"], info["alpha"] = img, al
+    return info
+
+
+def test_gradient_budget_covers_real_flips_and_rejects_rows_the_old_gate_let_through():
+    """tests/grad_gate.py.  (1) REAL flips: the same blend with its thresholds moved by less than the gate's eps
+    (alpha >= (1 +- 2.5e-4) / 255, stop at T' <= (1 +- 2e-3) 1e-4) flips exactly the decisions the margins call "could
+    flip" and nothing else; every gradient row must then lie within rounding + 1.5 x the row's flip budget of the
+    unperturbed one, and every pixel within the forward's flip-weight bound -- both bounds hold against what flips
+    really do.  (2) A backward that is WRONG on Gaussians near a threshold (here: every row of ~100
+    touched Gaussians doubled) passed the round-3 gate, which exempted touched rows altogether, and fails this one."""
+    import pytest
+    from grad_gate import compare
+    W, H, deg = 160, 112, 1
+    g = synthetic_scene(12000, math.log(0.07), deg, 9)
+    cam = camera_ring(1, W, H, thetas=[0.9])[0]
+    rng = np.random.default_rng(3)
+    w_img = rng.normal(size=(H, W, 4)).astype(np.float32)
+    w_a = rng.normal(size=(H, W)).astype(np.float32)
+    ref = _blend_grads(g, cam, W, H, deg, w_img, w_a, want_budget=True)
+    bud, touched = ref["budget"], ref["touched"]
+    vis = ref["radii"] > 0
+    assert bud.shape == (len(g), 4) and (bud >= 0).all() and not bud[~touched].any()
+    assert 0.02 < touched[vis].mean() < 0.9 and (bud[touched] > 0).any(axis=1).mean() > 0.9
+    rows = {"means2d": (ref["g_means2d"], bud[:, 0]), "conics": (ref["g_conics"], bud[:, 1]),
+            "feats": (ref["g_feats"], bud[:, 2]), "opacities": (ref["g_opacities"].reshape(-1, 1), bud[:, 3])}
+    # (1) real flips
+    moved = 0
+    eps = O.EPS_PATH_GRAD
+    for thr in ((1 + 0.8 * eps["alpha"], 1.0), (1 - 0.8 * eps["alpha"], 1.0), (1.0, 1 + 0.6 * eps["T"]), (1.0, 1 - 0.6 * eps["T"]),
+                (1 + 0.8 * eps["alpha"], 1 - 0.6 * eps["T"])):
+        per = _blend_grads(g, cam, W, H, deg, w_img, w_a, thresholds=thr)
+        # the image moved at could-flip pixels only, by no more than the flip weight allows
+        d_img = np.abs(per["image"].astype(np.float64) - ref["image"])
+        fmax = np.abs(ref["feats"][vis]).max(axis=0)
+        assert (d_img <= 1e-6 + 1.5 * ref["flip_weight"][..., None] * 2 * fmax).all()
+        assert (np.abs(per["alpha"].astype(np.float64) - ref["alpha"]) <= 1e-6 + 1.5 * ref["flip_weight"]).all()
+        for name, (r, b) in rows.items():
+            key = "g_" + name if name != "opacities" else "g_opacities"
+            st = compare(name + f" (thresholds x {thr})", per[key].reshape(r.shape), r, row_tol=1e-7, bad_frac=1.0, cos_min=0.99,
+                         budget=b, verbose=False)
+            moved += st["rows_over_rounding"]
+    assert moved > 0, "the perturbation flipped nothing: the case does not exercise the budget"
+    # (2) a backward wrong on touched rows only
+    cand = np.flatnonzero(touched & vis)
+    idx = cand[::max(1, int(math.ceil(len(cand) / (0.008 * len(g)))))]        # under the old gate's 1 % allowance
+    assert 50 < len(idx) <= 0.01 * len(g)
+    for name, (r, b) in rows.items():
+        bad = r.copy()
+        bad[idx] *= 2.0
+        compare(name + " (old gate)", bad, r, row_tol=2e-3, bad_frac=1e-2, cos_min=0.9, touched=touched, verbose=False)
+        with pytest.raises(AssertionError, match="flip budget"):
+            compare(name + " (new gate)", bad, r, row_tol=2e-3, bad_frac=1e-2, cos_min=0.9, budget=b, verbose=False)
