@@ -51,16 +51,30 @@ sys.path.insert(0, ROOT)
 
 from robosimgs_amd import camera_ring, synthetic_scene  # noqa: E402
 from robosimgs_amd import ops  # noqa: E402
-from robosimgs_amd.distributed import shard_cameras  # noqa: E402
+from robosimgs_amd.distributed import root_weights, shard_cameras, shard_sizes  # noqa: E402
 from robosimgs_amd.rendering import rasterization  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
 MODE = "RGB+ED"                # what splatfacto renders and INTEGRATION.md tells users to call
 RING = 64                      # configs[3]: 64 novel-view cameras
-PAYLOADS = {"dataset": "dataset frames: RGBA8 + fp32 ray distance, 8 B per pixel, the layout DatasetWriter stores and the "
+PAYLOADS = {"dataset16": "dataset frames, light: RGBA8 + fp16 ray distance, 6 B per pixel -- the RGBA image load_images reads and a "
+                         "half-precision distance map (np.float16: load_depths / distance_to_depth take it as it is); "
+                         "mgs_frame_to_dataset on the device, inside the timed region",
+            "dataset": "dataset frames: RGBA8 + fp32 ray distance, 8 B per pixel, the layout DatasetWriter stores and the "
                        "reference's load_images / load_depths read (mgs_frame_to_dataset on the device, inside the timed region)",
             "fp32": "fp32 RGB + expected depth + alpha (20 B per pixel)",
             "u8": "8-bit RGB images (frame_to_u8 on the device, inside the timed region)"}
+PAYLOAD_BYTES_PER_PX = {"dataset16": 6, "dataset": 8, "fp32": 20, "u8": 3}
+XGMI_LINK_GBS = 50.0           # what an RCCL point-to-point gather is assumed to sustain per xGMI link and direction
+                               # (peak 153 GB/s per link both ways, MI355X_MICROARCH.md; not measured: no multi-GPU box)
+
+
+def root_bound_frames_per_s(mode, W, H, world):
+    """Ceiling the single gathering rank puts on the job: its inbound links carry (world - 1) / world of every frame."""
+    if world < 2:
+        return None
+    inbound = XGMI_LINK_GBS * 1e9 * min(world - 1, 7)
+    return inbound / (PAYLOAD_BYTES_PER_PX[mode] * W * H * (world - 1) / world)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -85,7 +99,10 @@ def parse():
     # load_images / load_depths read it: RGBA8 + fp32 ray distance, 8 B per pixel = 16.6 MB per frame, converted on the
     # device inside the timed region (mgs_frame_to_dataset); "fp32" = the raw renders, RGB + depth + alpha, 41.5 MB per
     # frame (332 MB per rank and pass at 8 ranks); "u8" = 8-bit RGB only (6.2 MB per frame).
-    ap.add_argument("--gather-dtype", choices=("dataset", "fp32", "u8"), default="dataset")
+    ap.add_argument("--gather-dtype", choices=("dataset16", "dataset", "fp32", "u8"), default="dataset16")
+    # the rank that receives every frame (and converts its own) renders a smaller block of the ring: its share in units
+    # of the other ranks' (1 = equal blocks).  At 8 ranks 0.5 gives 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 cameras.
+    ap.add_argument("--root-weight", type=float, default=0.5)
     ap.add_argument("--gather-batch", type=int, default=4, help="frames per collective (N > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
@@ -176,8 +193,9 @@ def main():
     t = scene.to_torch(dev, deg)
     tile_w, tile_h = -(-W // 16), -(-H // 16)
     # cameras: the single theta = 0.3 view of configs[1], or this rank's block of the 64-camera ring
+    weights = root_weights(world, a.root_weight) if (ring and world > 1) else None
     if ring:
-        mine = shard_cameras(RING, world, rank)
+        mine = shard_cameras(RING, world, rank, weights)
         thetas = [2.0 * math.pi * k / RING for k in mine]
     else:
         mine = range(1)
@@ -236,16 +254,19 @@ def main():
     # converted (u8) or copied (fp32) into its place in the batch, the slot is released at once, and
     # every gather_batch-th frame one collective ships the whole batch -- a per-frame collective
     # costs ~80 us of launch / stream hand-over each, a quarter of a frame time.
-    GB = max(1, min(a.gather_batch, max(1, math.ceil(RING / world)))) if ring else 1
+    GB = max(1, min(a.gather_batch, max(1, max(shard_sizes(RING, world, weights))))) if ring else 1
+    per_rank = {}                                  # HIP-event split of this rank's last timed region (N > 1)
 
     def time_frames(g_mode):
         """Warm-up, then regions of K steps until min_seconds are timed; the gathered payload is the dataset frame
         (RGBA8 plane + fp32 ray-distance plane, 8 B per pixel), fp32 RGB + expected depth + alpha, or the 8-bit RGB
         image.  Returns (regions, collectives)."""
         g_u8 = g_mode == "u8"
-        g_ds = g_mode == "dataset"
+        g_ds = g_mode in ("dataset", "dataset16")
+        g_dist = torch.float16 if g_mode == "dataset16" else torch.float32
         g_dtype = torch.float32 if g_mode == "fp32" else torch.uint8
-        g_ch = {"dataset": 8, "u8": 3, "fp32": 5}[g_mode]  # dataset: per frame [RGBA8 plane | fp32 distance plane] as bytes
+        g_ch = {"dataset16": 6, "dataset": 8, "u8": 3, "fp32": 5}[g_mode]  # dataset: per frame [RGBA8 plane | distance plane] as bytes
+        ev = {"start": None, "render_done": None, "convert": [], "last": None, "end": None}      # timed events of the region
         batch_shape = (GB, H, W, g_ch)
         staging = [torch.empty(batch_shape, device=dev, dtype=g_dtype) for _ in range(2)] if do_gather else None
         host_staging = ([torch.empty(batch_shape, device="cpu", dtype=g_dtype) for _ in range(2)]
@@ -273,6 +294,10 @@ def main():
             """Fetch the oldest frame; with N > 1 stage it for the (asynchronous) RCCL gather."""
             tk = tickets.pop(0)
             f = fr.fetch(tk, check=False)
+            c0 = None
+            if do_gather and ev["start"] is not None:
+                c0 = torch.cuda.Event(enable_timing=True)
+                c0.record()                                # (behind the wait for the slot: the conversion alone is timed)
             if do_gather:
                 cur, j = state["cur"], state["fill"]
                 if j == 0 and pending[cur] is not None:    # the collective that last read this staging buffer
@@ -281,13 +306,18 @@ def main():
                 if g_ds:                                   # RGBA8 + ray distance, one kernel, inside the timed region
                     flat = staging[cur][j].view(-1)
                     frame_to_dataset(f["colors"], f["alphas"], K_host, out=(flat[:H * W * 4].view(H, W, 4),
-                                                                            flat[H * W * 4:].view(torch.float32).view(H, W, 1)))
+                                                                            flat[H * W * 4:].view(g_dist).view(H, W, 1)))
                 elif g_u8:                                 # quantise on the device, inside the timed region
                     frame_to_u8(f["colors"], f["alphas"], out=staging[cur][j].view(-1, 3))
                 else:                                      # RGB + depth | alpha, straight from the slot's buffers
                     staging[cur][j][..., :4].copy_(f["colors"], non_blocking=True)
                     staging[cur][j][..., 4:].copy_(f["alphas"], non_blocking=True)
                 state["fill"] = j + 1
+                if c0 is not None:
+                    c1 = torch.cuda.Event(enable_timing=True)
+                    c1.record()
+                    ev["convert"].append((c0, c1))
+                    ev["last"] = c1
                 if state["fill"] == GB:
                     ship()
             fr.release(tk)
@@ -296,6 +326,10 @@ def main():
             if len(tickets) == n_fl:
                 retire()
             tickets.append(fr.submit(cam_dev))
+            if ev["start"] is not None:                    # when this rank's renders are done: an event behind the frame
+                d = torch.cuda.Event(enable_timing=True)
+                d.record(fr._slots[tickets[-1]]["stream"])
+                ev["render_done"] = d
 
         def step():
             for cd in cam_devs:
@@ -306,7 +340,7 @@ def main():
                 retire()
             if do_gather and state["fill"] > 0:            # a partial last batch still travels (whole buffer)
                 ship()
-            if do_gather and world > 1 and RING % world != 0:
+            if do_gather and world > 1 and len(set(shard_sizes(RING, world, weights))) > 1:
                 # ragged shards (64 cameras over e.g. 3 ranks): ranks with fewer frames issue empty collectives
                 # so that every rank has made the same number of gather calls when the region ends
                 nmax = torch.tensor([state["shipped"]], device=comm_dev, dtype=torch.int64)
@@ -321,10 +355,25 @@ def main():
         def region(k_steps):
             barrier_sync(use_dist)
             t0 = time.perf_counter()
+            if do_gather:
+                ev.update(start=torch.cuda.Event(enable_timing=True), render_done=None, convert=[], last=None)
+                ev["start"].record()
             for _ in range(k_steps):
                 step()
             drain()
+            if do_gather:
+                ev["end"] = torch.cuda.Event(enable_timing=True)
+                ev["end"].record()
             barrier_sync(use_dist)
+            if do_gather:          # this rank's split of the region (HIP events): renders, conversions, the tail behind them
+                s0 = ev["start"]
+                per_rank[g_mode] = {
+                    "frames": len(cam_devs) * k_steps,
+                    "render_span_ms": round(s0.elapsed_time(ev["render_done"]), 3) if ev["render_done"] is not None else 0.0,
+                    "convert_ms": round(sum(x.elapsed_time(y) for x, y in ev["convert"]), 3),
+                    "after_last_convert_ms": round(ev["last"].elapsed_time(ev["end"]), 3) if ev["last"] is not None
+                    else round(s0.elapsed_time(ev["end"]), 3),
+                    "region_ms": round(s0.elapsed_time(ev["end"]), 3)}
             dt = time.perf_counter() - t0
             if use_dist:                                   # MAX over ranks; every rank sees the same number
                 tt = torch.tensor([dt], device=comm_dev, dtype=torch.float64)
@@ -353,7 +402,7 @@ def main():
     # the other payload, timed the same way in the same run (N > 1 only): both are reported
     other = None
     if do_gather and not a.one_payload:
-        other_mode = "fp32" if g_mode != "fp32" else "dataset"
+        other_mode = "fp32" if g_mode != "fp32" else "dataset16"
         o_regions, _ = time_frames(other_mode)
         other = float(np.median(o_regions))
     # the same frames with the renderer keeping the caller's order (N = 1 only; half the timed span)
@@ -387,7 +436,7 @@ def main():
 
     if ring:
         workload = (f"configs[3]: {a.n} Gaussians, SH degree {deg}, {RING} novel-view cameras {W}x{H} "
-                    f"(theta_k = 2 pi k / {RING}), sharded {math.ceil(RING / world)} views per GPU over "
+                    f"(theta_k = 2 pi k / {RING}), sharded {'/'.join(str(x) for x in shard_sizes(RING, world, weights))} views over "
                     f"{world} GPU(s), RCCL gather to rank 0; one step = one pass over the ring")
     else:
         workload = (f"configs[1]: {a.n} Gaussians, SH degree {deg}, {W}x{H} forward render "
@@ -398,6 +447,10 @@ def main():
             nccl_ver = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:
             nccl_ver = "unknown"
+    all_ranks = None
+    if do_gather:                                  # every rank's split of its last region, by payload
+        all_ranks = [None] * world
+        dist.all_gather_object(all_ranks, per_rank)
     result = {
         "metric": "frames/sec + ms/frame (fwd, fwd+bwd) at 1M Gaussians 1920x1080",
         "value": round(frames_per_s, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
@@ -410,7 +463,19 @@ def main():
                    "world_size": dist.get_world_size() if use_dist else 1, "rccl_version": nccl_ver,
                    "frames_per_step_all_ranks": RING if ring else 1,
                    "frames_per_step_this_rank": frames_per_step,
-                   "frames_per_rank": [len(shard_cameras(RING, world, r)) for r in range(world)] if ring else [1],
+                   "frames_per_rank": shard_sizes(RING, world, weights) if ring else [1],
+                   "root_weight": a.root_weight if (ring and world > 1) else None,
+                   "per_rank": ({m: [r_.get(m) for r_ in all_ranks] for m in all_ranks[0]} if all_ranks else None),
+                   "per_rank_note": ("HIP events on each rank over its last timed region: render_span = region start -> the rank's "
+                                     "last frame rendered, convert = sum of the payload conversions, after_last_convert = what "
+                                     "the rank's stream still waited for (its collectives; on rank 0 the other ranks' frames)"
+                                     if all_ranks else None),
+                   "root_bound": ({m: {"bytes_per_frame": PAYLOAD_BYTES_PER_PX[m] * W * H,
+                                       "frames_per_s_ceiling": round(root_bound_frames_per_s(m, W, H, world), 0)}
+                                   for m in PAYLOADS} if (ring and world > 1) else None),
+                   "root_bound_note": (f"rank 0's inbound xGMI at {XGMI_LINK_GBS:g} GB/s per link (assumed, not measured) carries "
+                                       "(N - 1) / N of every frame: the ceiling of a single-root gather whatever the renderers do"
+                                       if (ring and world > 1) else None),
                    "gather": ((PAYLOADS[g_mode]
                                + f" to rank 0 (RCCL), {GB} frames per collective, "
                                  f"{n_collectives} collectives issued") if do_gather else "none"),
@@ -556,6 +621,11 @@ def main():
             result["fwd_bwd"] = bench_fwd_bwd(a, t_given, vm, K, W, H, deg, cap, dev)      # a trainer's own order
             result["fwd_bwd"]["scene_order"] = "as given"
             result["fwd_bwd"]["roofline"] = bwd_roofline(t_given, vm, K, W, H, deg, cap, n_isect, std)
+            # the same step with the parameters in Morton order of the means (what a trainer gets by re-ordering its
+            # parameter tensors and optimiser state with robosimgs_amd.pipeline.locality_order every few hundred steps)
+            if t is not t_given:
+                m = bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev)
+                result["fwd_bwd"]["morton_order"] = {"ms_per_step": m["ms_per_step"], "steps_per_s": m["steps_per_s"]}
         except Exception as e:  # keep the headline line even if this leg fails
             result["fwd_bwd"] = {"error": repr(e)[:200]}
 

@@ -367,7 +367,9 @@ int mgs_frame_to_u8(int n_px, const float *rgb, int rgb_stride, const float *alp
  *     through INTEGER pixel coordinates, z = the last channel of colors (the "ED" depth of an RGB+ED frame;
  *     color_stride >= 4) -- what load_depths (:104-118) opens and distance_to_depth (:135-146) turns back
  *     into z.  Computed in fp64 and rounded once; with the f64 output the reader recovers z to the last
- *     fp32 bit, with f32 (what `ns-render` stores) to one ulp.
+ *     fp32 bit, with f32 (what `ns-render` stores) to one ulp.  distance_f64 == 2: IEEE half (np.float16, which
+ *     np.load and the reader's arithmetic take as they are; 11 significant bits: the light payload of the
+ *     multi-GPU gather, 6 B per pixel with the RGBA image).
  *   Kinv_host: HOST pointer to the 9 doubles of K^-1 (row-major), read during the call. */
 int mgs_frame_to_dataset(int width, int height, const float *colors, int color_stride,
                          const float *alpha, const float *background, const double *Kinv_host,

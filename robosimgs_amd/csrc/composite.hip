@@ -175,7 +175,11 @@ extern "C" int mgs_frame_to_dataset(int width, int height, const float* colors, 
   unsigned grid = div_up((unsigned)(width * height), 256u);
   if (grid > 4096u) grid = 4096u;
   hipStream_t s = (hipStream_t)stream;
-  if (distance_f64)
+  MGS_REQUIRE(distance_f64 >= 0 && distance_f64 <= 2, "frame_to_dataset: distance type %d not in {0: f32, 1: f64, 2: f16}", distance_f64);
+  if (distance_f64 == 2)
+    hipLaunchKernelGGL(frame_to_dataset_kernel<_Float16>, dim3(grid), dim3(256), 0, s, width, height, colors, color_stride,
+                       alpha, background, ki, reinterpret_cast<uint32_t*>(rgba), static_cast<_Float16*>(distance));
+  else if (distance_f64)
     hipLaunchKernelGGL(frame_to_dataset_kernel<double>, dim3(grid), dim3(256), 0, s, width, height, colors, color_stride,
                        alpha, background, ki, reinterpret_cast<uint32_t*>(rgba), static_cast<double*>(distance));
   else

@@ -128,6 +128,11 @@ __device__ __forceinline__ void blend_pixel(PixelState<CHT>& px, unsigned long l
 #ifndef MGS_RASTER_Q_BREAK
 #define MGS_RASTER_Q_BREAK 0        // one wave per 8x8 block: leave the batch at the entry that closes the block's last pixel
 #endif
+#ifndef MGS_RASTER_CLOSE_BRANCH
+// 1: the lane-mask bookkeeping of a pixel that closes (s_andn2 / s_cselect / s_and) sits behind a scalar branch on "some
+// pixel closed" -- nearly always skipped: 4 instead of 6 scalar instructions per quadrant body
+#define MGS_RASTER_CLOSE_BRANCH 0
+#endif
 #ifndef MGS_RASTER_LIVE_BITS
 #define MGS_RASTER_LIVE_BITS 1      // one wave per tile: a quadrant whose last pixel closes is skipped for the rest of the batch
 #endif
@@ -227,11 +232,15 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, unsign
       "v_mov_b32 %[last], %[idx]\n"
       ".endif\n"
       "s_xor_b64 vcc, vcc, %[acc]\n"                   // counted but not accumulated: the pixels this Gaussian closes
+      ".if %[closebranch]\n"                           // (SCC = some pixel closes: rare -- the bookkeeping sits behind a branch)
+      "s_cbranch_scc0 1f\n"
+      ".endif\n"
       "s_andn2_b64 %[alive], %[alive], vcc\n"          // (SCC = some pixel of the quadrant is still open)
       ".if %[livebit] >= 0\n"
       "s_cselect_b32 vcc_lo, -1, %[clr]\n"
       "s_and_b32 %[live], %[live], vcc_lo\n"
       ".endif\n"
+      "1:\n"
       "s_mov_b64 exec, -1\n"
       : [dx] "=&v"(dx), [t0] "=&v"(t0), [t1] "=&v"(t1), [acc] "=&s"(acc), [alive] "+s"(alive), [live] "+s"(live),
         [T] "+v"(px.T), [c0] "+v"(px.C[0]), [c1] "+v"(px.C[1]), [c2] "+v"(px.C[2]), [c3] "+v"(c3), [last] "+v"(px.last)
@@ -239,7 +248,7 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, unsign
         [yy] "v"(pp.yy), [A] "v"(A), [B] "v"(B), [C] "v"(C),
         [f0] "v"(feat[0]), [f1] "v"(feat[1]), [f2] "v"(feat[2]), [f3] "v"(f3), [amin] "s"(amin), [tstop] "s"(tstop),
         [four] "n"(CHT == 4 ? 1 : 0), [track] "n"(TRACK_LAST ? 1 : 0), [idx] "v"(idx), [livebit] "n"(LIVE_BIT),
-        [clr] "n"(LIVE_BIT >= 0 ? ~(1 << LIVE_BIT) : -1)
+        [clr] "n"(LIVE_BIT >= 0 ? ~(1 << LIVE_BIT) : -1), [closebranch] "n"(MGS_RASTER_CLOSE_BRANCH)
       : "vcc", "scc");            // (s_xor / s_andn2 write SCC: the loop counter's compare must not straddle the body)
   if (CHT == 4) px.C[CHT - 1] = c3;
 }

@@ -106,7 +106,16 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
   // reads one ds_read_b64 and makes one 64-bit compare per candidate
   __shared__ unsigned long long lc[kFast];
   uint32_t* li = reinterpret_cast<uint32_t*>(lc);
-  const int tile = blockIdx.x;
+  // GROUPED: the 2^shift workgroups of a group all read the group's segment.  Workgroup b runs on XCD b % 8 (observed
+  // placement, used for speed only), each XCD has its own L2: with tile = blockIdx.x the four readers sat on four XCDs
+  // and the segment came out of HBM / Infinity Cache four times (FETCH_SIZE 2 x 39 MB for 15 MB of entries).  Blocks
+  // of 8 * 2^shift consecutive workgroups take 8 groups, one per XCD: b = 8 G q + r -> group 8 q + r % 8, tile r / 8
+  // of it, so a group's readers share one L2 and are dispatched within 8 G workgroups of each other.
+  int tile = blockIdx.x;
+  if (GROUPED) {
+    const int G = 1 << shift, r = blockIdx.x % (8 * G);
+    tile = ((blockIdx.x / (8 * G)) * 8 + (r & 7)) * G + (r >> 3);
+  }
   if (tile >= n_tiles) return;
   const int tid = threadIdx.x;
   int s, e, gs = 0, ge = 0;
@@ -482,8 +491,10 @@ int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depth
   uint32_t* t = static_cast<uint32_t*>(temp);
   // average list length the capacity allows: short lists -> the fast path with the smaller LDS list
   const bool short_lists = (size_t)capacity <= (size_t)n_tiles * 640;
+  // (GROUPED launches are padded to whole blocks of 8 groups: the kernel's XCD-aware tile numbering)
+  const int per = 8 << group_shift, n_wg = staging ? (n_tiles + per - 1) / per * per : n_tiles;
 #define MGS_TS_LAUNCH(G, F, OFFS, STG, SH, OUT)                                                              \
-  hipLaunchKernelGGL((tile_depth_sort_kernel<G, F>), dim3(n_tiles), dim3(kTS), 0, stream, n_tiles, OFFS,   \
+  hipLaunchKernelGGL((tile_depth_sort_kernel<G, F>), dim3(n_wg), dim3(kTS), 0, stream, n_tiles, OFFS,   \
                      depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,    \
                      STG, SH, OUT)
   if (staging) {

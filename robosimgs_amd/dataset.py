@@ -141,7 +141,8 @@ def frame_to_dataset(colors, alphas, K=None, background: Optional[Sequence[float
     "RGB+ED" / "RGB+D" frame), alphas [H,W,1] or [H,W], K [3,3] (numpy / list; None = image only).
     Returns (rgba uint8 [H,W,4] or None, distance [H,W,1] or None) on the device.
     distance_dtype: torch.float32 (default, what `ns-render` stores; the reader recovers z to one ulp) or
-    torch.float64 (the reader recovers z to the last fp32 bit).
+    torch.float64 (the reader recovers z to the last fp32 bit), or torch.float16 (11 significant bits: the light
+    payload of the multi-GPU gather).
     out = (rgba uint8 [H,W,4], distance [H,W,1]) writes into existing contiguous buffers (e.g. a gather's staging area)."""
     import torch
 
@@ -163,17 +164,17 @@ def frame_to_dataset(colors, alphas, K=None, background: Optional[Sequence[float
             raise ValueError("out = (uint8 [H,W,4], float [H,W,1]), both contiguous")
         if dist_out is not None:
             distance_dtype = dist_out.dtype
-    f64 = distance_dtype == torch.float64
+    dist_type = {torch.float64: 1, torch.float16: 2}.get(distance_dtype, 0)
     if K is not None:
         if d < 4:
             raise ValueError("the distance map needs a depth channel: render with render_mode='RGB+ED'")
-        if distance_dtype not in (None, torch.float32, torch.float64):
-            raise ValueError("distance_dtype must be torch.float32 or torch.float64")
+        if distance_dtype not in (None, torch.float32, torch.float64, torch.float16):
+            raise ValueError("distance_dtype must be torch.float32, torch.float64 or torch.float16")
         kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(K, dtype=np.float64).reshape(3, 3)))
         dist = (out[1] if out is not None and out[1] is not None
-                else torch.empty(h, w, 1, dtype=torch.float64 if f64 else torch.float32, device=dev))
+                else torch.empty(h, w, 1, dtype=distance_dtype or torch.float32, device=dev))
     bg = torch.tensor(list(background), dtype=torch.float32, device=dev) if background is not None else None
     check(_lib.lib().mgs_frame_to_dataset(w, h, ptr(c), d, ptr(a), ptr(bg),
                                           kinv.ctypes.data if kinv is not None else None, ptr(rgba), ptr(dist),
-                                          int(f64), stream_handle()), "mgs_frame_to_dataset")
+                                          dist_type, stream_handle()), "mgs_frame_to_dataset")
     return rgba, dist

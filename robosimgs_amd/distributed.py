@@ -14,28 +14,50 @@ import torch
 import torch.distributed as dist
 
 
-def shard_cameras(n_cameras: int, world_size: int, rank: int) -> range:
-    """Contiguous block of camera indices owned by `rank`; blocks differ by at most one."""
+def shard_sizes(n_cameras: int, world_size: int, weights: Optional[Sequence[float]] = None) -> List[int]:
+    """Cameras per rank.  weights (one per rank, > 0; None = equal): shares in proportion, rounded by largest remainder
+    (ties to the lower rank), so the sizes always add up to n_cameras.  The rank that also RECEIVES the gathered frames
+    (and converts its own) gets a weight below 1: at 8 ranks it takes 7/8 of every frame over its seven xGMI links."""
+    if weights is None:
+        base, rem = divmod(n_cameras, world_size)
+        return [base + (1 if r < rem else 0) for r in range(world_size)]
+    w = [float(x) for x in weights]
+    if len(w) != world_size or min(w) <= 0:
+        raise ValueError(f"need {world_size} positive weights, got {weights}")
+    exact = [n_cameras * x / sum(w) for x in w]
+    sizes = [int(e) for e in exact]
+    order = sorted(range(world_size), key=lambda r: (-(exact[r] - sizes[r]), r))
+    for r in order[:n_cameras - sum(sizes)]:
+        sizes[r] += 1
+    return sizes
+
+
+def shard_cameras(n_cameras: int, world_size: int, rank: int, weights: Optional[Sequence[float]] = None) -> range:
+    """Contiguous block of camera indices owned by `rank`; equal blocks differ by at most one, weighted blocks
+    (shard_sizes) follow the weights."""
     if not 0 <= rank < world_size:
         raise ValueError(f"rank {rank} outside world of {world_size}")
-    base, rem = divmod(n_cameras, world_size)
-    start = rank * base + min(rank, rem)
-    return range(start, start + base + (1 if rank < rem else 0))
+    sizes = shard_sizes(n_cameras, world_size, weights)
+    start = sum(sizes[:rank])
+    return range(start, start + sizes[rank])
 
 
-def shard_sizes(n_cameras: int, world_size: int) -> List[int]:
-    return [len(shard_cameras(n_cameras, world_size, r)) for r in range(world_size)]
+def root_weights(world_size: int, root_weight: float = 1.0, dst: int = 0) -> Optional[List[float]]:
+    """Weights for shard_cameras with the gathering rank at `root_weight` and every other rank at 1 (None when equal)."""
+    if world_size < 2 or root_weight == 1.0:
+        return None
+    return [root_weight if r == dst else 1.0 for r in range(world_size)]
 
 
 def gather_frames(local: torch.Tensor, n_cameras: int, dst: int = 0,
-                  group=None) -> Optional[torch.Tensor]:
+                  group=None, weights: Optional[Sequence[float]] = None) -> Optional[torch.Tensor]:
     """Gather per-rank frame blocks [c_r, H, W, D] onto `dst` in camera order.
 
     Ragged shards (n_cameras % world != 0) are padded to the largest shard for the collective
     and trimmed afterwards.  Returns [n_cameras, H, W, D] on `dst`, None elsewhere."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    sizes = shard_sizes(n_cameras, world)
+    sizes = shard_sizes(n_cameras, world, weights)
     if local.shape[0] != sizes[rank]:
         raise ValueError(f"rank {rank} holds {local.shape[0]} frames, shard is {sizes[rank]}")
     biggest = max(sizes)
@@ -72,7 +94,7 @@ def all_reduce_gradients(params: Sequence[torch.Tensor], group=None, average: bo
 
 def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, width: int,
                    height: int, dst: int = 0, group=None, gather: bool = True, renderer=None,
-                   as_u8: bool = False, u8_background=None,
+                   as_u8: bool = False, u8_background=None, weights: Optional[Sequence[float]] = None,
                    **kw) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], range]:
     """Render this rank's block of the C cameras and (optionally) gather all frames on `dst`.
     `renderer`: a persistent `FrameRenderer` built for this scene / resolution / render mode;
@@ -84,12 +106,13 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
     Returns (colors, alphas, my_range): full [C,...] tensors on `dst` when gathered, this
     rank's block otherwise.  as_u8=True gathers 8-bit RGB images instead of fp32 renders
     (compositing.frame_to_u8 with `u8_background`; alphas are then not gathered): a quarter of the
-    bytes over xGMI, which is what a dataset writer stores anyway."""
+    bytes over xGMI, which is what a dataset writer stores anyway.
+    weights: camera shares per rank (shard_sizes; root_weights(world, 0.5) halves the gathering rank's share)."""
     from .rendering import rasterization
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     C = viewmats.shape[0]
-    mine = shard_cameras(C, world, rank)
+    mine = shard_cameras(C, world, rank, weights)
     sel = slice(mine.start, mine.stop)
     if len(mine) and renderer is not None:
         cs, als = [None] * len(mine), [None] * len(mine)
@@ -118,5 +141,5 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
                   else torch.zeros(0, height, width, 3, dtype=torch.uint8, device=viewmats.device))
     if not gather or world == 1:
         return colors, alphas, mine
-    return (gather_frames(colors, C, dst, group),
-            None if as_u8 else gather_frames(alphas, C, dst, group), mine)
+    return (gather_frames(colors, C, dst, group, weights),
+            None if as_u8 else gather_frames(alphas, C, dst, group, weights), mine)

@@ -24,7 +24,20 @@ def test_plain_python_bench_gpus_2_launches_its_ranks_and_prints_one_json_line()
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["world_size"] == 2
-    assert res["config"]["frames_per_rank"] == [32, 32]
+    # rank 0 also receives and converts: half a share by default (--root-weight 0.5): 64 * 0.5 / 1.5 = 21.3 -> 21 + 43
+    cfg = res["config"]
+    assert cfg["frames_per_rank"] == [21, 43] and cfg["root_weight"] == 0.5
+    # where each rank's time went (HIP events), for both payloads of the run, and the single-root ceiling by payload
+    for mode in ("dataset16", "fp32"):
+        rows = cfg["per_rank"][mode]
+        assert len(rows) == 2 and [r_["frames"] for r_ in rows] == [21 * 2, 43 * 2]
+        for r_ in rows:
+            assert set(r_) == {"frames", "render_span_ms", "convert_ms", "after_last_convert_ms", "region_ms"}
+            assert 0 < r_["render_span_ms"] <= r_["region_ms"] and r_["convert_ms"] > 0 and r_["after_last_convert_ms"] >= 0
+    rb = cfg["root_bound"]
+    assert rb["dataset16"]["bytes_per_frame"] == 6 * 1920 * 1080 and rb["fp32"]["bytes_per_frame"] == 20 * 1920 * 1080
+    assert rb["u8"]["frames_per_s_ceiling"] > rb["dataset16"]["frames_per_s_ceiling"] > rb["dataset"]["frames_per_s_ceiling"] > rb["fp32"]["frames_per_s_ceiling"]
+    assert "fp16 ray distance" in cfg["gather"] and cfg["gather_other_payload"]["frames_per_s"] > 0
     assert res["scaling"] == "strong" and res["steps"] == 2 and res["warmup"] == 1
     assert res["config"]["frames_per_step_all_ranks"] == 64
     assert res["value"] > 0 and abs(res["value"] - 64 * 2 / (res["ms_per_step"] * 2 * 1e-3)) / res["value"] < 1e-3

@@ -29,6 +29,11 @@ def test_kernel_writes_the_arrays_the_reference_read(i, tmp_path):
         img, dep = DatasetWriter(str(tmp_path / tag)).write(i, rgba, dist)
         assert open(img, "rb").read() == G[f"png_bytes_{i}"].tobytes()                    # the very files
         assert open(dep, "rb").read() == G[f"npygz_bytes_{tag}_{i}"].tobytes()            # the reference opened
+    # the light gather payload: the same distance rounded ONCE to IEEE half (what np.float16 of the f64 array gives)
+    rgba16, d16 = frame_to_dataset(colors, alpha[..., None], G[f"K_{i}"], background=G["background"].tolist(),
+                                   distance_dtype=torch.float16)
+    assert d16.dtype == torch.float16 and np.array_equal(rgba16.cpu().numpy(), G[f"rgba_{i}"])
+    assert np.array_equal(d16.cpu().numpy(), G[f"distance_f64_{i}"].astype(np.float16))
     rgba_only, none = frame_to_dataset(colors[..., :3].contiguous(), alpha)              # RGB frame: image only
     assert none is None and np.array_equal(rgba_only.cpu().numpy()[..., 3], G[f"rgba_{i}"][..., 3])
     with pytest.raises(ValueError):
