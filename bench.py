@@ -10,17 +10,20 @@ libmgs.so, replayed as one HIP graph with the scene resident in HBM.
 
 N > 1 (configs[3]; one process per GPU over RCCL -- started by torch.distributed.run as the driver does, or by
 bench.py itself when it is called as plain `python bench.py --gpus N` without WORLD_SIZE in the environment): a step is one
-pass over the 64-camera novel-view ring theta_k = 2 pi k / 64; rank r renders the contiguous block
-shard_cameras(64, N, r) through its FrameRenderer and rank 0 gathers all 64 finished frames.  The payload `value`
-is measured with is the DATASET frame -- RGBA8 + fp32 ray distance, 8 bytes per pixel = 16.6 MB per frame, the layout
-DatasetWriter stores and the reference's load_images / load_depths read, converted on the device inside the timed
-region (mgs_frame_to_dataset); the same run then times the ring again with the raw fp32 renders (RGB + expected depth
-+ alpha, 20 B per pixel = 41.5 MB per frame) and reports that rate beside it as config.gather_other_payload
-(`--gather-dtype fp32 | u8` picks another payload for `value`, `--one-payload` skips the second leg).  At 8 ranks rank 0
-takes 7/8 of every frame over its seven xGMI links, which bounds the whole job at (rank 0's inbound xGMI rate) /
-(payload per frame) whatever the renderers do: ~21 k frames/s for the dataset frames and 8-9 k for the raw renders if
-RCCL's point-to-point gather sustains ~50 GB/s per link (not measured: no multi-GPU box in this round), ~55 k for
-8-bit RGB alone.
+pass over the 64-camera novel-view ring theta_k = 2 pi k / 64; rank r renders its contiguous block of the ring through
+its FrameRenderer and rank 0 gathers all 64 finished frames.  Rank 0 receives (N - 1) / N of every frame over its seven
+xGMI links, which bounds the whole job at (its inbound rate) / (payload per frame) whatever the renderers do, so
+  * the payload `value` is measured with is the light DATASET frame -- RGBA8 + fp16 ray distance, 6 bytes per pixel =
+    12.4 MB per frame (`--gather-dtype dataset16`; the RGBA image the reference's load_images reads plus the distance map
+    as np.float16), converted on the device inside the timed region (mgs_frame_to_dataset): at an assumed 50 GB/s per
+    link the single root then allows ~32 k frames/s at 8 ranks, above 6 x the one-GPU rate; `dataset` (fp32 distance,
+    8 B per pixel, what DatasetWriter stores: ~24 k), `fp32` (the raw renders, 20 B per pixel: ~9.6 k) and `u8` (8-bit RGB:
+    ~64 k) are the alternates; the same run then times the ring again with the raw fp32 renders and reports that rate
+    beside it (config.gather_other_payload; `--one-payload` skips it); config.root_bound holds the table for the run;
+  * rank 0 renders a smaller block: `--root-weight 0.5` (default) = half a share, 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 cameras
+    at 8 ranks;
+  * config.per_rank carries each rank's HIP-event split of its last timed region (render span, conversions, what its
+    stream still waited for behind its last conversion), so that a scaling run shows where the time went.
 Total work is fixed as N grows: scaling is "strong"; value = frames all ranks rendered / time.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
@@ -29,9 +32,11 @@ torch.cuda.synchronize() on both sides and reduced with MAX over ranks; regions 
 region gives ms_per_step and value.
 
 Rank 0 prints ONE JSON line.  Beside the contract fields it carries
-  roofline      tile-raster forward kernel: algorithmic bytes / HIP-event time vs 8 TB/s
+  roofline      tile-raster forward kernel: algorithmic bytes / HIP-event time vs 8 TB/s (+ roofline_projection, _binning)
   cpu_baseline  the C++/OpenMP port in oracle/gs_cpu.cpp timed on this box's host cores
-  fwd_bwd       the training-step variant (configs[2]): forward + L1 loss + backward
+  fwd_bwd       the training-step variant (configs[2]): forward + L1 loss + backward, in the caller's and in Morton order,
+                with fwd_bwd.roofline for its dominant kernel (the segmented backward raster)
+  stress_4k     configs[4]: 5 M Gaussians at 3840x2160, per stage against its algorithmic bytes, and frames/s
 """
 from __future__ import annotations
 
@@ -276,7 +281,8 @@ def main():
             gather_bufs = [[torch.empty(batch_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
                            for _ in range(2)]
         pending = [None, None]
-        state = {"cur": 0, "fill": 0, "shipped": 0}
+        state = {"cur": 0, "fill": 0, "shipped": 0, "target": 0}
+        sizes_all = shard_sizes(RING, world, weights) if ring else [1]
         tickets = []
 
         def ship():
@@ -340,12 +346,12 @@ def main():
                 retire()
             if do_gather and state["fill"] > 0:            # a partial last batch still travels (whole buffer)
                 ship()
-            if do_gather and world > 1 and len(set(shard_sizes(RING, world, weights))) > 1:
-                # ragged shards (64 cameras over e.g. 3 ranks): ranks with fewer frames issue empty collectives
-                # so that every rank has made the same number of gather calls when the region ends
-                nmax = torch.tensor([state["shipped"]], device=comm_dev, dtype=torch.int64)
-                dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
-                while state["shipped"] < int(nmax.item()):
+            if do_gather and world > 1:
+                # unequal shards (weighted, or 64 cameras over e.g. 3 ranks): ranks with fewer frames issue padding
+                # collectives until every rank has made the same number of gather calls in this region.  The count is
+                # arithmetic every rank does alike -- no collective decides it, so the ranks' sequences of
+                # collectives cannot get out of step (a gather on one rank never meets an all-reduce on another)
+                while state["shipped"] < state["target"]:
                     ship()
             for k in range(2):
                 if pending[k] is not None:
@@ -354,6 +360,8 @@ def main():
 
         def region(k_steps):
             barrier_sync(use_dist)
+            # gather calls every rank will have made when this region ends: the largest shard's batches
+            state["target"] = state["shipped"] + max(math.ceil(sz * k_steps / GB) for sz in sizes_all)
             t0 = time.perf_counter()
             if do_gather:
                 ev.update(start=torch.cuda.Event(enable_timing=True), render_done=None, convert=[], last=None)
@@ -381,6 +389,7 @@ def main():
                 dt = float(tt.item())
             return dt
 
+        state["target"] = max(math.ceil(sz * a.warmup / GB) for sz in sizes_all) if do_gather else 0
         for _ in range(a.warmup):
             step()
         drain()

@@ -229,6 +229,47 @@ int mgs_render_frames(int n, const float *means, const float *quats, const float
                       uint32_t isect_capacity, float *render, float *alphas, uint32_t *n_isect,
                       uint32_t *status, void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
 
+/* -------------------------------------------------------------------------------------
+ * A batch of TRAINING frames (gsplat `rasterization(...)` for C cameras with gradients) behind two calls.
+ * mgs_render_frames_train: per camera mgs_project_color_fwd (all outputs) -> mgs_isect_tiles (seeded; tiles_per_gauss,
+ * tile ids, pair_info, launch order) -> mgs_rasterize_fwd (last_ids, checkpoints every checkpoint_interval entries;
+ * 0 = none), enqueued back to back.  Everything the backward and gsplat's `meta` need stays, per camera, in the caller's
+ * `state`: n_cams blocks of *bytes_per_camera bytes (256-byte aligned) whose fields sit at
+ * mgs_train_state_layout's offsets[MGS_TRAIN_FIELDS], in this order:
+ *   radii[N] i32 | means2d[N,2] | depths[N] | conics[N,3] | opacities x compensation [N] (antialiased only) |
+ *   feats[N,channels] | splats[N,12] | tiles_per_gauss[N] i32 | pair_info[N,4] i32 | tile_ids[cap] u32 |
+ *   flatten_ids[cap] i32 | tile_offsets[n_tiles+1] i32 | tile_group_order[ceil(n_tiles/4)] i32 | last_ids[H,W] i32 |
+ *   checkpoints | {n_isect, status} u32
+ * flags: MGS_RASTER_EXPECTED_LAST, MGS_RASTER_LATENCY, MGS_FRAMES_CLASSIC_BOUNDS.  Workspace (shared by the cameras):
+ * two-phase size query, 256-byte aligned.
+ * mgs_render_frames_backward: per camera mgs_rasterize_bwd_det (segmented when checkpoint_interval != 0) ->
+ * mgs_project_color_bwd; v_means / v_quats / v_scales / v_sh_coeffs / v_opacities are OVERWRITTEN by the first camera
+ * and added to by the others (no zero fill); v_viewmats[C,4,4] (nullable) is accumulated with atomics: zero it first.
+ * v_means2d / v_means2d_abs [C,N,2] (nullable): the screen-space gradients per camera (densification); absgrad is
+ * computed iff v_means2d_abs is given.  v_alphas[C,H,W] nullable.  Same arithmetic, in the same order, as the
+ * per-camera entry points: bit-identical gradients.
+ * ----------------------------------------------------------------------------------- */
+#define MGS_TRAIN_FIELDS 16
+int mgs_train_state_layout(int n, int width, int height, int channels, uint32_t isect_capacity, int antialiased,
+                           int checkpoint_interval, size_t *offsets, size_t *bytes_per_camera);
+int mgs_render_frames_train(int n, const float *means, const float *quats, const float *scales,
+                            const float *opacities, int sh_degree, int coeff_stride, const float *sh_coeffs,
+                            int n_cams, const float *viewmats, const float *Ks, int width, int height,
+                            float eps2d, float near_plane, float far_plane, float radius_clip, int antialiased,
+                            int channels, int flags, const float *backgrounds, uint32_t isect_capacity,
+                            int checkpoint_interval, float *render, float *alphas, void *state, void *workspace,
+                            size_t *workspace_bytes, mgs_stream_t stream);
+int mgs_render_frames_backward(int n, const float *means, const float *quats, const float *scales,
+                               const float *opacities, int sh_degree, int coeff_stride, const float *sh_coeffs,
+                               int n_cams, const float *viewmats, const float *Ks, int width, int height,
+                               float eps2d, int antialiased, int channels, int flags, const float *backgrounds,
+                               uint32_t isect_capacity, int checkpoint_interval, const float *render,
+                               const float *alphas, const float *v_render, const float *v_alphas,
+                               const void *state, float *v_means, float *v_quats, float *v_scales,
+                               float *v_sh_coeffs, float *v_opacities, float *v_viewmats, float *v_means2d,
+                               float *v_means2d_abs, void *workspace, size_t *workspace_bytes,
+                               mgs_stream_t stream);
+
 /* gsplat `isect_offset_encode`: first sorted index per (cam, tile) from sorted int64 keys.
  * n_isect is a HOST value here (the operator takes a materialised key tensor).
  * offsets[n_cams*tile_h*tile_w]. */

@@ -52,6 +52,9 @@ def _load(path: str = None, hooks: bool = False) -> ctypes.CDLL:
         "mgs_isect_tiles": ([i, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
         "mgs_render_frames": ([i, p, p, p, p, i, i, p, i, p, p, i, i, f, f, f, f, i, i, i, p, u32, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_train_state_layout": ([i, i, i, i, u32, i, i, POINTER(c_size_t), POINTER(c_size_t)], c_int),
+        "mgs_render_frames_train": ([i, p, p, p, p, i, i, p, i, p, p, i, i, f, f, f, f, i, i, i, p, u32, i, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_render_frames_backward": ([i, p, p, p, p, i, i, p, i, p, p, i, i, f, i, i, i, p, u32, i, p, p, p, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_rasterize_fwd": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, i, p, p, p, p, i, p], c_int),
         "mgs_raster_checkpoint_floats": ([u32, i, i, i, i], c_size_t),
         "mgs_rasterize_bwd": ([i, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, p, p, p], c_int),
@@ -123,7 +126,7 @@ EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_projection_fwd", "mgs_pr
            "mgs_rasterize_bwd_det", "mgs_composite_over", "mgs_points_project",
            "mgs_points_depth_map", "mgs_points_sample_mask", "mgs_l1_loss_fwd", "mgs_l1_loss_bwd",
            "mgs_transform_gaussians", "mgs_frame_to_u8", "mgs_frame_to_dataset", "mgs_render_frames",
-           "mgs_raster_checkpoint_floats"]
+           "mgs_raster_checkpoint_floats", "mgs_train_state_layout", "mgs_render_frames_train", "mgs_render_frames_backward"]
 
 
 def check(rc: int, what: str) -> None:

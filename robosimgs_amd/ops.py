@@ -193,6 +193,121 @@ def checkpoint_buffer(capacity: int, tile_w: int, tile_h: int, channels: int, in
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
+TRAIN_FIELDS = ("radii", "means2d", "depths", "conics", "opac_aa", "feats", "splats", "tiles_per_gauss", "pair_info",
+                "tile_ids", "flatten_ids", "tile_offsets", "group_order", "last_ids", "checkpoints", "counts")
+
+
+class TrainState:
+    """Per-camera state of a batch of training frames (mgs_render_frames_train writes it, mgs_render_frames_backward
+    reads it): one device buffer, fields at the offsets mgs_train_state_layout reports; `views(c)` hands them out as
+    tensors without copying."""
+
+    def __init__(self, n, n_cams, width, height, channels, capacity, antialiased, interval, device):
+        offs = (ctypes.c_size_t * len(TRAIN_FIELDS))()
+        per = ctypes.c_size_t(0)
+        check(_lib.lib().mgs_train_state_layout(n, width, height, channels, int(capacity), int(bool(antialiased)), int(interval),
+                                                offs, ctypes.byref(per)), "mgs_train_state_layout")
+        self.offsets, self.per_camera = list(offs), per.value
+        self.n, self.n_cams, self.width, self.height, self.channels = n, n_cams, width, height, channels
+        self.capacity, self.antialiased, self.interval = int(capacity), bool(antialiased), int(interval)
+        self.buf = torch.empty(self.per_camera * n_cams + 256, dtype=torch.uint8, device=device)
+        self.pad = (-self.buf.data_ptr()) % 256
+        self.n_tiles = (-(-width // TILE_SIZE)) * (-(-height // TILE_SIZE))
+
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + self.pad
+
+    def views(self, c: int) -> dict:
+        n, cap, nt = self.n, self.capacity, self.n_tiles
+        shapes = {"radii": (torch.int32, (n,)), "means2d": (torch.float32, (n, 2)), "depths": (torch.float32, (n,)),
+                  "conics": (torch.float32, (n, 3)), "opac_aa": (torch.float32, (n,) if self.antialiased else (0,)),
+                  "feats": (torch.float32, (n, self.channels)), "splats": (torch.float32, (n, 12)),
+                  "tiles_per_gauss": (torch.int32, (n,)), "pair_info": (torch.int32, (n, 4)), "tile_ids": (torch.int32, (cap,)),
+                  "flatten_ids": (torch.int32, (cap,)), "tile_offsets": (torch.int32, (nt + 1,)),
+                  "group_order": (torch.int32, ((nt + 3) // 4,)), "last_ids": (torch.int32, (self.height, self.width)),
+                  "counts": (torch.int32, (2,))}
+        out = {}
+        base = self.pad + self.per_camera * c
+        for name, off in zip(TRAIN_FIELDS, self.offsets):
+            if name not in shapes:
+                continue
+            dt, shape = shapes[name]
+            numel = 1
+            for d_ in shape:
+                numel *= d_
+            nbytes = numel * (4)
+            out[name] = self.buf[base + off:base + off + nbytes].view(dt).view(shape)
+        return out
+
+    def tile_lists(self, c: int, v: dict = None) -> "TileLists":
+        v = v or self.views(c)
+        tl = TileLists()
+        tl.capacity = self.capacity
+        tl.n_isect, tl.status = v["counts"][0:1], v["counts"][1:2]
+        tl.tile_ids, tl.flatten_ids, tl.tile_offsets = v["tile_ids"], v["flatten_ids"], v["tile_offsets"]
+        tl.tiles_per_gauss, tl.pair_info, tl.group_order, tl.isect_ids = v["tiles_per_gauss"], v["pair_info"], v["group_order"], None
+        return tl
+
+
+def _aligned_ws(nbytes, dev):
+    ws = _workspace(nbytes + 256, dev)
+    base = ws.data_ptr()
+    aligned = (base + 255) // 256 * 256
+    return aligned, ws.numel() - (aligned - base)
+
+
+def render_frames_train_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d,
+                            near_plane, far_plane, radius_clip, antialiased, with_depth, capacity, interval,
+                            backgrounds=None, expected_last=False, latency=True, tight=True, out=None):
+    """mgs_render_frames_train: C training frames in one C call.  Returns (render [C,H,W,ch], alphas [C,H,W], TrainState)."""
+    dev = means.device
+    C, n = viewmats.shape[0], means.shape[0]
+    ch = 4 if with_depth else 3
+    if out is None:
+        render = torch.empty(C, height, width, ch, dtype=torch.float32, device=dev)
+        alphas = torch.empty(C, height, width, dtype=torch.float32, device=dev)
+    else:
+        render, alphas = out
+    st = TrainState(n, C, width, height, ch, capacity, antialiased, interval, dev)
+    flags = int(bool(expected_last)) | (2 if latency else 0) | (0 if tight else 4)
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t(0)
+    args = [n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), int(sh_degree), sh_coeffs.shape[1], ptr(sh_coeffs), C,
+            ptr(viewmats), ptr(Ks), int(width), int(height), eps2d, near_plane, far_plane, radius_clip, int(bool(antialiased)),
+            ch, flags, ptr(backgrounds), int(capacity), int(interval), ptr(render), ptr(alphas), st.ptr()]
+    check(L.mgs_render_frames_train(*args, None, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames_train(size query)")
+    aligned, room = _aligned_ws(nbytes.value, dev)
+    nbytes = ctypes.c_size_t(room)
+    check(L.mgs_render_frames_train(*args, aligned, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames_train")
+    st.flags = flags
+    return render, alphas, st
+
+
+def render_frames_backward_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, eps2d, backgrounds, st,
+                               render, alphas, v_render, v_alphas, absgrad=False, want_viewmats=False):
+    """mgs_render_frames_backward on a TrainState.  Returns (v_means, v_quats, v_scales, v_sh, v_opacities, v_viewmats|None,
+    v_means2d [C,N,2], v_means2d_abs [C,N,2]|None)."""
+    dev = means.device
+    C, n = viewmats.shape[0], means.shape[0]
+    v_means, v_quats, v_scales = torch.empty_like(means), torch.empty_like(quats), torch.empty_like(scales)
+    v_sh, v_opac = torch.empty_like(sh_coeffs), torch.empty_like(opacities)
+    v_vm = torch.zeros_like(viewmats) if want_viewmats else None
+    v_m2d = torch.empty(C, n, 2, dtype=torch.float32, device=dev)
+    v_abs = torch.empty(C, n, 2, dtype=torch.float32, device=dev) if absgrad else None
+    L = _lib.lib()
+    nbytes = ctypes.c_size_t(0)
+    args = [n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), int(sh_degree), sh_coeffs.shape[1], ptr(sh_coeffs), C,
+            ptr(viewmats), ptr(Ks), st.width, st.height, eps2d, int(st.antialiased), st.channels, st.flags, ptr(backgrounds),
+            st.capacity, st.interval, ptr(render), ptr(alphas), ptr(v_render), ptr(v_alphas), st.ptr(), ptr(v_means),
+            ptr(v_quats), ptr(v_scales), ptr(v_sh), ptr(v_opac), ptr(v_vm), ptr(v_m2d), ptr(v_abs)]
+    check(L.mgs_render_frames_backward(*args, None, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames_backward(size query)")
+    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=dev)
+    aligned = (ws.data_ptr() + 255) // 256 * 256
+    nbytes = ctypes.c_size_t(ws.numel() - (aligned - ws.data_ptr()))
+    check(L.mgs_render_frames_backward(*args, aligned, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames_backward")
+    return v_means, v_quats, v_scales, v_sh, v_opac, v_vm, v_m2d, v_abs
+
+
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                       tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None,
                       expected_last=False, latency=False, group_order=None, channels=None,

@@ -82,6 +82,28 @@ class _RenderSH(torch.autograd.Function):
             meta_out["lean"] = dict(n_isects=n_isects, isect_status=status)
             ctx.set_materialize_grads(False)
             return render, alphas.unsqueeze(-1)
+        if training and isect_capacity is not None:
+            # the whole batch of training cameras behind ONE C call (mgs_render_frames_train): what the backward and the
+            # meta dict need stays per camera in one state buffer; no read-back, so the step captures in a HIP graph
+            _, _, st = ops.render_frames_train_raw(
+                means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, antialiased, with_depth, isect_capacity, segment, backgrounds=backgrounds,
+                expected_last=expected_depth, latency=latency, tight=tight, out=(render, alphas))
+            per_cam = []
+            for c in range(C):
+                v = st.views(c)
+                per_cam.append((v["radii"], v["means2d"], v["depths"], v["conics"], v["opac_aa"] if antialiased else None,
+                                v["feats"], st.tile_lists(c, v), v["splats"], None))
+            ctx.train_state = st
+            ctx.expected_depth = bool(expected_depth)
+            ctx.channels = ch
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds, alphas, None, render)
+            ctx.cfg = (width, height, tile_w, tile_h, sh_degree, eps2d, antialiased, with_depth, absgrad)
+            meta_out["per_cam"] = per_cam
+            ctx.meta_out = meta_out
+            return render, alphas.unsqueeze(-1)
+        ctx.train_state = None
         per_cam = []
         for c in range(C):
             # the projection kernel also seeds the binning (tile rectangle + count per Gaussian)
@@ -138,6 +160,26 @@ class _RenderSH(torch.autograd.Function):
             v_render = torch.zeros(C, height, width, ctx.channels, dtype=torch.float32, device=means.device)
         v_render = _f32c(v_render)
         v_alphas = _f32c(v_alphas).reshape(C, height, width) if v_alphas is not None else None
+        if ctx.train_state is not None:
+            # the batch's backward behind one C call (mgs_render_frames_backward): same kernels, same order
+            v_means, v_quats, v_scales, v_sh, v_opacities, v_viewmats, v_m2d, v_abs = ops.render_frames_backward_raw(
+                means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, eps2d, backgrounds, ctx.train_state,
+                render_out, alphas, v_render, v_alphas, absgrad=absgrad, want_viewmats=ctx.needs_input_grad[5])
+            ctx.meta_out["means2d_grad"] = [v_m2d[c] for c in range(C)]
+            if absgrad:
+                ctx.meta_out["means2d_absgrad"] = [v_abs[c] for c in range(C)]
+            m2d = ctx.meta_out.get("means2d")
+            if m2d is not None and m2d.requires_grad:
+                m2d.grad = v_m2d
+                if absgrad:
+                    m2d.absgrad = v_abs
+            v_bg = None
+            if backgrounds is not None and ctx.needs_input_grad[7]:
+                vr = v_render
+                if ctx.expected_depth:
+                    vr = torch.cat([vr[..., :-1], (vr[..., -1] / alphas.clamp(min=1e-10)).unsqueeze(-1)], dim=-1)
+                v_bg = (vr * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
+            return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 17
         # "RGB+ED": the raster backward's prologue undoes the divide by max(alpha, 1e-10) itself
         # (expected_render=...); only a background gradient needs the converted cotangent here
         # the first camera overwrites the outputs, later ones accumulate: no zero-fill pass

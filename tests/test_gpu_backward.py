@@ -210,6 +210,49 @@ def test_multi_camera_gradients_accumulate():
         torch.testing.assert_close(x, y + z, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode,aa,bg,seg", [("RGB+ED", False, True, 64), ("RGB", True, False, 256), ("RGB+D", False, False, 0)])
+def test_batched_training_cameras_through_one_call_equal_the_per_camera_loop(mode, aa, bg, seg):
+    """rasterization() with gradients and a fixed list capacity sends the whole camera batch through
+    mgs_render_frames_train / mgs_render_frames_backward (two C calls instead of five per camera): frames, every
+    gradient, the per-camera screen-space gradients and the meta arrays are those of the per-camera entry points, bit
+    for bit; camera-pose gradients agree to the order of their atomics."""
+    from robosimgs_amd import rasterization
+    g = synthetic_scene(9000, math.log(0.09), 2, 5)
+    cams = camera_ring(3, 144, 96)
+    vm0 = _t(np.stack([c.viewmat() for c in cams]))
+    Ks = _t(np.stack([c.K for c in cams]))
+    ch = 3 if mode == "RGB" else 4
+    gen = torch.Generator(DEV).manual_seed(8)
+    w_c = torch.randn(3, 96, 144, ch, device=DEV, generator=gen)
+    w_a = torch.randn(3, 96, 144, 1, device=DEV, generator=gen)
+    bgs = torch.rand(3, ch, device=DEV, generator=gen) if bg else None
+    names = ("means", "quats", "scales", "opacities", "colors")
+
+    def run(cap):
+        t = g.to_torch(DEV, 2)
+        p = {k: t[k].detach().clone().requires_grad_(True) for k in names}
+        vm = vm0.clone().requires_grad_(True)
+        c, a, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, Ks, 144, 96,
+                                   sh_degree=2, render_mode=mode, rasterize_mode="antialiased" if aa else "classic",
+                                   backgrounds=bgs, absgrad=True, isect_capacity=cap, backward_segment=seg)
+        meta["means2d"].retain_grad()
+        ((c * w_c).sum() + (a * w_a).sum()).backward()
+        return c.detach(), a.detach(), [p[k].grad for k in names], vm.grad, meta
+
+    c0, a0, g0, v0, m0 = run(None)               # per-camera entry points (the capacity is read back per camera)
+    c1, a1, g1, v1, m1 = run(600_000)            # the batch behind two C calls
+    assert torch.equal(c0, c1) and torch.equal(a0, a1)
+    for k, x, y in zip(names, g0, g1):
+        assert torch.equal(x, y), k
+    torch.testing.assert_close(v0, v1, rtol=1e-4, atol=1e-5)
+    assert torch.equal(m0["means2d"].grad, m1["means2d"].grad) and torch.equal(m0["means2d"].absgrad, m1["means2d"].absgrad)
+    for key in ("radii", "means2d", "depths", "conics", "tiles_per_gauss", "n_isects", "isect_offsets"):
+        assert torch.equal(m0[key], m1[key]), key
+    n_is = [int(x) for x in m1["n_isects"]]
+    assert all(torch.equal(m0["tile_lists"][c].flatten_ids[:n_is[c]], m1["tile_lists"][c].flatten_ids[:n_is[c]]) for c in range(3))
+    assert int(m1["isect_status"].max()) == 0 and len(m1["flatten_ids"]) == sum(n_is)     # gsplat's flat lists still assemble
+
+
 def test_deterministic_backward_matches_atomic_and_is_bit_reproducible():
     """mgs_rasterize_bwd_det (records + per-Gaussian reduce) vs mgs_rasterize_bwd (atomics):
     same sums up to float re-association; two det runs are bit-identical."""
