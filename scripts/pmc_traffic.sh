@@ -12,7 +12,8 @@ for stage in raster_inf raster_inf_q raster_bwd_split project binning; do
   for ctr in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
     tag=$(echo $ctr | cut -d' ' -f1)
     rm -rf $OUT/${stage}_$tag
-    SEG=256 timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${stage}_$tag -o pmc -- python $REPO/scripts/run_stage.py $stage 3 > /dev/null 2>&1
+    # (the backward is measured on the scene in the caller's order, as bench.py's fwd_bwd leg runs it)
+    MORTON=$([ $stage = raster_bwd_split ] && echo 0 || echo 1) SEG=256 timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/${stage}_$tag -o pmc -- python $REPO/scripts/run_stage.py $stage 3 > /dev/null 2>&1
   done
 done
 python - <<PY

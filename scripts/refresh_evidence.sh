@@ -1,17 +1,26 @@
 #!/bin/bash
-# One pass over everything profiles/ quotes, on the GPU box:  gpurun --timeout 2400 -- bash scripts/refresh_evidence.sh
+# One pass over everything profiles/ quotes, on the GPU box:  gpurun --timeout 3000 -- bash scripts/refresh_evidence.sh
 # Results land under gpurun_out/refresh/; copy what is to be judged into profiles/ afterwards.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/refresh
 mkdir -p $OUT
 cd $REPO
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $OUT/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 bash scripts/pmc_traffic.sh > $OUT/pmc_traffic_stdout.txt 2>&1
 cp gpurun_out/pmc_r4/pmc_traffic.json profiles/pmc_traffic.json     # so that the bench lines below carry `traffic`
 cp gpurun_out/pmc_r4/pmc_traffic.json $OUT/pmc_traffic.json
+python scripts/summarize_pmc.py > $OUT/pmc_summary_stdout.txt 2>&1
+cp profiles/r4/06_pmc_counters.md $OUT/06_pmc_counters.md
+python bench.py > $OUT/bench_no_profiler.json 2> $OUT/bench_no_profiler.err
 bash scripts/profile_bench.sh refresh_default
-bash scripts/profile_bench.sh refresh_inflight1 --inflight 1 --no-cpu-baseline
-MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 python bench.py --force-gather --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/ring_world_of_one.json
+bash scripts/profile_bench.sh refresh_inflight1 --inflight 1 --no-cpu-baseline --no-stress
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python bench.py --force-gather --no-cpu-baseline --no-stress --steps 3 --warmup 1 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/ring_world_of_one.json
 cp gpurun_out/refresh_default_* gpurun_out/refresh_inflight1_* $OUT/ 2>/dev/null
-cat $OUT/pytest_gpu.txt; tail -3 $OUT/smoke.txt
+# per-unit timelines of the backward raster (instrumented build), then the shipped build again
+MGS_RASTER_BWD_FLAGS="-DMGS_RASTER_BWD_TIMING" python robosimgs_amd/csrc/build.py > /dev/null 2>&1
+for s in 0 256; do MGS_RASTER_BWD_FLAGS="-DMGS_RASTER_BWD_TIMING" SEG=$s timeout 300 python scripts/dbg/bwd_timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/bwd_timeline_$s.txt; done
+python robosimgs_amd/csrc/build.py > /dev/null 2>&1
+SEGS=128,256 timeout 300 python scripts/raster_bwd_split_ab.py 2>&1 | grep segment > $OUT/bwd_split_ab.txt
+timeout 600 python scripts/ab_builds.py raster_fwd.hip "-DMGS_RASTER_CLOSE_BRANCH=1" 2>&1 | grep -v amdgpu.ids | tail -3 > $OUT/ab_close_branch.txt
+cat $OUT/pytest_gpu.txt; tail -3 $OUT/smoke.txt; cat $OUT/bwd_split_ab.txt
