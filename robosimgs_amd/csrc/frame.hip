@@ -289,7 +289,8 @@ extern "C" int mgs_render_frames_backward(int n, const float* means, const float
     float* g_abs = v_means2d_abs ? v_means2d_abs + 2 * (size_t)n * c : nullptr;
     float* g_con = reinterpret_cast<float*>(w + ws.v_conics);
     float* g_feat = reinterpret_cast<float*>(w + ws.v_feats);
-    float* g_opac = reinterpret_cast<float*>(w + ws.v_opac);
+    // (not anti-aliased: the blend's opacity gradient IS the parameter's -- the first camera's reduce writes it in place)
+    float* g_opac = (!antialiased && c == 0) ? v_opacities : reinterpret_cast<float*>(w + ws.v_opac);
     const float* frame = render + n_px * channels * c;
     const bool ed = (flags & MGS_RASTER_EXPECTED_LAST) != 0;
     size_t rw = raster_ws;
@@ -308,10 +309,8 @@ extern "C" int mgs_render_frames_backward(int n, const float* means, const float
                                antialiased ? v_opacities : nullptr, v_viewmats ? v_viewmats + 16 * (size_t)c : nullptr,
                                c > 0 ? 1 : 0, stream);
     if (rc) return rc;
-    if (!antialiased && n > 0) {     // the blend's opacity gradient IS the parameter's: first camera stores, later ones add
-      hipLaunchKernelGGL(add_rows_kernel, dim3(mgs::div_up((unsigned)n, 256u)), dim3(256), 0, hs, (size_t)n, g_opac, v_opacities,
-                         c == 0 ? 1 : 0);
-    }
+    if (!antialiased && n > 0 && c > 0)     // later cameras add theirs
+      hipLaunchKernelGGL(add_rows_kernel, dim3(mgs::div_up((unsigned)n, 256u)), dim3(256), 0, hs, (size_t)n, g_opac, v_opacities, 0);
   }
   return mgs::check_launch("render_frames_backward");
 }
