@@ -179,6 +179,9 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 #ifndef MGS_RASTER_BWD_PIPE
 #define MGS_RASTER_BWD_PIPE 0
 #endif
+#ifndef MGS_RASTER_BWD_XCD_RUN
+#define MGS_RASTER_BWD_XCD_RUN 4       // segmented launch: consecutive units per XCD (see raster_bwd_kernel); 1 = plain numbering.  FETCH_SIZE 422 / 387 / 360 / 344 MiB for 1 / 2 / 4 / 8, same time
+#endif
 #ifndef MGS_RASTER_BWD_ORDER
 #define MGS_RASTER_BWD_ORDER 1         // launch the tiles by falling list length (tile_order_kernel): 623 -> 572 us
 #endif
@@ -692,7 +695,16 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
 #define MGS_RB_ARGS means2d, conics, feats, opacities, splats, background, channels, width, height, tile_w, n_tiles, \
     tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_feats,    \
     v_opacities, pair_info, records, flags, capacity, expected_render, tile_order, ckpt, ckpt_shift, seg_table, render_out
-  raster_bwd_unit<CHT, ABSGRAD, RECORDS, HALF, SPLIT>(blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6), MGS_RB_ARGS);
+  int unit = blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6);
+  if constexpr (SPLIT && MGS_RASTER_BWD_XCD_RUN > 1 && MGS_RASTER_BWD_WG_WAVES == 1) {
+    // a tile's whole segments are neighbours in the unit table and re-read the same 10 KB of frame state; workgroup b
+    // runs on XCD b % 8 (observed placement, speed only), so runs of R consecutive units go to one XCD's L2:
+    // blocks of 8 R workgroups, unit = block + (b % 8) R + (b / 8) % R -- the launch order is kept to within a block
+    constexpr int R = MGS_RASTER_BWD_XCD_RUN;
+    const int b = unit, in = b % (8 * R);
+    unit = b - in + (in & 7) * R + (in >> 3);
+  }
+  raster_bwd_unit<CHT, ABSGRAD, RECORDS, HALF, SPLIT>(unit, MGS_RB_ARGS);
 #undef MGS_RB_ARGS
 }
 
@@ -993,7 +1005,9 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
       order = mine;
     }
   }
-  const int n_units = split ? (int)n_seg_units : order ? (n_tiles + 3) / 4 * 4 : n_tiles * (int)kSlots;
+  // (segmented: whole blocks of the XCD-aware unit numbering; units past the live count leave at once)
+  const int n_units = split ? (int)((n_seg_units + 8 * MGS_RASTER_BWD_XCD_RUN - 1) / (8 * MGS_RASTER_BWD_XCD_RUN)) * 8 * MGS_RASTER_BWD_XCD_RUN
+                            : order ? (n_tiles + 3) / 4 * 4 : n_tiles * (int)kSlots;
 #define MGS_RD_RASTER(C, A, SP)                                                                 \
   hipLaunchKernelGGL((raster_bwd_kernel<C, A, true, kHalf, SP>), dim3(div_up(n_units, MGS_RASTER_BWD_WG_WAVES)), dim3(64 * MGS_RASTER_BWD_WG_WAVES), MGS_RASTER_BWD_LDS_PAD, s, means2d,   \
                      conics, feats, opacities, reinterpret_cast<const float4*>(splats),        \

@@ -55,6 +55,32 @@ def test_config2_matches_cpu_port_and_survey_counts(config2):
     assert float(al.min()) >= 0.0 and float(al.max()) < 1.0
 
 
+def test_config2_headline_path_frame_renderer_in_morton_order_matches_fp64_port(config2):
+    """The path bench.py's `value` is measured on: FrameRenderer with three frames in flight, its resident copy of the
+    scene in Morton order, the per-tile raster schedule, "RGB+ED", lean frames through mgs_render_frames -- every frame of
+    a five-camera sweep (the bench camera and four ring cameras) against the fp64 port on the scene in the CALLER's order,
+    zero unexplained pixels and the flip bound.  (Depth ties resolve by the copy's indices: they are could-flip pixels of
+    the depth-order margin.)"""
+    from robosimgs_amd import FrameRenderer
+    g, cam, t = config2
+    W, H = 1920, 1080
+    cams = [cam] + list(camera_ring(4, W, H, thetas=[1.1, 2.6, 4.0, 5.5]))
+    fr = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=3, sizing_camera=(cam.viewmat(), cam.K),
+                       capacity_margin=1.6)
+    assert fr.order is not None and fr.kw["raster_schedule"] == "throughput" and fr.kw["lean_meta"]
+    frames = {}
+    fr.render_sequence(cams, lambda i, f: frames.__setitem__(i, (f["colors"].cpu().numpy(), f["alphas"].cpu().numpy())))
+    for i, c in enumerate(cams):
+        ref, ra, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, c.viewmat(), c.K, W, H, 3,
+                                           with_depth=True, flip_eps=O.EPS_PATH)
+        ref = ref.astype(np.float64)
+        ref[..., 3] /= np.maximum(ra, 1e-10)                  # the port returns the depth sum ("D")
+        st = O.check_frame(frames[i][0], frames[i][1], ref, ra, info["margins"], O.EPS_PATH, info["edge_mask"],
+                           expected_depth=True, what=f"FrameRenderer camera {i}", flip_weight=info["flip_weight"],
+                           feat_max=info["feat_max"], require_flip_bound=True)
+        print(f"\nFrameRenderer (Morton copy, 3 in flight) camera {i}: {st}")
+
+
 def test_config2_tile_lists_sorted_and_complete(config2):
     from robosimgs_amd import ops
     g, cam, t = config2
