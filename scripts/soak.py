@@ -32,7 +32,8 @@ for seed in range(40):
     outs=[]
     for b in ("classic","tight"):
         p={k:t[k].clone().requires_grad_(True) for k in ("means","quats","scales","opacities","colors")}
-        c,a,meta=rasterization(p["means"],p["quats"],p["scales"],p["opacities"],p["colors"],vm,K,W,H,sh_degree=deg,render_mode="RGB+ED",tile_bounds=b)
+        # (backward_segment=0: bit identity of the gradients is a property of the whole-list walk; the segmented walk is soaked in soak_backward.py)
+        c,a,meta=rasterization(p["means"],p["quats"],p["scales"],p["opacities"],p["colors"],vm,K,W,H,sh_degree=deg,render_mode="RGB+ED",tile_bounds=b,backward_segment=0)
         (c.sum()+a.sum()).backward()
         outs.append((c.detach(),a.detach(),[v.grad for v in p.values()],int(meta["n_isects"][0])))
     same=torch.equal(outs[0][0],outs[1][0]) and torch.equal(outs[0][1],outs[1][1]) and all(torch.equal(x,y) for x,y in zip(outs[0][2],outs[1][2]))
