@@ -639,7 +639,7 @@ def main():
             result["fwd_bwd"] = {"error": repr(e)[:200]}
 
         # ---- configs[4]: 5 M Gaussians at 3840x2160 (HBM-pressure / tile-overflow stress), per stage ----------
-        if not a.no_stress:
+        if not a.no_stress and not ring:          # (N = 1 only: in a multi-GPU run the other ranks would wait for it)
             try:
                 del radii, m2d, depths, con, feats, splats, tl, tl_b, out, seed
                 torch.cuda.empty_cache()
