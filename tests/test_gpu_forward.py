@@ -50,7 +50,10 @@ def test_single_hip_runtime_loaded(ops):
     with open("/proc/self/maps") as f:
         libs = {line.split()[-1] for line in f if "libamdhip64" in line}
     assert len(libs) == 1, f"two HIP runtimes mapped: {libs}"
-    assert any("libmgs.so" in line for line in open("/proc/self/maps"))
+    # (MGS_USE_DEBUG_LIB=1 runs the suite on libmgs_debug.so: the knob sweeps of profiles/)
+    import os
+    want = "libmgs_debug.so" if os.environ.get("MGS_USE_DEBUG_LIB") else "libmgs.so"
+    assert any(want in line for line in open("/proc/self/maps"))
 
 
 @pytest.mark.parametrize("n,mu,w,h,theta", [(10_000, 0.05, 256, 256, 0.3),
