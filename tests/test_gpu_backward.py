@@ -535,6 +535,19 @@ def test_deterministic_backward_with_overflowed_lists_stays_inside_its_workspace
                                         last, v_r, v_a, splats=splats, canary_bytes=1 << 20)
         torch.cuda.synchronize()
         assert bool((out[5] == 0xA5).all()), f"capacity {cap}: the backward wrote past its workspace"
+        # the segmented walk on the same cut lists: checkpoints and unit tables are sized by the capacity too
+        n_ck = ops.checkpoint_buffer(cap, tw, th, 3, 64, DEV).numel()
+        ck = torch.full((n_ck + 65536,), 1234.5, device=DEV)
+        render, alphas, last = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, 160, 128, tw, th,
+                                                     tl.tile_offsets, tl.flatten_ids, splats=splats, latency=True,
+                                                     checkpoints=ck[:n_ck], checkpoint_interval=64)
+        out = ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, 160, 128, tw, th, tl, alphas,
+                                        last, v_r, v_a, splats=splats, canary_bytes=1 << 20, render_out=render,
+                                        checkpoints=ck[:n_ck], checkpoint_interval=64)
+        torch.cuda.synchronize()
+        assert bool((ck[n_ck:] == 1234.5).all()), f"capacity {cap}: the forward wrote past its checkpoint buffer"
+        assert bool((out[5] == 0xA5).all()), f"capacity {cap}: the segmented backward wrote past its workspace"
+        assert all(bool(torch.isfinite(x).all()) for x in out[:4])
 
 
 @pytest.mark.parametrize("mode", ["RGB", "RGB+ED"])
