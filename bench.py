@@ -20,8 +20,8 @@ xGMI links, which bounds the whole job at (its inbound rate) / (payload per fram
     8 B per pixel, what DatasetWriter stores: ~24 k), `fp32` (the raw renders, 20 B per pixel: ~9.6 k) and `u8` (8-bit RGB:
     ~64 k) are the alternates; the same run then times the ring again with the raw fp32 renders and reports that rate
     beside it (config.gather_other_payload; `--one-payload` skips it); config.root_bound holds the table for the run;
-  * rank 0 renders a smaller block: `--root-weight 0.5` (default) = half a share, 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 cameras
-    at 8 ranks;
+  * rank 0 renders a smaller block the more ranks send to it: `--root-weight` defaults to max(0.5, 1 - 0.07 (N - 1)), i.e.
+    31 + 33 cameras at 2 ranks, 13 + 17 + 17 + 17 at 4, 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 at 8;
   * config.per_rank carries each rank's HIP-event split of its last timed region (render span, conversions, what its
     stream still waited for behind its last conversion), so that a scaling run shows where the time went.
 Total work is fixed as N grows: scaling is "strong"; value = frames all ranks rendered / time.
@@ -106,8 +106,10 @@ def parse():
     # frame (332 MB per rank and pass at 8 ranks); "u8" = 8-bit RGB only (6.2 MB per frame).
     ap.add_argument("--gather-dtype", choices=("dataset16", "dataset", "fp32", "u8"), default="dataset16")
     # the rank that receives every frame (and converts its own) renders a smaller block of the ring: its share in units
-    # of the other ranks' (1 = equal blocks).  At 8 ranks 0.5 gives 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 cameras.
-    ap.add_argument("--root-weight", type=float, default=0.5)
+    # of the other ranks' (1 = equal blocks).
+    # Default: max(0.5, 1 - 0.07 (N - 1)) = 0.93 / 0.79 / 0.51 at 2 / 4 / 8 ranks (31 + 33; 13 + 17 + 17 + 17; 4 + 9 + 9 + 9 + 9 + 8 + 8
+    # + 8 cameras): the more ranks send to it, the smaller its block -- the other ranks' largest block then sets the pass.
+    ap.add_argument("--root-weight", type=float, default=None)
     ap.add_argument("--gather-batch", type=int, default=4, help="frames per collective (N > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
@@ -198,6 +200,8 @@ def main():
     t = scene.to_torch(dev, deg)
     tile_w, tile_h = -(-W // 16), -(-H // 16)
     # cameras: the single theta = 0.3 view of configs[1], or this rank's block of the 64-camera ring
+    if a.root_weight is None:
+        a.root_weight = max(0.5, 1.0 - 0.07 * (world - 1))
     weights = root_weights(world, a.root_weight) if (ring and world > 1) else None
     if ring:
         mine = shard_cameras(RING, world, rank, weights)

@@ -24,13 +24,14 @@ def test_plain_python_bench_gpus_2_launches_its_ranks_and_prints_one_json_line()
     assert len(lines) == 1, r.stdout[-2000:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["world_size"] == 2
-    # rank 0 also receives and converts: half a share by default (--root-weight 0.5): 64 * 0.5 / 1.5 = 21.3 -> 21 + 43
+    # rank 0 also receives the other rank's frames: a slightly smaller block by default (weight 1 - 0.07 (N - 1) = 0.93:
+    # 64 * 0.93 / 1.93 = 30.8 -> 31 + 33)
     cfg = res["config"]
-    assert cfg["frames_per_rank"] == [21, 43] and cfg["root_weight"] == 0.5
+    assert cfg["frames_per_rank"] == [31, 33] and abs(cfg["root_weight"] - 0.93) < 1e-9
     # where each rank's time went (HIP events), for both payloads of the run, and the single-root ceiling by payload
     for mode in ("dataset16", "fp32"):
         rows = cfg["per_rank"][mode]
-        assert len(rows) == 2 and [r_["frames"] for r_ in rows] == [21 * 2, 43 * 2]
+        assert len(rows) == 2 and [r_["frames"] for r_ in rows] == [31 * 2, 33 * 2]
         for r_ in rows:
             assert set(r_) == {"frames", "render_span_ms", "convert_ms", "after_last_convert_ms", "region_ms"}
             assert 0 < r_["render_span_ms"] <= r_["region_ms"] and r_["convert_ms"] > 0 and r_["after_last_convert_ms"] >= 0
