@@ -231,6 +231,15 @@ class FrameRenderer:
         s["released"].record(torch.cuda.current_stream(self.dev))
         s["state"] = "free"
 
+    def to_caller_order(self, x: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        """A per-Gaussian array of a frame's meta (radii, means2d, depths ... with lean_meta=False; the renderer's own
+        index order along `dim`) in the order of the tensors the renderer was built from.  Identity when reorder=None."""
+        if self.order is None:
+            return x
+        out = torch.empty_like(x)
+        out.index_copy_(dim, self.order.to(x.device), x)
+        return out
+
     def render(self, viewmat, K) -> Dict:
         """Synchronous convenience: one frame, returned as copies (the slot is released)."""
         t = self.submit(viewmat, K)

@@ -220,3 +220,22 @@ def test_batched_frames_ragged_sizes_empty_scene_and_everything_culled():
         c2, a2, m2 = rasterization(e["means"], e["quats"], e["scales"], e["opacities"], e["colors"], vm[:1], Ks[:1], 333, 207,
                                    sh_degree=1, render_mode="RGB", isect_capacity=1000, lean_meta=True)
     assert c2.shape == (1, 207, 333, 3) and float(c2.abs().max()) == 0.0 and int(m2["n_isects"][0]) == 0
+
+
+def test_frame_renderer_meta_maps_back_to_the_callers_order():
+    """reorder="morton" (the default) renders from the renderer's own Z-curve copy: per-Gaussian meta arrays of a
+    lean_meta=False frame come in ITS order; to_caller_order() puts them in the order of the tensors it was given."""
+    from robosimgs_amd import FrameRenderer, rasterization
+    g = synthetic_scene(20_000, math.log(0.05), 1, 3)
+    cam = camera_ring(1, 240, 160, thetas=[0.8])[0]
+    t = g.to_torch(DEV, 1)
+    fr = FrameRenderer(t, 240, 160, render_mode="RGB", frames_in_flight=1, isect_capacity=600_000, lean_meta=False)
+    assert fr.order is not None
+    f = fr.render(cam.viewmat(), cam.K)
+    with torch.no_grad():
+        _, _, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], _t(cam.viewmat())[None],
+                                   _t(cam.K)[None], 240, 160, sh_degree=1, isect_capacity=600_000)
+    for key in ("radii", "means2d", "depths", "conics"):
+        got = fr.to_caller_order(f["meta"][key][0])
+        assert torch.equal(got, meta[key][0]), key
+    assert not torch.equal(f["meta"]["radii"][0], meta["radii"][0])          # (it really was another order)
