@@ -95,3 +95,34 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.MgsError, match="no CPU or PyTorch fallback"):
         _lib.lib()
+
+
+def test_host_side_size_queries_need_no_gpu():
+    """mgs_raster_checkpoint_floats and mgs_train_state_layout are host arithmetic: the checkpoint buffer holds a 4-int
+    header per tile plus (capacity / S + tiles + 1) units of (1 + channels) x 256 floats; the training state's fields are
+    256-byte aligned, in the order include/mgs.h lists them, and large enough for what they hold."""
+    import ctypes
+    from robosimgs_amd import _lib, ops
+    L = _lib.lib()
+    tw, th, cap, ch, S = 120, 68, 4_640_000, 4, 256
+    n = L.mgs_raster_checkpoint_floats(cap, tw, th, ch, S)
+    header = (tw * th * 4 + 255) // 256 * 256
+    assert n == header + (cap // S + tw * th + 1) * (1 + ch) * 256
+    assert L.mgs_raster_checkpoint_floats(cap, tw, th, ch, 100) == 0 and L.mgs_raster_checkpoint_floats(cap, tw, th, ch, 32) == 0
+    offs = (ctypes.c_size_t * len(ops.TRAIN_FIELDS))()
+    per = ctypes.c_size_t(0)
+    N, W, H = 1_000_000, 1920, 1080
+    assert L.mgs_train_state_layout(N, W, H, ch, cap, 0, S, offs, ctypes.byref(per)) == 0
+    o = dict(zip(ops.TRAIN_FIELDS, offs))
+    assert list(offs) == sorted(offs) and all(x % 256 == 0 for x in offs) and per.value % 256 == 0
+    need = {"radii": 4 * N, "means2d": 8 * N, "depths": 4 * N, "conics": 12 * N, "opac_aa": 0, "feats": 4 * ch * N,
+            "splats": 48 * N, "tiles_per_gauss": 4 * N, "pair_info": 16 * N, "tile_ids": 4 * cap, "flatten_ids": 4 * cap,
+            "tile_offsets": 4 * (tw * th + 1), "group_order": 4 * ((tw * th + 3) // 4), "last_ids": 4 * W * H,
+            "checkpoints": 4 * n, "counts": 8}
+    names = list(ops.TRAIN_FIELDS)
+    for a, b in zip(names, names[1:] + [None]):
+        end = o[b] if b else per.value
+        assert end - o[a] >= need[a], a
+    assert per.value < 1.02 * sum(need.values()) + 16 * 256
+    assert L.mgs_train_state_layout(N, W, H, 5, cap, 0, S, offs, ctypes.byref(per)) == -1       # 3 or 4 channels
+    assert L.mgs_train_state_layout(N, W, H, ch, cap, 0, 100, offs, ctypes.byref(per)) == -1    # not a power of two
