@@ -38,9 +38,12 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
     if name == "l1_loss":
         from . import losses
         return losses.l1_loss
-    if name == "FrameRenderer":
+    if name in ("FrameRenderer", "locality_order"):
         from . import pipeline
-        return pipeline.FrameRenderer
+        return getattr(pipeline, name)
+    if name == "reorder_parameters":
+        from . import training
+        return training.reorder_parameters
     if name in ("render_sharded", "gather_frames", "shard_cameras"):
         from . import distributed
         return getattr(distributed, name)

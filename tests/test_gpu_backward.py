@@ -574,3 +574,39 @@ def test_unused_outputs_need_no_zero_cotangent(mode):
                        (lambda c, a: (a * w_a).sum(), lambda c, a: (a * w_a).sum() + (c * 0.0).sum())):
         for x, y in zip(grads(only), grads(both)):
             assert torch.equal(x, y)
+
+
+def test_reordering_a_trainers_parameters_changes_nothing_but_memory_order():
+    """robosimgs_amd.reorder_parameters: parameters AND Adam's moments go into Morton order of the means, in place (the
+    optimiser keeps its tensors); the next optimiser steps are those of the un-reordered run, row for row."""
+    from robosimgs_amd import l1_loss, rasterization, reorder_parameters
+    g = synthetic_scene(8000, math.log(0.08), 2, 12)
+    cam = camera_ring(1, 160, 112, thetas=[0.5])[0]
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    names = ("means", "quats", "scales", "opacities", "colors")
+    target = torch.rand(1, 112, 160, 3, device=DEV, generator=torch.Generator(DEV).manual_seed(2))
+
+    def make():
+        t = g.to_torch(DEV, 2)
+        p = {k: t[k].detach().clone().requires_grad_(True) for k in names}
+        return p, torch.optim.Adam(list(p.values()), lr=1e-3)
+
+    def step(p, opt):
+        opt.zero_grad(set_to_none=True)
+        c, a, _ = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, K, 160, 112, sh_degree=2)
+        l1_loss(c, target).backward()
+        opt.step()
+
+    pa, oa = make()
+    pb, ob = make()
+    for _ in range(2):
+        step(pa, oa); step(pb, ob)
+    ids = {k: pb[k].data_ptr() for k in names}
+    order = reorder_parameters(pb, ob)
+    assert sorted(order.tolist()) == list(range(8000)) and not torch.equal(order, torch.arange(8000, device=DEV))
+    assert all(pb[k].data_ptr() == ids[k] for k in names)                     # in place
+    assert torch.equal(pb["means"], pa["means"][order])
+    for _ in range(2):
+        step(pa, oa); step(pb, ob)
+    for k in names:       # same trajectory up to the summation order of a Gaussian's pixels (depth ties, float re-association)
+        torch.testing.assert_close(pb[k], pa[k][order], rtol=2e-4, atol=2e-6)
