@@ -251,7 +251,13 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
 // 256 x 8 3,561 (the radix partition: 3,585).
 constexpr int kDirectThreads = MGS_DIRECT_THREADS;
 #ifndef MGS_DIRECT_PER_THREAD
-#define MGS_DIRECT_PER_THREAD 8
+// Round 4: 4 (was 8).  At 1 M Gaussians 512 x 8 is 245 workgroups -- fewer than CUs, two waves per SIMD -- and on a
+// Morton-ordered scene their shares of the pairs differ by 2.7 x (15 k on average, 40 k at most: near Gaussians are
+// neighbours in memory AND cover many tiles).  490 workgroups: scatter 29.5 -> 21.7 us, histogram 14.4 -> 11.5, the
+// column scan (twice the rows) 6.9 -> 12 before it got 64 row groups per workgroup; stage 88.7 -> 73.6 us, three frames
+// in flight 4,503 -> 4,561 frames/s.  With the scene in random order the shares are even and the extra rows cost the
+// scatter 4 us (fragmented stores): 90 -> 100 us alone before the column-scan change, the same frames/s.
+#define MGS_DIRECT_PER_THREAD 4
 #endif
 constexpr int kDirectPerThread = MGS_DIRECT_PER_THREAD;   // Gaussians per thread of those kernels
 constexpr int kDirectMaxBlocks = 1024;         // table rows (beyond threads x per-thread x this many Gaussians: longer runs per workgroup)
@@ -293,15 +299,21 @@ __global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
   for (int i = threadIdx.x; i < n_tiles; i += kDirectThreads) hist[i] = 0u;
   __syncthreads();
   const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
-  for (int base = g0; base < g1; base += kDirectThreads) {
-    const int g = base + (int)threadIdx.x;
-    uint32_t pack = kEmptyTileRect, cnt = 0;
-    if (g < g1) {
-      const uint2 info = ginfo[g];
-      pack = info.x; cnt = info.y;
-      if (tiles_per_gauss) tiles_per_gauss[g] = (int32_t)cnt;
+  // the workgroup's rectangles are fetched kDirectPerThread at a time, all loads in flight together: at 1 M Gaussians
+  // the launch is 245 workgroups -- two waves per SIMD -- and a load per trip was one exposed round trip per trip
+  for (int base = g0; base < g1; base += kDirectThreads * kDirectPerThread) {
+    uint2 info[kDirectPerThread];
+#pragma unroll
+    for (int i = 0; i < kDirectPerThread; ++i) {
+      const int g = base + i * kDirectThreads + (int)threadIdx.x;
+      info[i] = g < g1 ? ginfo[g] : make_uint2(kEmptyTileRect, 0u);
     }
-    for_each_tile(pack, cnt, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile >> shift], 1u); });
+#pragma unroll
+    for (int i = 0; i < kDirectPerThread; ++i) {
+      const int g = base + i * kDirectThreads + (int)threadIdx.x;
+      if (g < g1 && tiles_per_gauss) tiles_per_gauss[g] = (int32_t)info[i].y;
+      for_each_tile(info[i].x, info[i].y, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile >> shift], 1u); });
+    }
   }
   __syncthreads();
   uint32_t* row = table + (size_t)blockIdx.x * n_tiles;
@@ -310,13 +322,21 @@ __global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
 
 // 256 threads: 16 bins (64 bytes of a row) x 16 row groups; two passes over the group's rows (sum, then rewrite as
 // the exclusive prefix), 16 loads in flight per thread
-constexpr int kColThreads = 256;
+#ifndef MGS_COLSCAN_BINS
+// 256 threads: kColBins bins (4 bytes each, consecutive in a table row) x 256 / kColBins row groups; two passes over the
+// group's rows (sum, then rewrite as the exclusive prefix), 16 loads in flight per thread.  Re-measured in round 4 at
+// the 490 table rows of 1 M Gaussians (same process, builds taking turns; seeded binning stage): 16 bins x 16 groups
+// 73.8 us, 8 x 32 82.6, 4 x 64 85.5; 16 x 32 with 512 threads 2 us faster alone but 4,170 against 4,504 frames/s with
+// three frames in flight (a 512-thread workgroup waits for room between other frames' raster waves).
+#define MGS_COLSCAN_BINS 16
+#endif
+constexpr int kColThreads = 256, kColBins = MGS_COLSCAN_BINS, kColGroups = kColThreads / kColBins;
 __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
     int nb, int n_tiles, uint32_t* __restrict__ table, uint32_t* __restrict__ tile_count) {
-  __shared__ uint32_t part[16][16];
-  const int bl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int t = blockIdx.x * 16 + bl;
-  const int rpg = (nb + 15) / 16;
+  __shared__ uint32_t part[kColGroups][kColBins];
+  const int bl = threadIdx.x % kColBins, rg = threadIdx.x / kColBins;
+  const int t = blockIdx.x * kColBins + bl;
+  const int rpg = (nb + kColGroups - 1) / kColGroups;
   const int r0 = rg * rpg, r1 = min(nb, r0 + rpg);
   const bool ok = t < n_tiles;
   uint32_t sum = 0;
@@ -330,8 +350,8 @@ __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
   part[rg][bl] = sum;
   __syncthreads();
   uint32_t off = 0, tot = 0;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
+#pragma unroll 16
+  for (int g = 0; g < kColGroups; ++g) {
     const uint32_t s = part[g][bl];
     if (g < rg) off += s;
     tot += s;
@@ -405,18 +425,22 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
   }
   __syncthreads();
   const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
-  for (int base = g0; base < g1; base += kDirectThreads) {
-    const int g = base + (int)threadIdx.x;
-    uint32_t pack = kEmptyTileRect, cnt = 0;
-    if (g < g1) {
-      const uint2 info = ginfo[g];
-      pack = info.x; cnt = info.y;
+  for (int base = g0; base < g1; base += kDirectThreads * kDirectPerThread) {      // (loads in flight together: direct_hist_kernel)
+    uint2 info[kDirectPerThread];
+#pragma unroll
+    for (int i = 0; i < kDirectPerThread; ++i) {
+      const int g = base + i * kDirectThreads + (int)threadIdx.x;
+      info[i] = g < g1 ? ginfo[g] : make_uint2(kEmptyTileRect, 0u);
     }
-    for_each_tile(pack, cnt, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t gs) {
-      const uint32_t p = atomicAdd(&cursor[tile >> shift], 1u);
-      // grouped: the entry carries its tile's place in the group above the id (ids < 2^(32 - shift))
-      if (p < capacity) flatten_ids[p] = shift ? gs | ((tile & local_mask) << (32 - shift)) : gs;
-    });
+#pragma unroll
+    for (int i = 0; i < kDirectPerThread; ++i) {
+      const int g = base + i * kDirectThreads + (int)threadIdx.x;
+      for_each_tile(info[i].x, info[i].y, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t gs) {
+        const uint32_t p = atomicAdd(&cursor[tile >> shift], 1u);
+        // grouped: the entry carries its tile's place in the group above the id (ids < 2^(32 - shift))
+        if (p < capacity) flatten_ids[p] = shift ? gs | ((tile & local_mask) << (32 - shift)) : gs;
+      });
+    }
   }
 }
 
@@ -619,7 +643,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
       const size_t lds = (size_t)bins * sizeof(uint32_t);
       hipLaunchKernelGGL(direct_hist_kernel, dim3(nb), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
                          n_tiles, gshift, u32(ws.table), tiles_per_gauss);
-      hipLaunchKernelGGL(direct_colscan_kernel, dim3(div_up((unsigned)bins, 16)), dim3(kColThreads), 0, s,
+      hipLaunchKernelGGL(direct_colscan_kernel, dim3(div_up((unsigned)bins, (unsigned)kColBins)), dim3(kColThreads), 0, s,
                          (int)nb, bins, u32(ws.table), u32(ws.tile_count));
       const bool order_in_scatter = tile_group_order && gshift == 2;
       order_done = order_in_scatter;

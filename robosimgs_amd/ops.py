@@ -116,7 +116,7 @@ def _workspace(nbytes: int, device) -> Tensor:
 def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_id=0, n_cams=1,
                     want_isect_ids=False, want_tiles_per_gauss=True,
                     want_pair_info=False, conics=None, opacities=None, seed=None,
-                    want_tile_ids=True) -> TileLists:
+                    want_tile_ids=True, want_group_order=True) -> TileLists:
     """conics + opacities given: tile rectangles tightened to the tiles a Gaussian can reach with
     alpha >= 1/255 (shorter lists, bit-identical render); None: gsplat's classic rectangles.
     seed = (seed_info, seed_sums) from project_color_fwd_raw(bin_seed=...): the rectangles come from
@@ -136,7 +136,7 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     out.isect_ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_isect_ids else None
     out.pair_info = torch.empty(n, 4, dtype=torch.int32, device=dev) if want_pair_info else None
     # launch order of the raster kernels' tiles (groups of four, longest lists first): a schedule, not a result
-    out.group_order = torch.empty((tile_w * tile_h + 3) // 4, dtype=torch.int32, device=dev)
+    out.group_order = (torch.empty((tile_w * tile_h + 3) // 4, dtype=torch.int32, device=dev) if want_group_order else None)
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), TILE_SIZE,
             tile_w, tile_h, cam_id, n_cams,

@@ -25,7 +25,7 @@ for rep in range(4):
     torch.cuda.synchronize()
     e0.record()
     for sd in fresh:
-        ops.isect_tiles_raw(None, None, dep, tw, th, CAP, want_tiles_per_gauss=False, seed=sd, want_tile_ids=False)
+        ops.isect_tiles_raw(None, None, dep, tw, th, CAP, want_tiles_per_gauss=False, seed=sd, want_tile_ids=False, want_group_order=os.environ.get('NO_ORDER') is None)
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 20)
 print(f"{os.environ.get('TAG', '')}: seeded binning stage {best * 1e3:.1f} us", flush=True)
