@@ -457,6 +457,12 @@ int mgs_l1_loss_fwd(size_t n, const float *a, const float *b, float *loss, void 
                     size_t *workspace_bytes, mgs_stream_t stream);
 int mgs_l1_loss_bwd(size_t n, const float *a, const float *b, const float *v_loss, float *v_a,
                     mgs_stream_t stream);
+/* The training step's form: loss AND v_a = sign(a - b) / n (the gradient for v_loss = 1) in ONE pass over a and b
+ * -- the same bits as the two calls above.  mgs_l1_loss_bwd_scale then turns v_a into the gradient for the v_loss
+ * that arrived, in place (v_a <- sign(v_a) * v_loss / n: idempotent), and is a no-op launch when *v_loss == 1. */
+int mgs_l1_loss_fwd_grad(size_t n, const float *a, const float *b, float *loss, float *v_a,
+                         void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
+int mgs_l1_loss_bwd_scale(size_t n, const float *v_loss, float *v_a, mgs_stream_t stream);
 
 /* -------------------------------------------------------------------------------------
  * Similarity transforms of Gaussian groups (world-frame alignment,

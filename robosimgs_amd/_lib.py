@@ -67,6 +67,8 @@ def _load(path: str = None, hooks: bool = False) -> ctypes.CDLL:
         "mgs_transform_gaussians": ([i, p, p, p, i, i, p, p, i, p, p, p, p, p, p, p], c_int),
         "mgs_l1_loss_fwd": ([c_size_t, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_l1_loss_bwd": ([c_size_t, p, p, p, p, p], c_int),
+        "mgs_l1_loss_fwd_grad": ([c_size_t, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_l1_loss_bwd_scale": ([c_size_t, p, p, p], c_int),
         "mgs_rasterize_bwd_det": ([i, p, p, p, p, p, p, i, i, i, i, i, p, p, p, p, p, p, p, p, p, u32, p, p, i, i, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
     }
     for name, (argtypes, restype) in sig.items():
@@ -124,7 +126,7 @@ EXPORTS = ["mgs_version", "mgs_last_error_string", "mgs_projection_fwd", "mgs_pr
            "mgs_sh_fwd", "mgs_sh_bwd", "mgs_project_color_fwd", "mgs_project_color_bwd",
            "mgs_isect_tiles", "mgs_isect_offset_encode", "mgs_rasterize_fwd", "mgs_rasterize_bwd",
            "mgs_rasterize_bwd_det", "mgs_composite_over", "mgs_points_project",
-           "mgs_points_depth_map", "mgs_points_sample_mask", "mgs_l1_loss_fwd", "mgs_l1_loss_bwd",
+           "mgs_points_depth_map", "mgs_points_sample_mask", "mgs_l1_loss_fwd", "mgs_l1_loss_bwd", "mgs_l1_loss_fwd_grad", "mgs_l1_loss_bwd_scale",
            "mgs_transform_gaussians", "mgs_frame_to_u8", "mgs_frame_to_dataset", "mgs_render_frames",
            "mgs_raster_checkpoint_floats", "mgs_train_state_layout", "mgs_render_frames_train", "mgs_render_frames_backward"]
 

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(
 // latency chain: load -> wave scan -> LDS -> store), 16384 sums per trip = 1 M Gaussians.
 constexpr int kScanThreads = 1024;
 constexpr int kScanPerThread = 16;
-__global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
+template <int kScanThreads>
+__device__ __forceinline__ void scan_blocksums_body(
     uint32_t nblk, uint32_t* __restrict__ blocksums, uint32_t capacity,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
   __shared__ uint32_t ws[kScanThreads / 64];
@@ -120,6 +121,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
     *n_isect = wrapped ? 0xffffffffu : running;
     *status = (wrapped || running > capacity) ? MGS_STATUS_ISECT_OVERFLOW : 0u;   // this call's result: no zero-fill needed
   }
+}
+__global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
+    uint32_t nblk, uint32_t* __restrict__ blocksums, uint32_t capacity,
+    uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status) {
+  scan_blocksums_body<kScanThreads>(nblk, blocksums, capacity, n_isect, status);
 }
 
 // Slots for the deterministic backward, Gaussian-index-major: Gaussian g owns the slots
@@ -293,8 +299,15 @@ __device__ __forceinline__ void for_each_tile(uint32_t pack, uint32_t cnt, uint3
 
 __global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
     int n, int chunk, const uint2* __restrict__ ginfo, int tile_w, int n_tiles, int shift,
-    uint32_t* __restrict__ table, int32_t* __restrict__ tiles_per_gauss) {
+    uint32_t* __restrict__ table, int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ scan_sums, uint32_t n_sums) {
   extern __shared__ uint32_t hist[];
+  if (scan_sums && blockIdx.x == gridDim.x - 1) {
+    // training only, one workgroup more than the histogram needs: the per-64 sums of the tile counts scanned in place
+    // (the backward's record slots are the index-order scan of the counts; the scatter kernel finishes them per
+    // Gaussian) -- beside the histogram instead of a launch of one workgroup in front of it
+    scan_blocksums_body<kDirectThreads>(n_sums, scan_sums, 0u, nullptr, nullptr);
+    return;
+  }
   n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins: groups of 2^shift consecutive tiles
   for (int i = threadIdx.x; i < n_tiles; i += kDirectThreads) hist[i] = 0u;
   __syncthreads();
@@ -370,11 +383,17 @@ __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
   if (rg == 0 && ok) tile_count[t] = tot;
 }
 
+// PAIRS (training): also the record slots of the deterministic backward, Gaussian-index-major -- Gaussian g owns the
+// slots [base, base + w * h) with base = the exclusive scan of the tile counts in INDEX order (scanned_sums: per 64
+// Gaussians, by the histogram launch's extra workgroup; the wave finishes it), so that the per-Gaussian reduction reads
+// contiguous memory from consecutive lanes.  (pair_info_kernel, for the radix path, is the same as a launch of its own.)
+template <bool PAIRS>
 __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     int n, int chunk, const uint2* __restrict__ ginfo, int tile_w, int n_tiles, int shift,
     const uint32_t* __restrict__ table, const uint32_t* __restrict__ tile_count, uint32_t capacity,
     uint32_t* __restrict__ flatten_ids, int32_t* __restrict__ tile_offsets,
-    uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status, int32_t* __restrict__ group_order) {
+    uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status, int32_t* __restrict__ group_order,
+    const uint32_t* __restrict__ scanned_sums, int4* __restrict__ pair_info) {
   extern __shared__ uint32_t cursor[];
   n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins (see direct_hist_kernel)
   if (group_order && blockIdx.x == gridDim.x - 1) {
@@ -431,6 +450,32 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     for (int i = 0; i < kDirectPerThread; ++i) {
       const int g = base + i * kDirectThreads + (int)threadIdx.x;
       info[i] = g < g1 ? ginfo[g] : make_uint2(kEmptyTileRect, 0u);
+    }
+    if (PAIRS) {
+      // (a wave's 64 lanes are 64 consecutive Gaussians starting at a multiple of 64: chunk and the pass are multiples of 512)
+      uint32_t sbase[kDirectPerThread];
+#pragma unroll
+      for (int i = 0; i < kDirectPerThread; ++i) {
+        const int g = base + i * kDirectThreads + (int)threadIdx.x;
+        sbase[i] = g < g1 ? scanned_sums[g / kSum] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < kDirectPerThread; ++i) {
+        const int g = base + i * kDirectThreads + (int)threadIdx.x;
+        const uint32_t cnt = info[i].y;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = __shfl_up(incl, d);
+          if (lane >= (unsigned)d) incl += t;
+        }
+        if (g < g1) {
+          const uint32_t w = info[i].x >> 20;
+          pair_info[g] = cnt ? make_int4((int)(sbase[i] + incl - cnt), (int)(info[i].x & 1023u), (int)((info[i].x >> 10) & 1023u),
+                                         (int)(w | ((cnt / w) << 16)))
+                             : make_int4(0, 0, 0, 0);
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < kDirectPerThread; ++i) {
@@ -631,27 +676,26 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
       ginfo = gi;
     }
     if (direct) {
-      if (pair_info) {   // training only: the record slots of the backward are the index-order scan of the counts
-        hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nsum, sums, cap,
-                           (uint32_t*)nullptr, (uint32_t*)nullptr);
-        hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h, sums,
-                           reinterpret_cast<int4*>(pair_info));
-      }
+      // (training: the backward's record slots -- pair_info -- come out of the histogram and scatter launches)
       const int chunk = (int)direct_chunk((unsigned)n);
       const unsigned nb = direct_blocks((unsigned)n);
       const int bins = (n_tiles + (1 << gshift) - 1) >> gshift;
       const size_t lds = (size_t)bins * sizeof(uint32_t);
-      hipLaunchKernelGGL(direct_hist_kernel, dim3(nb), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
-                         n_tiles, gshift, u32(ws.table), tiles_per_gauss);
+      hipLaunchKernelGGL(direct_hist_kernel, dim3(nb + (pair_info ? 1 : 0)), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
+                         n_tiles, gshift, u32(ws.table), tiles_per_gauss, pair_info ? sums : nullptr, nsum);
       hipLaunchKernelGGL(direct_colscan_kernel, dim3(div_up((unsigned)bins, (unsigned)kColBins)), dim3(kColThreads), 0, s,
                          (int)nb, bins, u32(ws.table), u32(ws.tile_count));
       const bool order_in_scatter = tile_group_order && gshift == 2;
       order_done = order_in_scatter;
-      hipLaunchKernelGGL(direct_scatter_kernel, dim3(nb + (order_in_scatter ? 1 : 0)), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
-                         n_tiles, gshift, u32(ws.table), u32(ws.tile_count), cap,
-                         gshift ? u32(ws.id_alt) : reinterpret_cast<uint32_t*>(flatten_ids),
-                         gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status,
-                         order_in_scatter ? tile_group_order : nullptr);
+#define MGS_SCATTER(P)                                                                                                   \
+      hipLaunchKernelGGL(direct_scatter_kernel<P>, dim3(nb + (order_in_scatter ? 1 : 0)), dim3(kDirectThreads), lds, s, n, \
+                         chunk, ginfo, tile_w, n_tiles, gshift, u32(ws.table), u32(ws.tile_count), cap,                   \
+                         gshift ? u32(ws.id_alt) : reinterpret_cast<uint32_t*>(flatten_ids),                             \
+                         gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status,      \
+                         order_in_scatter ? tile_group_order : nullptr, sums, reinterpret_cast<int4*>(pair_info))
+      if (pair_info) MGS_SCATTER(true);
+      else MGS_SCATTER(false);
+#undef MGS_SCATTER
     } else {
       hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(kScanThreads), 0, s, nsum, sums, cap,
                          n_isect, status);

@@ -1,6 +1,8 @@
 """Loss terms of the training step as fused HIP kernels.  `l1_loss(render, target)` is
-`(render - target).abs().mean()` with its gradient: two streaming launches forward, one backward
-(mgs_l1_loss_fwd / _bwd) instead of six elementwise / reduction kernels, bit-reproducible."""
+`(render - target).abs().mean()` with its gradient.  Where the render wants a gradient the forward is ONE streaming
+launch that also leaves sign(render - target) / n (mgs_l1_loss_fwd_grad) and the backward a launch that does nothing
+for the usual grad_output of 1 (mgs_l1_loss_bwd_scale); without a gradient, mgs_l1_loss_fwd alone.  Instead of six
+elementwise / reduction kernels of eager PyTorch; bit-reproducible."""
 from __future__ import annotations
 
 import ctypes
@@ -19,20 +21,32 @@ class _L1(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=a.device)
         L = _lib.lib()
         nbytes = ctypes.c_size_t(0)
-        check(L.mgs_l1_loss_fwd(n, None, None, None, None, ctypes.byref(nbytes), None), "mgs_l1_loss_fwd(size query)")
+        if not ctx.needs_input_grad[0]:
+            check(L.mgs_l1_loss_fwd(n, None, None, None, None, ctypes.byref(nbytes), None), "mgs_l1_loss_fwd(size query)")
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=a.device)
+            check(L.mgs_l1_loss_fwd(n, ptr(a), ptr(b), ptr(loss), ptr(ws), ctypes.byref(nbytes),
+                                    stream_handle()), "mgs_l1_loss_fwd")
+            return loss
+        check(L.mgs_l1_loss_fwd_grad(n, None, None, None, None, None, ctypes.byref(nbytes), None), "mgs_l1_loss_fwd_grad(size query)")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=a.device)
-        check(L.mgs_l1_loss_fwd(n, ptr(a), ptr(b), ptr(loss), ptr(ws), ctypes.byref(nbytes),
-                                stream_handle()), "mgs_l1_loss_fwd")
+        v_a = torch.empty_like(a)
+        check(L.mgs_l1_loss_fwd_grad(n, ptr(a), ptr(b), ptr(loss), ptr(v_a), ptr(ws), ctypes.byref(nbytes),
+                                     stream_handle()), "mgs_l1_loss_fwd_grad")
         ctx.save_for_backward(a, b)
+        ctx.v_a = v_a
         return loss
 
     @staticmethod
     def backward(ctx, v_loss):
+        g = _f32c(v_loss)
+        v_a, ctx.v_a = ctx.v_a, None
+        if v_a is not None:
+            check(_lib.lib().mgs_l1_loss_bwd_scale(v_a.numel(), ptr(g), ptr(v_a), stream_handle()), "mgs_l1_loss_bwd_scale")
+            return v_a, None
+        # a second backward through a retained graph: autograd owns the first buffer by now
         a, b = ctx.saved_tensors
         v_a = torch.empty_like(a)
-        g = _f32c(v_loss)
-        check(_lib.lib().mgs_l1_loss_bwd(a.numel(), ptr(a), ptr(b), ptr(g), ptr(v_a), stream_handle()),
-              "mgs_l1_loss_bwd")
+        check(_lib.lib().mgs_l1_loss_bwd(a.numel(), ptr(a), ptr(b), ptr(g), ptr(v_a), stream_handle()), "mgs_l1_loss_bwd")
         return v_a, None
 
 

@@ -25,7 +25,7 @@ def _declared(hooks=False):
 def test_header_symbols_are_exported_and_bound():
     from robosimgs_amd import _lib
     decl = _declared()
-    assert len(decl) == 27, sorted(decl)
+    assert len(decl) == 29, sorted(decl)
     assert sorted(decl) == sorted(_lib.EXPORTS)
     L = _lib.lib()
     for name, nargs in decl.items():

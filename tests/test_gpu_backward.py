@@ -444,6 +444,14 @@ def test_fused_l1_loss_matches_torch(shape):
     assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, ref.item())
     torch.testing.assert_close(a.grad, a2.grad, rtol=1e-6, atol=0)
     assert l1_loss(a, b).item() == loss.item()                  # fixed summation order
+    assert l1_loss(a.detach(), b).item() == loss.item()         # the forward-only kernels: the same bits
+    # grad_output 1 (the scale launch returns at once), and a second backward through a retained graph
+    a3 = a.detach().clone().requires_grad_(True)
+    l3 = l1_loss(a3, b)
+    l3.backward(retain_graph=True)
+    torch.testing.assert_close(a3.grad * 3.0, a2.grad, rtol=1e-6, atol=0)
+    l3.backward()
+    torch.testing.assert_close(a3.grad * 1.5, a2.grad, rtol=1e-6, atol=0)
     # a contiguous view at an odd element offset
     if len(shape) == 1:
         v = torch.rand(9, device=DEV)[1:8]
