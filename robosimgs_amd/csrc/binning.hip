@@ -259,10 +259,10 @@ constexpr int kDirectThreads = MGS_DIRECT_THREADS;
 #ifndef MGS_DIRECT_PER_THREAD
 // Round 4: 4 (was 8).  At 1 M Gaussians 512 x 8 is 245 workgroups -- fewer than CUs, two waves per SIMD -- and on a
 // Morton-ordered scene their shares of the pairs differ by 2.7 x (15 k on average, 40 k at most: near Gaussians are
-// neighbours in memory AND cover many tiles).  490 workgroups: scatter 29.5 -> 21.7 us, histogram 14.4 -> 11.5, the
-// column scan (twice the rows) 6.9 -> 12 before it got 64 row groups per workgroup; stage 88.7 -> 73.6 us, three frames
-// in flight 4,503 -> 4,561 frames/s.  With the scene in random order the shares are even and the extra rows cost the
-// scatter 4 us (fragmented stores): 90 -> 100 us alone before the column-scan change, the same frames/s.
+// neighbours in memory AND cover many tiles).  490 workgroups, rocprofv3 per kernel in bench.py's run: scatter 30.3 ->
+// 25.7 us, histogram 14.3 -> 11.3, the column scan (twice the rows) 6.9 -> 11.6 (8.8 once it kept its rows in registers);
+// three frames in flight 4,503 -> 4,561 frames/s.  With the scene in random order the shares are even and the extra rows
+// cost the scatter ~4 us (fragmented stores), the same frames/s.
 #define MGS_DIRECT_PER_THREAD 4
 #endif
 constexpr int kDirectPerThread = MGS_DIRECT_PER_THREAD;   // Gaussians per thread of those kernels
@@ -336,11 +336,11 @@ __global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
 // 256 threads: 16 bins (64 bytes of a row) x 16 row groups; two passes over the group's rows (sum, then rewrite as
 // the exclusive prefix), 16 loads in flight per thread
 #ifndef MGS_COLSCAN_BINS
-// 256 threads: kColBins bins (4 bytes each, consecutive in a table row) x 256 / kColBins row groups; two passes over the
-// group's rows (sum, then rewrite as the exclusive prefix), 16 loads in flight per thread.  Re-measured in round 4 at
-// the 490 table rows of 1 M Gaussians (same process, builds taking turns; seeded binning stage): 16 bins x 16 groups
-// 73.8 us, 8 x 32 82.6, 4 x 64 85.5; 16 x 32 with 512 threads 2 us faster alone but 4,170 against 4,504 frames/s with
-// three frames in flight (a 512-thread workgroup waits for room between other frames' raster waves).
+// 256 threads: kColBins bins (4 bytes each, consecutive in a table row) x 256 / kColBins row groups.  rocprofv3 per
+// kernel at the 490 table rows of 1 M Gaussians (two trips over the column, round 4): 16 bins x 16 groups 11.6 us,
+// 8 x 32 11.3, 4 x 64 14.2, 32 x 8 16.4; 16 x 32 with 512 threads 2 us faster alone but 4,170 against 4,504 frames/s with
+// three frames in flight (a 512-thread workgroup waits for room between other frames' raster waves).  With the rows kept
+// in registers (one trip, below) 16 x 16 takes 8.8 us.
 #define MGS_COLSCAN_BINS 16
 #endif
 constexpr int kColThreads = 256, kColBins = MGS_COLSCAN_BINS, kColGroups = kColThreads / kColBins;
@@ -352,13 +352,28 @@ __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
   const int rpg = (nb + kColGroups - 1) / kColGroups;
   const int r0 = rg * rpg, r1 = min(nb, r0 + rpg);
   const bool ok = t < n_tiles;
+  // up to kColKeep rows per thread (1 M Gaussians: 490 rows, 31 per thread; 64 would cover every table but needs 124 VGPRs) stay in registers between the sum and the
+  // rewrite: one trip over the column instead of two (the kernel is its chain of load round trips)
+  constexpr int kColKeep = 32;
+  const bool keep = rpg <= kColKeep;              // uniform
+  uint32_t kept[kColKeep];
   uint32_t sum = 0;
-  for (int r = r0; r < r1; r += 16) {
-    uint32_t v[16];
+  if (keep) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (ok && r + j < r1) ? table[(size_t)(r + j) * n_tiles + t] : 0u;
+    for (int j = 0; j < kColKeep; ++j) {
+      if (j >= rpg) { kept[j] = 0u; continue; }    // (uniform: whole 16-row pieces past the group's share are skipped)
+      kept[j] = (ok && r0 + j < r1) ? table[(size_t)(r0 + j) * n_tiles + t] : 0u;
+    }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) sum += v[j];
+    for (int j = 0; j < kColKeep; ++j) sum += kept[j];
+  } else {
+    for (int r = r0; r < r1; r += 16) {
+      uint32_t v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = (ok && r + j < r1) ? table[(size_t)(r + j) * n_tiles + t] : 0u;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sum += v[j];
+    }
   }
   part[rg][bl] = sum;
   __syncthreads();
@@ -369,16 +384,27 @@ __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
     if (g < rg) off += s;
     tot += s;
   }
-  for (int r = r0; r < r1; r += 16) {
-    uint32_t v[16];
+  if (keep) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (ok && r + j < r1) ? table[(size_t)(r + j) * n_tiles + t] : 0u;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (ok && r + j < r1) {
-        table[(size_t)(r + j) * n_tiles + t] = off;
-        off += v[j];
+    for (int j = 0; j < kColKeep; ++j) {
+      if (j >= rpg) continue;
+      if (ok && r0 + j < r1) {
+        table[(size_t)(r0 + j) * n_tiles + t] = off;
+        off += kept[j];
       }
+    }
+  } else {
+    for (int r = r0; r < r1; r += 16) {
+      uint32_t v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = (ok && r + j < r1) ? table[(size_t)(r + j) * n_tiles + t] : 0u;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (ok && r + j < r1) {
+          table[(size_t)(r + j) * n_tiles + t] = off;
+          off += v[j];
+        }
+    }
   }
   if (rg == 0 && ok) tile_count[t] = tot;
 }
