@@ -343,7 +343,15 @@ __global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
 // in registers (one trip, below) 16 x 16 takes 8.8 us.
 #define MGS_COLSCAN_BINS 16
 #endif
+#ifndef MGS_COLSCAN_KEEP
+// Table rows a thread keeps in registers between the sum and the rewrite (one trip over the column instead of two) in a
+// TRAINING step, where the launch has the GPU to itself: 11.6 -> 8.8 us at 32 (92 VGPRs).  Inference frames keep the
+// two-trip scan (kColKeep 1, ~50 VGPRs): with three frames in flight the one-trip scan renders 4,421 against 4,503
+// frames/s (3,846 against 3,927 in the caller's order) -- its fatter waves wait for room between the raster's.
+#define MGS_COLSCAN_KEEP 32
+#endif
 constexpr int kColThreads = 256, kColBins = MGS_COLSCAN_BINS, kColGroups = kColThreads / kColBins;
+template <int kColKeep>
 __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
     int nb, int n_tiles, uint32_t* __restrict__ table, uint32_t* __restrict__ tile_count) {
   __shared__ uint32_t part[kColGroups][kColBins];
@@ -354,7 +362,6 @@ __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
   const bool ok = t < n_tiles;
   // up to kColKeep rows per thread (1 M Gaussians: 490 rows, 31 per thread; 64 would cover every table but needs 124 VGPRs) stay in registers between the sum and the
   // rewrite: one trip over the column instead of two (the kernel is its chain of load round trips)
-  constexpr int kColKeep = 32;
   const bool keep = rpg <= kColKeep;              // uniform
   uint32_t kept[kColKeep];
   uint32_t sum = 0;
@@ -709,8 +716,12 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
       const size_t lds = (size_t)bins * sizeof(uint32_t);
       hipLaunchKernelGGL(direct_hist_kernel, dim3(nb + (pair_info ? 1 : 0)), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
                          n_tiles, gshift, u32(ws.table), tiles_per_gauss, pair_info ? sums : nullptr, nsum);
-      hipLaunchKernelGGL(direct_colscan_kernel, dim3(div_up((unsigned)bins, (unsigned)kColBins)), dim3(kColThreads), 0, s,
-                         (int)nb, bins, u32(ws.table), u32(ws.tile_count));
+      if (pair_info)
+        hipLaunchKernelGGL(direct_colscan_kernel<MGS_COLSCAN_KEEP>, dim3(div_up((unsigned)bins, (unsigned)kColBins)), dim3(kColThreads), 0, s,
+                           (int)nb, bins, u32(ws.table), u32(ws.tile_count));
+      else
+        hipLaunchKernelGGL(direct_colscan_kernel<1>, dim3(div_up((unsigned)bins, (unsigned)kColBins)), dim3(kColThreads), 0, s,
+                           (int)nb, bins, u32(ws.table), u32(ws.tile_count));
       const bool order_in_scatter = tile_group_order && gshift == 2;
       order_done = order_in_scatter;
 #define MGS_SCATTER(P)                                                                                                   \
