@@ -815,7 +815,7 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
   const int n_units = tile_group_order ? (n_tiles + 3) / 4 * 4 : n_tiles;       // tile slots of the launch
 #define MGS_RF_LAUNCH_T(C, T)                                                                  \
   hipLaunchKernelGGL((raster_fwd_kernel<C, T>), dim3(div_up(n_units, (T) ? 1 : MGS_RASTER_WG_WAVES)),   \
-                     dim3(64 * ((T) ? 1 : MGS_RASTER_WG_WAVES)), 0, s, means2d, conics,           \
+                     dim3(64 * ((T) ? 1 : MGS_RASTER_WG_WAVES)), (T) ? 0 : (size_t)(g_raster_opts >> 8) * 1024, s, means2d, conics, \
                      feats, opacities, reinterpret_cast<const float4*>(splats), background,     \
                      channels, width, height, tile_w, n_tiles,                                 \
                      tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull,            \
