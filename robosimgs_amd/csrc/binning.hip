@@ -360,12 +360,14 @@ __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
   const int rpg = (nb + kColGroups - 1) / kColGroups;
   const int r0 = rg * rpg, r1 = min(nb, r0 + rpg);
   const bool ok = t < n_tiles;
-  // up to kColKeep rows per thread (1 M Gaussians: 490 rows, 31 per thread; 64 would cover every table but needs 124 VGPRs) stay in registers between the sum and the
-  // rewrite: one trip over the column instead of two (the kernel is its chain of load round trips)
-  const bool keep = rpg <= kColKeep;              // uniform
+  // up to kColKeep rows per thread (1 M Gaussians: 490 rows, 31 per thread; 64 would cover every table but needs 124
+  // VGPRs) stay in registers between the sum and the rewrite: one trip over the column instead of two (the kernel is its
+  // chain of load round trips).  kColKeep 1: the two-trip scan only.
+  constexpr bool kCanKeep = kColKeep > 1;
+  const bool keep = kCanKeep && rpg <= kColKeep;              // uniform
   uint32_t kept[kColKeep];
   uint32_t sum = 0;
-  if (keep) {
+  if (kCanKeep && keep) {
 #pragma unroll
     for (int j = 0; j < kColKeep; ++j) {
       if (j >= rpg) { kept[j] = 0u; continue; }    // (uniform: whole 16-row pieces past the group's share are skipped)
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(kColThreads) void direct_colscan_kernel(
     if (g < rg) off += s;
     tot += s;
   }
-  if (keep) {
+  if (kCanKeep && keep) {
 #pragma unroll
     for (int j = 0; j < kColKeep; ++j) {
       if (j >= rpg) continue;
