@@ -39,8 +39,10 @@ extern "C" {
 /* Bumped whenever a parameter list changes: a caller built against another header must not load this
  * library (robosimgs_amd/_lib.py asserts mgs_version() == the MGS_VERSION it was written for).
  * 100 round 1; 200 round 2 (seed / splats / tile_group_order arguments); 300 round 3; 400 round 4 (forward
- * checkpoints + segmented backward, batched training entry points, debug hooks out of the production build). */
-#define MGS_VERSION 400
+ * checkpoints + segmented backward, batched training entry points, debug hooks out of the production build);
+ * 410 round 4 (the radius rule as a policy: radii_y / radius_rule arguments, MGS_BIN_* / MGS_FRAMES_RADIUS_* flags,
+ * one more field in the training state). */
+#define MGS_VERSION 410
 
 #define MGS_OK 0
 #define MGS_ERR_INVALID_ARGUMENT (-1)
@@ -60,6 +62,27 @@ extern "C" {
 #define MGS_FRAMES_CLASSIC_BOUNDS 4 /* bin into gsplat's classic mean +- radius tile rectangles instead of the tightened
                                        ones: same pixels bit for bit, but n_isect / the overflow status then count the
                                        classic lists (a caller that sized its capacity with them) */
+
+#define MGS_FRAMES_RADIUS_OPACITY_AWARE 8 /* project with MGS_RADIUS_OPACITY_AWARE (below) instead of the classic rule */
+
+/* The radius rule ("make the radius rule a compile-time policy so the tighter one can be benchmarked").
+ * Inside the library the rule is a template constant of the projection kernels; both instantiations ship and the
+ * caller picks one per call.
+ *   MGS_RADIUS_CLASSIC        gsplat 1.4, A.2 step 5 (the semantics of this build's parity claim): one radius
+ *                             ceil(3 sqrt(lambda_1)) per Gaussian, tile rectangle of the square mean +- radius.
+ *   MGS_RADIUS_OPACITY_AWARE  gsplat >= 1.5: per-axis extents radii = ceil(e sqrt(Sigma_xx)), radii_y = ceil(e sqrt(Sigma_yy))
+ *                             with e = min(3.33, sqrt(2 ln(255 opacity))) (opacity x compensation when antialiased; e = 3.33
+ *                             without opacities); Gaussians of opacity < 1/255 are culled; a Gaussian is culled by
+ *                             radius_clip only when BOTH extents are <= radius_clip; screen cull and tile rectangle per
+ *                             axis.  Changes n_isect and, at the edge of opaque Gaussians (3.33 > 3 sigma) and in the
+ *                             corners of the classic square, pixels. */
+#ifndef MGS_RADIUS_CLASSIC
+#define MGS_RADIUS_CLASSIC 0
+#define MGS_RADIUS_OPACITY_AWARE 1
+#endif
+/* mgs_project_color_fwd bin_flags */
+#define MGS_BIN_TIGHT 1                 /* tightened tile rectangles in the binning seed (mgs_isect_tiles) */
+#define MGS_BIN_RADIUS_OPACITY_AWARE 2  /* MGS_RADIUS_OPACITY_AWARE instead of MGS_RADIUS_CLASSIC */
 
 /* mgs_rasterize_bwd_det flags */
 #define MGS_RASTER_BWD_RECORDS_ONLY 1 /* stop after the raster kernel: the workspace then holds one record and one flag
@@ -95,12 +118,16 @@ void mgs_debug_set_sort_opts(int opts);
  *   out: radii[N] i32 (0 = culled), means2d[N,2], depths[N], conics[N,3],
  *        compensations[N] (nullable; sqrt(max(0, det_orig/det_blur))).
  *   Culled Gaussians get zeros in every output.
+ *   radius_rule: MGS_RADIUS_CLASSIC (opacities / radii_y not read or written, may be NULL) or
+ *   MGS_RADIUS_OPACITY_AWARE: opacities[N] nullable (as gsplat >= 1.5's optional argument; multiplied by the compensation
+ *   iff compensations is given, gsplat's calc_compensations), radii = extent along x, radii_y[N] = extent along y.
  * ----------------------------------------------------------------------------------- */
 int mgs_projection_fwd(int n, const float *means, const float *quats, const float *scales,
                        const float *viewmat, const float *K, int width, int height,
                        float eps2d, float near_plane, float far_plane, float radius_clip,
                        int32_t *radii, float *means2d, float *depths, float *conics,
-                       float *compensations, mgs_stream_t stream);
+                       float *compensations, const float *opacities, int radius_rule,
+                       int32_t *radii_y, mgs_stream_t stream);
 
 /* Projection backward (gsplat `fully_fused_projection` backward).
  *   v_means2d[N,2] v_depths[N] v_conics[N,3] v_compensations[N] (nullable) are the
@@ -144,12 +171,14 @@ int mgs_sh_bwd(int n, int degree, int coeff_stride, const float *dirs, const flo
  * (means2d, conics, opacities, feats), which cuts their cache-line traffic: 266 -> 240 us.
  * bin_info[N,2] u32 + bin_sums[ceil(N/64)] u32 (nullable, together): the SEED of the tile binning
  * at tile size 16 -- per Gaussian {x0 | y0 << 10 | max(w,1) << 20, tile count} of its tile
- * rectangle (bin_tight != 0: tightened to the tiles it can reach with alpha >= 1/255, see
+ * rectangle (bin_flags & MGS_BIN_TIGHT: tightened to the tiles it can reach with alpha >= 1/255, see
  * mgs_isect_tiles) and the count sum of every 64 consecutive Gaussians.  Handed to
  * mgs_isect_tiles as seed_info / seed_sums they save the binning a pass and a launch.
  * radii / means2d / conics / feats may each be NULL when BOTH splats and bin_info are given (an
  * inference frame: the raster gathers from splats, the seeded binning reads bin_info and depths;
  * 36 of 84 MB of stores per 1 M Gaussians fall away).  depths is always written.
+ * bin_flags & MGS_BIN_RADIUS_OPACITY_AWARE: project with that radius rule (opacity x compensation when opac_out is
+ * given); radii_y[N] then receives the extents along y beside radii (x) -- required whenever radii is given, else NULL.
  * ----------------------------------------------------------------------------------- */
 int mgs_project_color_fwd(int n, const float *means, const float *quats, const float *scales,
                           const float *opacities, int sh_degree, int coeff_stride,
@@ -157,8 +186,8 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
                           int width, int height, float eps2d, float near_plane,
                           float far_plane, float radius_clip, int32_t *radii, float *means2d,
                           float *depths, float *conics, float *opac_out, int feat_stride,
-                          float *feats, float *splats, int bin_tight, uint32_t *bin_info,
-                          uint32_t *bin_sums, mgs_stream_t stream);
+                          float *feats, float *splats, int bin_flags, uint32_t *bin_info,
+                          uint32_t *bin_sums, int32_t *radii_y, mgs_stream_t stream);
 
 /* -------------------------------------------------------------------------------------
  * Tile binning  (gsplat `isect_tiles` with sort=True + `isect_offset_encode`, one camera)
@@ -199,8 +228,10 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * means2d / radii / conics / opacities are not read (and may be NULL) and seed_sums -- 16-byte aligned --
  * is overwritten (scanned in place).
  * tile_ids (nullable): an inference frame does not need it; NULL saves the store.
+ * radii_y[N] (nullable): per-axis radii as MGS_RADIUS_OPACITY_AWARE produces them (gsplat >= 1.5's radii[N,2] as two
+ * arrays): the tile rectangle is mean +- (radii, radii_y) instead of the square mean +- radii.
  * ----------------------------------------------------------------------------------- */
-int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const float *depths,
+int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const int32_t *radii_y, const float *depths,
                     const float *conics, const float *opacities, int tile_size, int tile_w,
                     int tile_h, int cam_id, int n_cams,
                     uint32_t isect_capacity, int32_t *tiles_per_gauss, uint32_t *n_isect,
@@ -239,8 +270,8 @@ int mgs_render_frames(int n, const float *means, const float *quats, const float
  *   radii[N] i32 | means2d[N,2] | depths[N] | conics[N,3] | opacities x compensation [N] (antialiased only) |
  *   feats[N,channels] | splats[N,12] | tiles_per_gauss[N] i32 | pair_info[N,4] i32 | tile_ids[cap] u32 |
  *   flatten_ids[cap] i32 | tile_offsets[n_tiles+1] i32 | tile_group_order[ceil(n_tiles/4)] i32 | last_ids[H,W] i32 |
- *   checkpoints | {n_isect, status} u32
- * flags: MGS_RASTER_EXPECTED_LAST, MGS_RASTER_LATENCY, MGS_FRAMES_CLASSIC_BOUNDS.  Workspace (shared by the cameras):
+ *   checkpoints | {n_isect, status} u32 | radii_y[N] i32 (written under MGS_FRAMES_RADIUS_OPACITY_AWARE only)
+ * flags: MGS_RASTER_EXPECTED_LAST, MGS_RASTER_LATENCY, MGS_FRAMES_CLASSIC_BOUNDS, MGS_FRAMES_RADIUS_OPACITY_AWARE.  Workspace (shared by the cameras):
  * two-phase size query, 256-byte aligned.
  * mgs_render_frames_backward: per camera mgs_rasterize_bwd_det (segmented when checkpoint_interval != 0) ->
  * mgs_project_color_bwd; v_means / v_quats / v_scales / v_sh_coeffs / v_opacities are OVERWRITTEN by the first camera
@@ -249,7 +280,7 @@ int mgs_render_frames(int n, const float *means, const float *quats, const float
  * computed iff v_means2d_abs is given.  v_alphas[C,H,W] nullable.  Same arithmetic, in the same order, as the
  * per-camera entry points: bit-identical gradients.
  * ----------------------------------------------------------------------------------- */
-#define MGS_TRAIN_FIELDS 16
+#define MGS_TRAIN_FIELDS 17
 int mgs_train_state_layout(int n, int width, int height, int channels, uint32_t isect_capacity, int antialiased,
                            int checkpoint_interval, size_t *offsets, size_t *bytes_per_camera);
 int mgs_render_frames_train(int n, const float *means, const float *quats, const float *scales,

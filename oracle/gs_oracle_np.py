@@ -84,12 +84,21 @@ def covar_world(quats, scales, dtype=np.float64):
     return M @ np.swapaxes(M, 1, 2)
 
 
+EXTENT_MAX = 3.33     # gsplat >= 1.5: the per-axis extent is capped at 3.33 sigma
+
+
 def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3,
-            near_plane=0.01, far_plane=1e10, radius_clip=0.0, dtype=np.float64):
+            near_plane=0.01, far_plane=1e10, radius_clip=0.0, dtype=np.float64,
+            radius_rule="classic", opacities=None, antialiased=False):
     """A.2 steps 1-5 for one camera.
 
     Returns dict(radii[N] int32, means2d[N,2], depths[N], conics[N,3],
     compensations[N]); culled Gaussians have radii 0 and zeros elsewhere.
+
+    radius_rule "classic": A.2 step 5 (gsplat 1.4).  "opacity_aware": SURVEY.md A.4 (gsplat >= 1.5) -- radii[N,2],
+    per-axis extents ceil(e sqrt(Sigma_xx)), ceil(e sqrt(Sigma_yy)) of the blurred 2-D covariance with
+    e = min(3.33, sqrt(2 ln(255 o))), o = opacity (x compensation when antialiased; e = 3.33 without opacities);
+    culled: o < 1/255, both extents <= radius_clip, the box mean +- extents wholly off screen.
     """
     means = np.asarray(means, dtype=dtype)
     viewmat = np.asarray(viewmat, dtype=dtype)
@@ -135,16 +144,45 @@ def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3,
 
     m = dtype(0.5) * (a + c)                                     # step 5
     lam = m + np.sqrt(np.maximum(dtype(0.01), m * m - dets))
-    radius = np.ceil(dtype(3.0) * np.sqrt(lam))
-    valid &= radius > dtype(radius_clip)
+    extra = {}
+    if radius_rule == "classic":
+        radius = np.ceil(dtype(3.0) * np.sqrt(lam))
+        radius_y = radius
+        valid &= radius > dtype(radius_clip)
+        extra["extent_xy"] = np.stack([dtype(3.0) * np.sqrt(lam)] * 2, axis=-1)
+    elif radius_rule == "opacity_aware":
+        ext = np.full(N, dtype(EXTENT_MAX), dtype=dtype)
+        op_ok = np.ones(N, dtype=bool)
+        if opacities is not None:
+            op = np.asarray(opacities, dtype=dtype)
+            if antialiased:
+                op = op * comp
+            op_ok = op >= dtype(1.0) / dtype(255.0)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                lim = np.sqrt(dtype(2.0) * np.log(np.where(op_ok, op, dtype(1.0)) * dtype(255.0)))
+            ext = np.minimum(ext, lim)
+            extra["op_rule"] = op
+        valid &= op_ok
+        ex, ey = ext * np.sqrt(np.maximum(a, 0)), ext * np.sqrt(np.maximum(c, 0))
+        radius, radius_y = np.ceil(ex), np.ceil(ey)
+        valid &= (radius > dtype(radius_clip)) | (radius_y > dtype(radius_clip))
+        valid &= (radius > 0) & (radius_y > 0)
+        extra["extent_xy"] = np.stack([ex, ey], axis=-1)
+        extra["extent"] = ext
+    else:
+        raise ValueError(radius_rule)
     valid &= ~((mu[:, 0] + radius <= 0) | (mu[:, 0] - radius >= W)
-               | (mu[:, 1] + radius <= 0) | (mu[:, 1] - radius >= H))
+               | (mu[:, 1] + radius_y <= 0) | (mu[:, 1] - radius_y >= H))
+    if radius_rule == "classic":
+        radii = np.where(valid, radius, 0).astype(np.int32)
+    else:
+        radii = np.where(valid[:, None], np.stack([radius, radius_y], axis=-1), 0).astype(np.int32)
 
     zok = (z >= dtype(near_plane)) & (z <= dtype(far_plane))
     out = {
         # un-masked intermediates (gaussian_edge_mask): lambda_1, raw means / depths / conics
-        "lam": lam, "mu": mu, "z": z, "det_ok": det > 0, "conics_all": conic, "z_ok": zok,
-        "radii": np.where(valid, radius, 0).astype(np.int32),
+        "lam": lam, "mu": mu, "z": z, "det_ok": det > 0, "conics_all": conic, "z_ok": zok, **extra,
+        "radii": radii,
         "means2d": np.where(valid[:, None], mu, 0),
         "depths": np.where(valid, z, 0),
         "conics": np.where(valid[:, None], conic, 0),
@@ -212,18 +250,24 @@ def campos_from_viewmat(viewmat):
 # --------------------------------------------------------------------------------------
 # A.2 steps 7-8: tile intersection, sort, ranges
 # --------------------------------------------------------------------------------------
+def visible(radii):
+    """bool [N]: radii [N] > 0, or the x extent of per-axis radii [N,2] > 0 (both are positive or both zero)."""
+    r = np.asarray(radii)
+    return (r > 0) if r.ndim == 1 else (r[:, 0] > 0)
+
+
 def tile_rects(means2d, radii, tile_size, tile_w, tile_h, dtype=np.float64):
-    """Per-Gaussian tile rectangle [x0,x1) x [y0,y1) (A.2 step 7)."""
+    """Per-Gaussian tile rectangle [x0,x1) x [y0,y1) (A.2 step 7); radii [N] or per-axis [N,2] (A.4)."""
     mu = np.asarray(means2d, dtype=dtype)
     r = np.asarray(radii).astype(dtype)
     ts = dtype(tile_size)
-    tr = r / ts
+    trx, try_ = (r / ts, r / ts) if r.ndim == 1 else (r[:, 0] / ts, r[:, 1] / ts)
     txc, tyc = mu[:, 0] / ts, mu[:, 1] / ts
-    x0 = np.clip(np.floor(txc - tr), 0, tile_w).astype(np.int64)
-    x1 = np.clip(np.ceil(txc + tr), 0, tile_w).astype(np.int64)
-    y0 = np.clip(np.floor(tyc - tr), 0, tile_h).astype(np.int64)
-    y1 = np.clip(np.ceil(tyc + tr), 0, tile_h).astype(np.int64)
-    vis = np.asarray(radii) > 0
+    x0 = np.clip(np.floor(txc - trx), 0, tile_w).astype(np.int64)
+    x1 = np.clip(np.ceil(txc + trx), 0, tile_w).astype(np.int64)
+    y0 = np.clip(np.floor(tyc - try_), 0, tile_h).astype(np.int64)
+    y1 = np.clip(np.ceil(tyc + try_), 0, tile_h).astype(np.int64)
+    vis = visible(radii)
     x0, x1, y0, y1 = (np.where(vis, v, 0) for v in (x0, x1, y0, y1))
     return x0, x1, y0, y1
 
@@ -503,28 +547,37 @@ def gaussian_edge_mask(p, opacities, width, height, tile_size=16, eps_radius=3e-
     whose membership in that Gaussian's tile rectangle depends on a knife edge of A.2 steps 2-5/7:
     3 sqrt(lambda) within eps_radius (relative) of an integer (the ceil), mean2d +- radius within
     d_mu pixels of a tile boundary or of the screen-cull limits, depth within 1e-5 relative of the
-    near / far plane.  `p` is the dict `project` returned ("lam" included)."""
+    near / far plane.  `p` is the dict `project` returned ("lam" included).  Under the per-axis radius rule (A.4)
+    the two extents e sqrt(Sigma_ii) take the place of 3 sqrt(lambda) ("extent_xy"), and an opacity within 1e-5
+    (relative) of 1/255 makes the Gaussian's very presence uncertain."""
     mask = np.zeros((height, width), dtype=bool)
     weight = np.zeros((height, width))           # sum of the alphas of the uncertain Gaussians reaching the pixel
     tw, th = -(-width // tile_size), -(-height // tile_size)
-    v = 3.0 * np.sqrt(p["lam"])
+    v = p["extent_xy"] if "extent_xy" in p else np.stack([3.0 * np.sqrt(p["lam"])] * 2, axis=-1)     # [N,2]
     z, mu = p["z"], p["mu"]
     r = np.ceil(v)
     fr = v - np.floor(v)
+    # (the opacity-aware extent goes through a logarithm of the opacity: its relative rounding is larger near o = 1/255)
     tol = eps_radius * np.maximum(v, 1.0) + 1e-6
+    if "extent" in p:                                           # d(extent) = d(ln) / extent with d(ln) ~ 2e-7 in fp32
+        tol = tol + v * (2e-7 / np.maximum(p["extent"] ** 2, 1e-12))[:, None]
     r_lo = np.where((fr > 0) & (fr < tol), r - 1, r)            # v barely above an integer: ceil may drop
     r_hi = np.where((1.0 - fr < tol) | (fr == 0), r + 1, r)     # v barely below one: ceil may rise
     zin = (z >= near_plane * (1 + 1e-5)) & (z <= far_plane * (1 - 1e-5)) & p["det_ok"]
     zout = (z >= near_plane * (1 - 1e-5)) & (z <= far_plane * (1 + 1e-5)) & p["det_ok"]
+    if "op_rule" in p:                                          # A.4: culled below 1/255 -- uncertain within 1e-5 of it
+        zin &= p["op_rule"] >= (1 + 1e-5) * ALPHA_MIN
+        zout &= p["op_rule"] >= (1 - 1e-5) * ALPHA_MIN
 
     def rect(rr, grow):
         d = d_mu if grow else -d_mu
-        x0 = np.clip(np.floor((mu[:, 0] - rr - d) / tile_size), 0, tw)
-        x1 = np.clip(np.ceil((mu[:, 0] + rr + d) / tile_size), 0, tw)
-        y0 = np.clip(np.floor((mu[:, 1] - rr - d) / tile_size), 0, th)
-        y1 = np.clip(np.ceil((mu[:, 1] + rr + d) / tile_size), 0, th)
-        on = ~((mu[:, 0] + rr + d <= 0) | (mu[:, 0] - rr - d >= width)
-               | (mu[:, 1] + rr + d <= 0) | (mu[:, 1] - rr - d >= height)) & (rr > 0)
+        rx, ry = rr[:, 0], rr[:, 1]
+        x0 = np.clip(np.floor((mu[:, 0] - rx - d) / tile_size), 0, tw)
+        x1 = np.clip(np.ceil((mu[:, 0] + rx + d) / tile_size), 0, tw)
+        y0 = np.clip(np.floor((mu[:, 1] - ry - d) / tile_size), 0, th)
+        y1 = np.clip(np.ceil((mu[:, 1] + ry + d) / tile_size), 0, th)
+        on = ~((mu[:, 0] + rx + d <= 0) | (mu[:, 0] - rx - d >= width)
+               | (mu[:, 1] + ry + d <= 0) | (mu[:, 1] - ry - d >= height)) & (rx > 0) & (ry > 0)
         return x0.astype(int), x1.astype(int), y0.astype(int), y1.astype(int), on
     ix0, ix1, iy0, iy1, ion = rect(r_lo, False)
     ox0, ox1, oy0, oy1, oon = rect(r_hi, True)
@@ -557,7 +610,7 @@ def gaussian_edge_mask(p, opacities, width, height, tile_size=16, eps_radius=3e-
 def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, height,
            sh_degree=None, tile_size=16, render_mode="RGB", eps2d=0.3,
            near_plane=0.01, far_plane=1e10, radius_clip=0.0, background=None,
-           rasterize_mode="classic", dtype=np.float64, margins=False, flip_eps=None):
+           rasterize_mode="classic", dtype=np.float64, margins=False, flip_eps=None, radius_rule="classic"):
     """Full single-camera frame following SURVEY.md A.1/A.2.  Inputs are post-activation
     (scales = exp(log_s), opacities = sigmoid(logit)).  Returns (colors[H,W,D],
     alpha[H,W,1], meta).  margins=True adds meta["margins"] (see `rasterize`) and
@@ -566,7 +619,8 @@ def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, hei
     tile_w = -(-width // tile_size)
     tile_h = -(-height // tile_size)
     p = project(means, quats, scales, viewmat, K, width, height, eps2d, near_plane,
-                far_plane, radius_clip, dtype)
+                far_plane, radius_clip, dtype, radius_rule=radius_rule, opacities=opacities,
+                antialiased=rasterize_mode == "antialiased")
     opac = np.asarray(opacities, dtype=dtype)
     if rasterize_mode == "antialiased":
         opac = opac * p["compensations"]
@@ -575,7 +629,7 @@ def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, hei
     else:
         rgb = sh_colors(sh_degree, means, campos_from_viewmat(viewmat), sh_or_colors,
                         dtype)
-        rgb = np.where((p["radii"] > 0)[:, None], rgb, 0)
+        rgb = np.where(visible(p["radii"])[:, None], rgb, 0)
     depth = p["depths"][:, None]
     if render_mode in ("RGB",):
         feats = rgb
@@ -608,11 +662,11 @@ def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, hei
             # T threshold by the factor (1 - alpha)
             fw = stats.pop("flip_weight") + ew
             fw = fw + np.where(em & (stats["margins"][1] < flip_eps["T"] + ew), stats.pop("t_at_min"), 0.0)
-            vis = p["radii"] > 0
+            vis = visible(p["radii"])
             meta.update(flip_weight=fw, feat_max=(np.abs(feats[vis]).max(axis=0) if vis.any()
                                                   else np.zeros(feats.shape[1])))
     meta.update(tiles_per_gauss=tpg, isect_ids=isect_ids, flatten_ids=flatten_ids,
                 isect_offsets=offs, last_ids=last, colors=rgb, opacities=opac,
                 tile_width=tile_w, tile_height=tile_h, n_isect=len(flatten_ids),
-                n_vis=int((p["radii"] > 0).sum()), **stats)
+                n_vis=int(visible(p["radii"]).sum()), **stats)
     return img, alpha[..., None], meta

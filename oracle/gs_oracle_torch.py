@@ -30,9 +30,10 @@ def quat_to_rotmat(q):
 
 
 def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_plane=0.01,
-            far_plane=1e10, radius_clip=0.0):
+            far_plane=1e10, radius_clip=0.0, radius_rule="classic", opacities=None, antialiased=False):
     """A.2 steps 1-5; differentiable in means/quats/scales/viewmat.  Returns dict with
-    radii (int, no grad), means2d, depths, conics, compensations (zeros where culled)."""
+    radii (int, no grad), means2d, depths, conics, compensations (zeros where culled).
+    radius_rule / opacities / antialiased: as gs_oracle_np.project (radii [N,2] under "opacity_aware")."""
     Rcw, tcw = viewmat[:3, :3], viewmat[:3, 3]
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     pc = means @ Rcw.T + tcw
@@ -64,12 +65,26 @@ def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_pla
     conic = torch.stack([c / dets, -b / dets, a / dets], dim=-1)
     m = 0.5 * (a + c)
     lam = m + torch.sqrt(torch.clamp(m * m - dets, min=0.01))
-    radius = torch.ceil(3.0 * torch.sqrt(lam)).detach()
-    valid = valid & (radius > radius_clip)
+    if radius_rule == "classic":
+        radius = torch.ceil(3.0 * torch.sqrt(lam)).detach()
+        radius_y = radius
+        valid = valid & (radius > radius_clip)
+    else:                                   # SURVEY.md A.4 (gsplat >= 1.5): per-axis, opacity-aware, not differentiable
+        ext = torch.full_like(lam, O.EXTENT_MAX)
+        if opacities is not None:
+            op = (opacities * comp if antialiased else opacities).detach()
+            ok = op >= 1.0 / 255.0
+            ext = torch.minimum(ext, torch.sqrt(2.0 * torch.log(torch.where(ok, op, torch.ones_like(op)) * 255.0)))
+            valid = valid & ok
+        radius = torch.ceil(ext * torch.sqrt(a)).detach()
+        radius_y = torch.ceil(ext * torch.sqrt(c)).detach()
+        valid = valid & ((radius > radius_clip) | (radius_y > radius_clip)) & (radius > 0) & (radius_y > 0)
     valid = valid & ~((mu[:, 0] + radius <= 0) | (mu[:, 0] - radius >= width)
-                      | (mu[:, 1] + radius <= 0) | (mu[:, 1] - radius >= height))
+                      | (mu[:, 1] + radius_y <= 0) | (mu[:, 1] - radius_y >= height))
     vf = valid.to(means.dtype)
-    return {"radii": torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32),
+    rr = radius if radius_rule == "classic" else torch.stack([radius, radius_y], dim=-1)
+    vr = valid if radius_rule == "classic" else valid[:, None]
+    return {"radii": torch.where(vr, rr, torch.zeros_like(rr)).to(torch.int32),
             "means2d": mu * vf[:, None], "depths": z * vf, "conics": conic * vf[:, None],
             "compensations": comp * vf}
 
@@ -157,13 +172,13 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
 
 def render(means, quats, scales, opacities, sh_or_colors, viewmat, K, width, height,
            sh_degree=None, tile_size=16, render_mode="RGB", eps2d=0.3, near_plane=0.01,
-           far_plane=1e10, radius_clip=0.0, background=None, rasterize_mode="classic"):
+           far_plane=1e10, radius_clip=0.0, background=None, rasterize_mode="classic", radius_rule="classic"):
     """Whole frame, differentiable w.r.t. means/quats/scales/opacities/colours/viewmat.
     The (integer) tile lists come from the NumPy oracle evaluated at the current values."""
     p = project(means, quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane,
-                radius_clip)
+                radius_clip, radius_rule=radius_rule, opacities=opacities, antialiased=rasterize_mode == "antialiased")
     opac = opacities * p["compensations"] if rasterize_mode == "antialiased" else opacities
-    vis = p["radii"] > 0
+    vis = p["radii"] > 0 if p["radii"].dim() == 1 else p["radii"][:, 0] > 0
     if sh_degree is None:
         rgb = sh_or_colors
     else:

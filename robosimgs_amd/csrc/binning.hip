@@ -39,14 +39,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 constexpr int kSum = 64;
 __global__ __launch_bounds__(kBlock) void tile_count_kernel(
     int n, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-    const float* __restrict__ conics, const float* __restrict__ opacities, float tile_size,
-    int tile_w, int tile_h, uint2* __restrict__ ginfo, uint32_t* __restrict__ sums) {
+    const int32_t* __restrict__ radii_y, const float* __restrict__ conics, const float* __restrict__ opacities,
+    float tile_size, int tile_w, int tile_h, uint2* __restrict__ ginfo, uint32_t* __restrict__ sums) {
   int g = blockIdx.x * kBlock + threadIdx.x;
   int radius = g < n ? radii[g] : 0;
   uint2 info = make_uint2(kEmptyTileRect, 0u);
   if (radius > 0) {
     float2 m = reinterpret_cast<const float2*>(means2d)[g];
-    TileRect r = tile_rect(m.x, m.y, radius, tile_size, tile_w, tile_h);
+    TileRect r = tile_rect(m.x, m.y, radius, radii_y ? radii_y[g] : radius, tile_size, tile_w, tile_h);
     if (conics)
       r = tighten_rect(r, m.x, m.y, conics[3 * (size_t)g], conics[3 * (size_t)g + 1],
                        conics[3 * (size_t)g + 2], opacities[g], tile_size);
@@ -646,7 +646,7 @@ int launch_tile_group_order(int n_tiles, const int32_t* tile_offsets, int32_t* o
 
 using namespace mgs;
 
-extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii,
+extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii, const int32_t* radii_y,
                                const float* depths, const float* conics, const float* opacities,
                                int tile_size, int tile_w, int tile_h,
                                int cam_id, int n_cams, uint32_t isect_capacity,
@@ -706,7 +706,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     if (!seed_info) {
       uint2* gi = reinterpret_cast<uint2*>(w + ws.ginfo);
       sums = u32(ws.blocksums);
-      hipLaunchKernelGGL(tile_count_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii, conics,
+      hipLaunchKernelGGL(tile_count_kernel, dim3(nblk), dim3(kBlock), 0, s, n, means2d, radii, radii_y, conics,
                          opacities, (float)tile_size, tile_w, tile_h, gi, sums);
       ginfo = gi;
     }

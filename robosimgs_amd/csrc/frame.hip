@@ -46,7 +46,7 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
   const int tile_w = (width + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE, tile_h = (height + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE;
   const int n_tiles = tile_w * tile_h;
   size_t isect_ws = 0;
-  int rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
+  int rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
                            isect_capacity, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr, nullptr, &isect_ws, stream);
   if (rc) return rc;
@@ -73,11 +73,12 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
     rc = mgs_project_color_fwd(n, means, quats, scales, opacities, sh_degree, coeff_stride, sh_coeffs,
                                viewmats + 16 * (size_t)c, Ks + 9 * (size_t)c, width, height, eps2d, near_plane, far_plane,
                                radius_clip, nullptr, nullptr, depths, nullptr, opac_aa, channels, nullptr, splats,
-                               (flags & MGS_FRAMES_CLASSIC_BOUNDS) ? 0 : 1 /* tight tile bounds: same pixels, shorter lists */,
-                               bin_info, bin_sums, stream);
+                               ((flags & MGS_FRAMES_CLASSIC_BOUNDS) ? 0 : MGS_BIN_TIGHT /* same pixels, shorter lists */) |
+                                   ((flags & MGS_FRAMES_RADIUS_OPACITY_AWARE) ? MGS_BIN_RADIUS_OPACITY_AWARE : 0),
+                               bin_info, bin_sums, nullptr, stream);
     if (rc) return rc;
     size_t iw = ws.isect_bytes;
-    rc = mgs_isect_tiles(n, nullptr, nullptr, depths, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
+    rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, depths, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
                          isect_capacity, nullptr, n_isect + c, nullptr, flatten, nullptr, offsets, nullptr, order,
                          status + c, bin_info, bin_sums, w + ws.isect, &iw, stream);
     if (rc) return rc;
@@ -99,7 +100,8 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
 // What rasterization() used to do with five ctypes calls and a dozen tensor allocations per camera.
 namespace {
 enum TrainField { TF_RADII, TF_MEANS2D, TF_DEPTHS, TF_CONICS, TF_OPAC, TF_FEATS, TF_SPLATS, TF_TILES_PER_GAUSS, TF_PAIR_INFO,
-                  TF_TILE_IDS, TF_FLATTEN, TF_OFFSETS, TF_ORDER, TF_LAST_IDS, TF_CKPT, TF_COUNTS, TF_FIELDS };
+                  TF_TILE_IDS, TF_FLATTEN, TF_OFFSETS, TF_ORDER, TF_LAST_IDS, TF_CKPT, TF_COUNTS, TF_RADII_Y, TF_FIELDS };
+static_assert(TF_FIELDS == MGS_TRAIN_FIELDS, "mgs.h: MGS_TRAIN_FIELDS");
 struct TrainState {
   size_t at[TF_FIELDS], total;
   TrainState(int n, int width, int height, int channels, uint32_t cap, bool antialiased, int interval) {
@@ -123,6 +125,7 @@ struct TrainState {
     take(TF_LAST_IDS, n_px * 4);
     take(TF_CKPT, interval ? mgs_raster_checkpoint_floats(cap, tile_w, tile_h, channels, interval) * 4 : 0);
     take(TF_COUNTS, 8);                      // n_isect, status
+    take(TF_RADII_Y, nn * 4);                // written under MGS_FRAMES_RADIUS_OPACITY_AWARE only
     total = o;
   }
 };
@@ -185,7 +188,7 @@ extern "C" int mgs_render_frames_train(int n, const float* means, const float* q
   MGS_REQUIRE(isect_capacity > 0, "render_frames_train: zero capacity");
   const int tile_w = (width + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE, tile_h = (height + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE;
   size_t isect_ws = 0;
-  int rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
+  int rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
                            isect_capacity, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr, nullptr, &isect_ws, stream);
   if (rc) return rc;
@@ -206,7 +209,8 @@ extern "C" int mgs_render_frames_train(int n, const float* means, const float* q
   uint32_t* bin_info = reinterpret_cast<uint32_t*>(w + ws.bin_info);
   uint32_t* bin_sums = reinterpret_cast<uint32_t*>(w + ws.bin_sums);
   const size_t n_px = (size_t)width * height;
-  const int tight = (flags & MGS_FRAMES_CLASSIC_BOUNDS) ? 0 : 1;
+  const int tight = ((flags & MGS_FRAMES_CLASSIC_BOUNDS) ? 0 : MGS_BIN_TIGHT) |
+                    ((flags & MGS_FRAMES_RADIUS_OPACITY_AWARE) ? MGS_BIN_RADIUS_OPACITY_AWARE : 0);
   for (int c = 0; c < n_cams; ++c) {
     char* s = static_cast<char*>(state) + st.total * (size_t)c;
     auto F = [&](int f) { return reinterpret_cast<float*>(s + st.at[f]); };
@@ -216,10 +220,10 @@ extern "C" int mgs_render_frames_train(int n, const float* means, const float* q
     rc = mgs_project_color_fwd(n, means, quats, scales, opacities, sh_degree, coeff_stride, sh_coeffs,
                                viewmats + 16 * (size_t)c, Ks + 9 * (size_t)c, width, height, eps2d, near_plane, far_plane,
                                radius_clip, I(TF_RADII), F(TF_MEANS2D), F(TF_DEPTHS), F(TF_CONICS), opac_aa, channels,
-                               F(TF_FEATS), F(TF_SPLATS), tight, bin_info, bin_sums, stream);
+                               F(TF_FEATS), F(TF_SPLATS), tight, bin_info, bin_sums, I(TF_RADII_Y), stream);
     if (rc) return rc;
     size_t iw = isect_ws;
-    rc = mgs_isect_tiles(n, nullptr, nullptr, F(TF_DEPTHS), nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, c, n_cams,
+    rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, F(TF_DEPTHS), nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, c, n_cams,
                          isect_capacity, I(TF_TILES_PER_GAUSS), U(TF_COUNTS), U(TF_TILE_IDS), I(TF_FLATTEN), nullptr,
                          I(TF_OFFSETS), I(TF_PAIR_INFO), I(TF_ORDER), U(TF_COUNTS) + 1, bin_info, bin_sums, w + ws.isect, &iw,
                          stream);

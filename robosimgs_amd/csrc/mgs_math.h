@@ -79,19 +79,31 @@ struct Projected {
   float depth;
   float conic[3];
   float compensation;
-  int radius;  // 0 = culled
+  int radius;    // 0 = culled; the extent along x under the per-axis rule
+  int radius_y;  // == radius under the classic rule
 };
+
+// The radius rule is a compile-time policy: every kernel passes it as a template constant.
+//   MGS_RADIUS_CLASSIC        gsplat 1.4 (A.2 step 5): one radius ceil(3 sqrt(lambda_1)), the square mean +- radius
+//   MGS_RADIUS_OPACITY_AWARE  gsplat >= 1.5: per-axis extents ceil(e sqrt(Sigma_xx)), ceil(e sqrt(Sigma_yy)) with
+//                             e = min(3.33, sqrt(2 ln(255 opacity))) -- the bounding box of the alpha >= 1/255 ellipse,
+//                             capped at 3.33 sigma; Gaussians of opacity < 1/255 are culled; opacity is multiplied by
+//                             the compensation in "antialiased" mode; without opacities e = 3.33
+#define MGS_RADIUS_CLASSIC 0
+#define MGS_RADIUS_OPACITY_AWARE 1
 
 // A.2 steps 1-5.  Returns radius == 0 for culled Gaussians (all other fields zeroed).
 MGS_HD Projected project_gaussian(const float mean[3], const float quat[4],
                                   const float scale[3], const CameraParams& cam, float W,
                                   float H, float eps2d, float near_plane, float far_plane,
-                                  float radius_clip) {
+                                  float radius_clip, int radius_rule = MGS_RADIUS_CLASSIC,
+                                  bool has_opacity = false, float opacity = 1.f, bool antialiased = false) {
   Projected out;
   out.mean2d[0] = out.mean2d[1] = out.depth = 0.f;
   out.conic[0] = out.conic[1] = out.conic[2] = 0.f;
   out.compensation = 0.f;
   out.radius = 0;
+  out.radius_y = 0;
 
   const float* R = cam.R;
   float x = R[0] * mean[0] + R[1] * mean[1] + R[2] * mean[2] + cam.t[0];
@@ -128,11 +140,26 @@ MGS_HD Projected project_gaussian(const float mean[3], const float quat[4],
   if (!(det > 0.f)) return out;
   float inv_det = 1.0f / det;
 
-  float m = 0.5f * (a + c);
-  float lam = m + sqrtf(fmaxf(0.01f, m * m - det));
-  float radius = ceilf(3.f * sqrtf(lam));
-  if (!(radius > radius_clip)) return out;
-  if (mx + radius <= 0.f || mx - radius >= W || my + radius <= 0.f || my - radius >= H)
+  float radius, radius_y;
+  if (radius_rule == MGS_RADIUS_OPACITY_AWARE) {
+    float extent = 3.33f;
+    if (has_opacity) {
+      const float op = antialiased ? opacity * sqrtf(fmaxf(0.f, det0 * inv_det)) : opacity;
+      if (!(op >= 1.0f / 255.0f)) return out;
+      extent = fminf(extent, sqrtf(2.f * logf(op * 255.0f)));
+    }
+    radius = ceilf(extent * sqrtf(a));
+    radius_y = ceilf(extent * sqrtf(c));
+    if (!(radius > radius_clip) && !(radius_y > radius_clip)) return out;
+    if (!(radius > 0.f) || !(radius_y > 0.f)) return out;            // an extent of exactly zero reaches no pixel
+  } else {
+    float m = 0.5f * (a + c);
+    float lam = m + sqrtf(fmaxf(0.01f, m * m - det));
+    radius = ceilf(3.f * sqrtf(lam));
+    radius_y = radius;
+    if (!(radius > radius_clip)) return out;
+  }
+  if (mx + radius <= 0.f || mx - radius >= W || my + radius_y <= 0.f || my - radius_y >= H)
     return out;
 
   out.mean2d[0] = mx;
@@ -143,6 +170,7 @@ MGS_HD Projected project_gaussian(const float mean[3], const float quat[4],
   out.conic[2] = a * inv_det;
   out.compensation = sqrtf(fmaxf(0.f, det0 * inv_det));
   out.radius = (int)radius;
+  out.radius_y = (int)radius_y;
   return out;
 }
 

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(kBlock) void projection_fwd_kernel(
     const float* __restrict__ Kmat, float W, float H, float eps2d, float near_plane,
     float far_plane, float radius_clip, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ conics,
-    float* __restrict__ compensations) {
+    float* __restrict__ compensations, const float* __restrict__ opacities, int radius_rule,
+    int32_t* __restrict__ radii_y) {
   int g = blockIdx.x * kBlock + threadIdx.x;
   if (g >= n) return;
   CameraParams cam = load_camera(viewmat, Kmat);
@@ -42,8 +43,10 @@ __global__ __launch_bounds__(kBlock) void projection_fwd_kernel(
   load3(scales + 3 * (size_t)g, s);
   float4 qq = reinterpret_cast<const float4*>(quats)[g];
   q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-  Projected p = project_gaussian(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
+  Projected p = project_gaussian(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip, radius_rule,
+                                 opacities != nullptr, opacities ? opacities[g] : 1.f, compensations != nullptr);
   radii[g] = p.radius;
+  if (radii_y) radii_y[g] = p.radius_y;
   reinterpret_cast<float2*>(means2d)[g] = make_float2(p.mean2d[0], p.mean2d[1]);
   depths[g] = p.depth;
   conics[3 * (size_t)g + 0] = p.conic[0];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void sh_fwd_kernel(
   colors[3 * (size_t)g + 2] = rgb[2];
 }
 
-template <int DEG, bool STAGED>
+template <int DEG, bool STAGED, int RULE>
 __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     int n, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, int stride_f,
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ conics,
     float* __restrict__ opac_out, int feat_stride, float* __restrict__ feats,
     float4* __restrict__ splats, uint2* __restrict__ bin_info, uint32_t* __restrict__ bin_sums,
-    int bin_tight, int tile_w, int tile_h) {
+    int bin_tight, int tile_w, int tile_h, int32_t* __restrict__ radii_y) {
   __shared__ float4 lds[STAGED ? (kBlock / kWave) * kWave * kShPitchF4 : 1];
   int g = blockIdx.x * kBlock + threadIdx.x;
   CameraParams cam = load_camera(viewmat, Kmat);
@@ -155,10 +158,15 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
     load3(scales + 3 * (size_t)g, s);
     float4 qq = reinterpret_cast<const float4*>(quats)[g];
     q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-    p = project_gaussian(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
+    if (RULE == MGS_RADIUS_CLASSIC)
+      p = project_gaussian(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip);
+    else
+      p = project_gaussian(m, q, s, cam, W, H, eps2d, near_plane, far_plane, radius_clip, RULE, opacities != nullptr,
+                           opacities ? opacities[g] : 1.f, opac_out != nullptr);
     // radii / means2d / conics (and feats below) are null in an inference frame: the raster reads the packed
     // records, the seeded binning reads bin_info + depths -- 36 MB of stores per 1 M Gaussians nobody would read
     if (radii) radii[g] = p.radius;
+    if (RULE != MGS_RADIUS_CLASSIC && radii_y) radii_y[g] = p.radius_y;
     if (means2d) reinterpret_cast<float2*>(means2d)[g] = make_float2(p.mean2d[0], p.mean2d[1]);
     depths[g] = p.depth;
     if (conics) {
@@ -175,7 +183,9 @@ __global__ __launch_bounds__(kBlock) void project_color_fwd_kernel(
   if (bin_info) {
     uint2 info = make_uint2(kEmptyTileRect, 0u);
     if (active) {
-      TileRect r = tile_rect(p.mean2d[0], p.mean2d[1], p.radius, (float)MGS_TILE_SIZE, tile_w, tile_h);
+      TileRect r = RULE == MGS_RADIUS_CLASSIC
+                       ? tile_rect(p.mean2d[0], p.mean2d[1], p.radius, (float)MGS_TILE_SIZE, tile_w, tile_h)
+                       : tile_rect(p.mean2d[0], p.mean2d[1], p.radius, p.radius_y, (float)MGS_TILE_SIZE, tile_w, tile_h);
       if (bin_tight)
         r = tighten_rect(r, p.mean2d[0], p.mean2d[1], p.conic[0], p.conic[1], p.conic[2],
                          opacities[g] * (opac_out ? p.compensation : 1.f), (float)MGS_TILE_SIZE);
@@ -231,15 +241,19 @@ extern "C" int mgs_projection_fwd(int n, const float* means, const float* quats,
                                   int width, int height, float eps2d, float near_plane,
                                   float far_plane, float radius_clip, int32_t* radii,
                                   float* means2d, float* depths, float* conics,
-                                  float* compensations, mgs_stream_t stream) {
+                                  float* compensations, const float* opacities, int radius_rule,
+                                  int32_t* radii_y, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "projection_fwd: bad sizes n=%d %dx%d", n, width, height);
   if (n == 0) return MGS_OK;
   MGS_REQUIRE(means && quats && scales && viewmat && K && radii && means2d && depths && conics,
               "projection_fwd: null pointer");
+  MGS_REQUIRE(radius_rule == MGS_RADIUS_CLASSIC || radius_rule == MGS_RADIUS_OPACITY_AWARE,
+              "projection_fwd: radius_rule %d is neither MGS_RADIUS_CLASSIC nor MGS_RADIUS_OPACITY_AWARE", radius_rule);
+  MGS_REQUIRE(radius_rule == MGS_RADIUS_CLASSIC || radii_y, "projection_fwd: the per-axis radius rule needs radii_y");
   hipLaunchKernelGGL(projection_fwd_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0,
                      (hipStream_t)stream, n, means, quats, scales, viewmat, K, (float)width,
                      (float)height, eps2d, near_plane, far_plane, radius_clip, radii, means2d,
-                     depths, conics, compensations);
+                     depths, conics, compensations, opacities, radius_rule, radii_y);
   return check_launch("projection_fwd");
 }
 
@@ -274,8 +288,10 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
                                      float far_plane, float radius_clip, int32_t* radii,
                                      float* means2d, float* depths, float* conics,
                                      float* opac_out, int feat_stride, float* feats,
-                                     float* splats, int bin_tight, uint32_t* bin_info,
-                                     uint32_t* bin_sums, mgs_stream_t stream) {
+                                     float* splats, int bin_flags, uint32_t* bin_info,
+                                     uint32_t* bin_sums, int32_t* radii_y, mgs_stream_t stream) {
+  const int bin_tight = bin_flags & MGS_BIN_TIGHT;
+  const bool per_axis = (bin_flags & MGS_BIN_RADIUS_OPACITY_AWARE) != 0;
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "project_color_fwd: bad sizes");
   MGS_REQUIRE(sh_degree >= 0 && sh_degree <= 3, "project_color_fwd: sh_degree %d not in 0..3", sh_degree);
   MGS_REQUIRE(coeff_stride >= (sh_degree + 1) * (sh_degree + 1), "project_color_fwd: coeff_stride too small");
@@ -290,6 +306,7 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
   MGS_REQUIRE(!splats || opacities, "project_color_fwd: splats needs opacities");
   MGS_REQUIRE((bin_info == nullptr) == (bin_sums == nullptr), "project_color_fwd: bin_info and bin_sums come together");
   MGS_REQUIRE(!(bin_info && bin_tight) || opacities, "project_color_fwd: tight tile bounds need opacities");
+  MGS_REQUIRE(!per_axis || !radii || radii_y, "project_color_fwd: the per-axis radius rule writes radii_y beside radii");
   const int tile_w = (width + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE, tile_h = (height + MGS_TILE_SIZE - 1) / MGS_TILE_SIZE;
   MGS_REQUIRE(!bin_info || (tile_w <= 1023 && tile_h <= 1023), "project_color_fwd: tile grid exceeds 1023x1023");
   dim3 grid(div_up(n, kBlock)), block(kBlock);
@@ -297,18 +314,21 @@ extern "C" int mgs_project_color_fwd(int n, const float* means, const float* qua
   int sf = coeff_stride * 3;
   bool staged = coeff_stride == 16 && sh_degree >= 2;
 #define MGS_PC_LAUNCH(D, S)                                                                   \
-  hipLaunchKernelGGL((project_color_fwd_kernel<D, S>), grid, block, 0, s, n, means, quats,    \
+  if (per_axis) MGS_PC_LAUNCH_R(D, S, MGS_RADIUS_OPACITY_AWARE); else MGS_PC_LAUNCH_R(D, S, MGS_RADIUS_CLASSIC)
+#define MGS_PC_LAUNCH_R(D, S, R)                                                              \
+  hipLaunchKernelGGL((project_color_fwd_kernel<D, S, R>), grid, block, 0, s, n, means, quats, \
                      scales, opacities, sf, sh_coeffs, viewmat, K, (float)width,              \
                      (float)height, eps2d, near_plane, far_plane, radius_clip, radii,         \
                      means2d, depths, conics, opac_out, feat_stride, feats,                    \
                      reinterpret_cast<float4*>(splats), reinterpret_cast<uint2*>(bin_info),     \
-                     bin_sums, bin_tight, tile_w, tile_h)
+                     bin_sums, bin_tight, tile_w, tile_h, radii_y)
   switch (sh_degree) {
     case 0: MGS_PC_LAUNCH(0, false); break;
     case 1: MGS_PC_LAUNCH(1, false); break;
-    case 2: if (staged) MGS_PC_LAUNCH(2, true); else MGS_PC_LAUNCH(2, false); break;
-    default: if (staged) MGS_PC_LAUNCH(3, true); else MGS_PC_LAUNCH(3, false); break;
+    case 2: if (staged) { MGS_PC_LAUNCH(2, true); } else { MGS_PC_LAUNCH(2, false); } break;
+    default: if (staged) { MGS_PC_LAUNCH(3, true); } else { MGS_PC_LAUNCH(3, false); } break;
   }
 #undef MGS_PC_LAUNCH
+#undef MGS_PC_LAUNCH_R
   return check_launch("project_color_fwd");
 }

@@ -9,18 +9,23 @@ namespace mgs {
 
 struct TileRect { int x0, y0, w, h; };
 
-// A.2 step 7: axis-aligned tile rectangle of the square mean2d +- radius
-__device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, float tile_size,
+// A.2 step 7: axis-aligned tile rectangle of mean2d +- (radius_x, radius_y) -- the square mean2d +- radius under the
+// classic radius rule, gsplat >= 1.5's per-axis box under MGS_RADIUS_OPACITY_AWARE (mgs_math.h)
+__device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius_x, int radius_y, float tile_size,
                                               int tile_w, int tile_h) {
   TileRect r;
-  float tr = (float)radius / tile_size;
+  float trx = (float)radius_x / tile_size, try_ = (float)radius_y / tile_size;
   float tx = mx / tile_size, ty = my / tile_size;
-  int x0 = min(max(0, (int)floorf(tx - tr)), tile_w);
-  int x1 = min(max(0, (int)ceilf(tx + tr)), tile_w);
-  int y0 = min(max(0, (int)floorf(ty - tr)), tile_h);
-  int y1 = min(max(0, (int)ceilf(ty + tr)), tile_h);
+  int x0 = min(max(0, (int)floorf(tx - trx)), tile_w);
+  int x1 = min(max(0, (int)ceilf(tx + trx)), tile_w);
+  int y0 = min(max(0, (int)floorf(ty - try_)), tile_h);
+  int y1 = min(max(0, (int)ceilf(ty + try_)), tile_h);
   r.x0 = x0; r.y0 = y0; r.w = x1 - x0; r.h = y1 - y0;
   return r;
+}
+__device__ __forceinline__ TileRect tile_rect(float mx, float my, int radius, float tile_size,
+                                              int tile_w, int tile_h) {
+  return tile_rect(mx, my, radius, radius, tile_size, tile_w, tile_h);
 }
 
 // Tiles that hold a pixel centre the Gaussian can reach with alpha >= 1/255: the bounding box of

@@ -35,31 +35,54 @@ def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
 # ======================================================================================
 # single-camera raw calls (no autograd); used by the operators below and by rendering.py
 # ======================================================================================
+RADIUS_RULES = {"classic": 0, "opacity_aware": 1}     # include/mgs.h MGS_RADIUS_CLASSIC / MGS_RADIUS_OPACITY_AWARE
+
+
+def radius_rule_id(radius_rule) -> int:
+    if radius_rule not in RADIUS_RULES:
+        raise ValueError(f"radius_rule {radius_rule!r} not in {tuple(RADIUS_RULES)}")
+    return RADIUS_RULES[radius_rule]
+
+
+def radii_x(radii):
+    """The per-Gaussian visibility / x-extent array of either radii layout: [N] (classic rule) or the planar [2,N]
+    pair of per-axis extents the raw calls keep under the opacity-aware rule."""
+    return radii if radii is None or radii.dim() == 1 else radii[0]
+
+
+def radii_meta(radii):
+    """Radii as the operator returns them: [N] (gsplat 1.4) or [N,2] (gsplat >= 1.5, per axis)."""
+    return radii if radii is None or radii.dim() == 1 else radii.t()
+
+
 def projection_fwd_raw(means, quats, scales, viewmat, K, width, height, eps2d, near_plane,
-                       far_plane, radius_clip, calc_compensations):
+                       far_plane, radius_clip, calc_compensations, opacities=None, radius_rule=0):
+    """radius_rule 1 (MGS_RADIUS_OPACITY_AWARE): radii comes back planar [2,N] (x extents, y extents)."""
     n = means.shape[0]
     dev = means.device
-    radii = torch.empty(n, dtype=torch.int32, device=dev)
+    radii = torch.empty((2, n) if radius_rule else (n,), dtype=torch.int32, device=dev)
     means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
     depths = torch.empty(n, dtype=torch.float32, device=dev)
     conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
     comp = torch.empty(n, dtype=torch.float32, device=dev) if calc_compensations else None
     check(_lib.lib().mgs_projection_fwd(n, ptr(means), ptr(quats), ptr(scales), ptr(viewmat),
                                         ptr(K), width, height, eps2d, near_plane, far_plane,
-                                        radius_clip, ptr(radii), ptr(means2d), ptr(depths),
-                                        ptr(conics), ptr(comp), stream_handle()),
+                                        radius_clip, ptr(radii_x(radii)), ptr(means2d), ptr(depths),
+                                        ptr(conics), ptr(comp), ptr(opacities) if radius_rule else None,
+                                        int(radius_rule), ptr(radii[1]) if radius_rule else None, stream_handle()),
           "mgs_projection_fwd")
     return radii, means2d, depths, conics, comp
 
 
 def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmat, K,
                           width, height, eps2d, near_plane, far_plane, radius_clip,
-                          antialiased, with_depth, want_splats=False, bin_seed=None, lean=False):
+                          antialiased, with_depth, want_splats=False, bin_seed=None, lean=False, per_axis=False):
     """Returns (radii, means2d, depths, conics, opac_aa|None, feats) and, with want_splats, a 7th
     item: the packed [N,12] records the raster kernels gather from.  bin_seed = "tight" | "classic":
     an 8th item (seed_info [N,2] i32, seed_sums [ceil(N/64)] i32) for isect_tiles_raw(seed=...).
     lean (needs want_splats and bin_seed): radii / means2d / conics / feats are not written and come back
-    as None -- an inference frame, whose raster reads the records and whose binning reads the seed."""
+    as None -- an inference frame, whose raster reads the records and whose binning reads the seed.
+    per_axis: project with MGS_RADIUS_OPACITY_AWARE; radii is then planar [2,N] (radii_x / radii_meta)."""
     n = means.shape[0]
     dev = means.device
     if lean and not (want_splats and bin_seed is not None):
@@ -67,7 +90,7 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
     stride = 4 if with_depth else 3
     radii = means2d = conics = feats = None
     if not lean:
-        radii = torch.empty(n, dtype=torch.int32, device=dev)
+        radii = torch.empty((2, n) if per_axis else (n,), dtype=torch.int32, device=dev)
         means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
         conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
         feats = torch.empty(n, stride, dtype=torch.float32, device=dev)
@@ -81,9 +104,10 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
     check(_lib.lib().mgs_project_color_fwd(
         n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), sh_degree, sh_coeffs.shape[1],
         ptr(sh_coeffs), ptr(viewmat), ptr(K), width, height, eps2d, near_plane, far_plane,
-        radius_clip, ptr(radii), ptr(means2d), ptr(depths), ptr(conics), ptr(opac), stride,
-        ptr(feats), ptr(splats), int(bin_seed == "tight"), ptr(seed[0]) if seed else None,
-        ptr(seed[1]) if seed else None, stream_handle()), "mgs_project_color_fwd")
+        radius_clip, ptr(radii_x(radii)), ptr(means2d), ptr(depths), ptr(conics), ptr(opac), stride,
+        ptr(feats), ptr(splats), int(bin_seed == "tight") | (2 if per_axis else 0), ptr(seed[0]) if seed else None,
+        ptr(seed[1]) if seed else None, ptr(radii[1]) if (per_axis and radii is not None) else None, stream_handle()),
+        "mgs_project_color_fwd")
     out = (radii, means2d, depths, conics, opac, feats)
     if want_splats or bin_seed is not None:
         out = out + (splats,)
@@ -120,7 +144,8 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     """conics + opacities given: tile rectangles tightened to the tiles a Gaussian can reach with
     alpha >= 1/255 (shorter lists, bit-identical render); None: gsplat's classic rectangles.
     seed = (seed_info, seed_sums) from project_color_fwd_raw(bin_seed=...): the rectangles come from
-    there (means2d / radii / conics / opacities are then not read and may be None; seed_sums is consumed)."""
+    there (means2d / radii / conics / opacities are then not read and may be None; seed_sums is consumed).
+    radii: [N], or planar [2,N] per-axis extents (gsplat >= 1.5's rule)."""
     n = depths.shape[0]
     dev = depths.device
     L = _lib.lib()
@@ -138,7 +163,8 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     # launch order of the raster kernels' tiles (groups of four, longest lists first): a schedule, not a result
     out.group_order = (torch.empty((tile_w * tile_h + 3) // 4, dtype=torch.int32, device=dev) if want_group_order else None)
     nbytes = ctypes.c_size_t(0)
-    args = [n, ptr(means2d), ptr(radii), ptr(depths), ptr(conics), ptr(opacities), TILE_SIZE,
+    args = [n, ptr(means2d), ptr(radii_x(radii)), ptr(radii[1]) if (radii is not None and radii.dim() == 2) else None,
+            ptr(depths), ptr(conics), ptr(opacities), TILE_SIZE,
             tile_w, tile_h, cam_id, n_cams,
             capacity, ptr(out.tiles_per_gauss), ptr(out.n_isect), ptr(out.tile_ids),
             ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.pair_info),
@@ -154,7 +180,7 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height,
                       eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth, capacity,
-                      backgrounds=None, expected_last=False, latency=False, out=None, tight=True):
+                      backgrounds=None, expected_last=False, latency=False, out=None, tight=True, per_axis=False):
     """mgs_render_frames: C inference frames in one C call (no per-Gaussian outputs, scratch reused from camera to
     camera).  viewmats [C,4,4], Ks [C,3,3], backgrounds [C,ch] or None.  Returns (render [C,H,W,ch], alphas [C,H,W],
     n_isects [C] i32, isect_status [C] i32); out = (render, alphas) to write into existing buffers.
@@ -173,7 +199,8 @@ def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, vie
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), int(sh_degree), sh_coeffs.shape[1], ptr(sh_coeffs),
             C, ptr(viewmats), ptr(Ks), int(width), int(height), eps2d, near_plane, far_plane, radius_clip,
-            int(bool(antialiased)), ch, int(bool(expected_last)) | (2 if latency else 0) | (0 if tight else 4),
+            int(bool(antialiased)), ch,
+            int(bool(expected_last)) | (2 if latency else 0) | (0 if tight else 4) | (8 if per_axis else 0),
             ptr(backgrounds),
             int(capacity), ptr(render), ptr(alphas), ptr(n_isect), ptr(status)]
     check(L.mgs_render_frames(*args, None, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames(size query)")
@@ -194,7 +221,7 @@ def checkpoint_buffer(capacity: int, tile_w: int, tile_h: int, channels: int, in
 
 
 TRAIN_FIELDS = ("radii", "means2d", "depths", "conics", "opac_aa", "feats", "splats", "tiles_per_gauss", "pair_info",
-                "tile_ids", "flatten_ids", "tile_offsets", "group_order", "last_ids", "checkpoints", "counts")
+                "tile_ids", "flatten_ids", "tile_offsets", "group_order", "last_ids", "checkpoints", "counts", "radii_y")
 
 
 class TrainState:
@@ -225,7 +252,7 @@ class TrainState:
                   "tiles_per_gauss": (torch.int32, (n,)), "pair_info": (torch.int32, (n, 4)), "tile_ids": (torch.int32, (cap,)),
                   "flatten_ids": (torch.int32, (cap,)), "tile_offsets": (torch.int32, (nt + 1,)),
                   "group_order": (torch.int32, ((nt + 3) // 4,)), "last_ids": (torch.int32, (self.height, self.width)),
-                  "counts": (torch.int32, (2,))}
+                  "counts": (torch.int32, (2,)), "radii_y": (torch.int32, (n,))}
         out = {}
         base = self.pad + self.per_camera * c
         for name, off in zip(TRAIN_FIELDS, self.offsets):
@@ -258,7 +285,7 @@ def _aligned_ws(nbytes, dev):
 
 def render_frames_train_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d,
                             near_plane, far_plane, radius_clip, antialiased, with_depth, capacity, interval,
-                            backgrounds=None, expected_last=False, latency=True, tight=True, out=None):
+                            backgrounds=None, expected_last=False, latency=True, tight=True, out=None, per_axis=False):
     """mgs_render_frames_train: C training frames in one C call.  Returns (render [C,H,W,ch], alphas [C,H,W], TrainState)."""
     dev = means.device
     C, n = viewmats.shape[0], means.shape[0]
@@ -269,7 +296,7 @@ def render_frames_train_raw(means, quats, scales, opacities, sh_degree, sh_coeff
     else:
         render, alphas = out
     st = TrainState(n, C, width, height, ch, capacity, antialiased, interval, dev)
-    flags = int(bool(expected_last)) | (2 if latency else 0) | (0 if tight else 4)
+    flags = int(bool(expected_last)) | (2 if latency else 0) | (0 if tight else 4) | (8 if per_axis else 0)
     L = _lib.lib()
     nbytes = ctypes.c_size_t(0)
     args = [n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), int(sh_degree), sh_coeffs.shape[1], ptr(sh_coeffs), C,
@@ -410,20 +437,21 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
 class _Projection(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
-                far_plane, radius_clip, calc_compensations):
+                far_plane, radius_clip, calc_compensations, opacities=None, radius_rule=0):
         C = viewmats.shape[0]
         outs = [projection_fwd_raw(means, quats, scales, viewmats[c], Ks[c], width, height,
                                    eps2d, near_plane, far_plane, radius_clip,
-                                   calc_compensations) for c in range(C)]
-        radii = torch.stack([o[0] for o in outs])
+                                   calc_compensations, opacities, radius_rule) for c in range(C)]
+        radii_out = torch.stack([radii_meta(o[0]) for o in outs])      # [C,N], or [C,N,2] under the per-axis rule
+        radii = torch.stack([radii_x(o[0]) for o in outs])             # [C,N]: > 0 = visible (what the backward reads)
         means2d = torch.stack([o[1] for o in outs])
         depths = torch.stack([o[2] for o in outs])
         conics = torch.stack([o[3] for o in outs])
         comps = torch.stack([o[4] for o in outs]) if calc_compensations else None
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics, comps)
         ctx.dims = (width, height, eps2d)
-        ctx.mark_non_differentiable(radii)
-        return radii, means2d, depths, conics, comps
+        ctx.mark_non_differentiable(radii_out)
+        return radii_out, means2d, depths, conics, comps
 
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps):
@@ -447,7 +475,7 @@ class _Projection(torch.autograd.Function):
                 ptr(v_scales), ptr(v_viewmats[c]) if want_view else None, stream_handle()),
                 "mgs_projection_bwd")
         return (v_means, v_quats, v_scales, v_viewmats, None, None, None, None, None, None,
-                None, None)
+                None, None, None, None)
 
 
 def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Tensor,
@@ -455,11 +483,15 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Tenso
                            height: int, eps2d: float = 0.3, near_plane: float = 0.01,
                            far_plane: float = 1e10, radius_clip: float = 0.0,
                            packed: bool = False, sparse_grad: bool = False,
-                           calc_compensations: bool = False
+                           calc_compensations: bool = False, opacities: Optional[Tensor] = None,
+                           radius_rule: str = "classic"
                            ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Optional[Tensor]]:
     """World -> screen EWA projection of N Gaussians for C cameras.
     Returns radii [C,N] i32, means2d [C,N,2], depths [C,N], conics [C,N,3],
-    compensations [C,N] | None."""
+    compensations [C,N] | None.
+    radius_rule: "classic" (gsplat 1.4, SURVEY.md A.2 step 5: one radius ceil(3 sqrt(lambda_1))) or "opacity_aware"
+    (gsplat >= 1.5, SURVEY.md A.4: per-axis extents min(3.33, sqrt(2 ln(255 opacity))) sqrt(Sigma_ii), radii [C,N,2];
+    `opacities` [N] optional as in that operator, no gradient flows to it -- the extent is not differentiable)."""
     if covars is not None:
         raise NotImplementedError("precomputed covariances are not supported; pass quats+scales")
     if packed:
@@ -472,9 +504,15 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Tenso
         raise ValueError("expected means [N,3], quats [N,4], scales [N,3]")
     if viewmats.dim() != 3 or viewmats.shape[1:] != (4, 4) or Ks.shape != (viewmats.shape[0], 3, 3):
         raise ValueError("expected viewmats [C,4,4], Ks [C,3,3]")
+    rule = radius_rule_id(radius_rule)
+    if opacities is not None:
+        require_device(opacities)
+        opacities = _f32c(opacities.detach())
+        if opacities.shape != (means.shape[0],):
+            raise ValueError("expected opacities [N]")
     return _Projection.apply(means, quats, scales, viewmats, Ks, int(width), int(height),
                              float(eps2d), float(near_plane), float(far_plane),
-                             float(radius_clip), bool(calc_compensations))
+                             float(radius_clip), bool(calc_compensations), opacities if rule else None, rule)
 
 
 class _SphericalHarmonics(torch.autograd.Function):
@@ -526,6 +564,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
                 gaussian_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """Tile intersection + sort.  Returns tiles_per_gauss [C,N] i32, isect_ids [n_isects] i64
     (cam | tile | depth bits, ascending), flatten_ids [n_isects] i32 (cam*N + gaussian).
+    radii [C,N] (one radius: the square mean +- radius) or [C,N,2] (per-axis extents, gsplat >= 1.5).
     Reads the intersection count back to size the outputs (one sync, as the reference
     operator does); the render path in rendering.py avoids that with a capacity."""
     if packed or not sort:
@@ -535,7 +574,12 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
     require_device(means2d, radii, depths)
     C, N = means2d.shape[0], means2d.shape[1]
     means2d, depths = _f32c(means2d), _f32c(depths)
-    radii = radii.to(torch.int32).contiguous()
+    radii = radii.to(torch.int32)
+    if radii.dim() == 3:
+        if radii.shape[-1] != 2:
+            raise ValueError("expected radii [C,N] or [C,N,2]")
+        radii = radii.transpose(1, 2)                # planar [C,2,N] for the raw call
+    radii = radii.contiguous()
     tpg, keys, ids = [], [], []
     for c in range(C):
         cap = max(1, int(_upper_bound_isects(radii[c], tile_width, tile_height)))
@@ -549,12 +593,14 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int,
 
 
 def _upper_bound_isects(radii_c: Tensor, tile_w: int, tile_h: int) -> int:
-    """Cheap device-side bound: sum over visible Gaussians of min((2r/16+2)^2, tiles)."""
-    r = radii_c.clamp_min(0).to(torch.float32)
-    side = torch.floor(2.0 * r / TILE_SIZE) + 2.0
-    per = torch.minimum(side.clamp_max(tile_w) * side.clamp_max(tile_h),
-                        torch.tensor(float(tile_w * tile_h), device=r.device))
-    return int(torch.where(radii_c > 0, per, torch.zeros_like(per)).sum().item())
+    """Cheap device-side bound: sum over visible Gaussians of min((2r/16+2)^2, tiles); radii_c [N] or planar [2,N]."""
+    rx = radii_x(radii_c).clamp_min(0).to(torch.float32)
+    ry = rx if radii_c.dim() == 1 else radii_c[1].clamp_min(0).to(torch.float32)
+    side_x = torch.floor(2.0 * rx / TILE_SIZE) + 2.0
+    side_y = torch.floor(2.0 * ry / TILE_SIZE) + 2.0
+    per = torch.minimum(side_x.clamp_max(tile_w) * side_y.clamp_max(tile_h),
+                        torch.tensor(float(tile_w * tile_h), device=rx.device))
+    return int(torch.where(radii_x(radii_c) > 0, per, torch.zeros_like(per)).sum().item())
 
 
 @torch.no_grad()

@@ -60,6 +60,8 @@ class _RenderSH(torch.autograd.Function):
                 latency, lean, segment):
         C = viewmats.shape[0]
         dev = means.device
+        # `tight` carries the binning policy: bit 0 tightened tile rectangles, bit 1 the per-axis (gsplat >= 1.5) radius rule
+        per_axis, tight = bool(int(tight) & 2), bool(int(tight) & 1)
         tile_w, tile_h = -(-width // TILE_SIZE), -(-height // TILE_SIZE)
         ch = 4 if with_depth else 3
         render = torch.empty(C, height, width, ch, dtype=torch.float32, device=dev)
@@ -78,7 +80,7 @@ class _RenderSH(torch.autograd.Function):
             _, _, n_isects, status = ops.render_frames_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d,
                 near_plane, far_plane, radius_clip, antialiased, with_depth, isect_capacity, backgrounds=backgrounds,
-                expected_last=expected_depth, latency=latency, out=(render, alphas), tight=tight)
+                expected_last=expected_depth, latency=latency, out=(render, alphas), tight=tight, per_axis=per_axis)
             meta_out["lean"] = dict(n_isects=n_isects, isect_status=status)
             ctx.set_materialize_grads(False)
             return render, alphas.unsqueeze(-1)
@@ -88,11 +90,11 @@ class _RenderSH(torch.autograd.Function):
             _, _, st = ops.render_frames_train_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d, near_plane,
                 far_plane, radius_clip, antialiased, with_depth, isect_capacity, segment, backgrounds=backgrounds,
-                expected_last=expected_depth, latency=latency, tight=tight, out=(render, alphas))
+                expected_last=expected_depth, latency=latency, tight=tight, out=(render, alphas), per_axis=per_axis)
             per_cam = []
             for c in range(C):
                 v = st.views(c)
-                per_cam.append((v["radii"], v["means2d"], v["depths"], v["conics"], v["opac_aa"] if antialiased else None,
+                per_cam.append((torch.stack([v["radii"], v["radii_y"]]) if per_axis else v["radii"], v["means2d"], v["depths"], v["conics"], v["opac_aa"] if antialiased else None,
                                 v["feats"], st.tile_lists(c, v), v["splats"], None))
             ctx.train_state = st
             ctx.expected_depth = bool(expected_depth)
@@ -110,7 +112,7 @@ class _RenderSH(torch.autograd.Function):
             radii, means2d, depths, conics, opac_aa, feats, splats, seed = ops.project_color_fwd_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats[c], Ks[c], width,
                 height, eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth,
-                want_splats=True, bin_seed="tight" if tight else "classic", lean=lean)
+                want_splats=True, bin_seed="tight" if tight else "classic", lean=lean, per_axis=per_axis)
             opac = opac_aa if antialiased else opacities
             cap = isect_capacity
             if cap is None:
@@ -211,7 +213,7 @@ class _RenderSH(torch.autograd.Function):
             check(L.mgs_project_color_bwd(
                 n, ptr(means), ptr(quats), ptr(scales), ptr(opacities), sh_degree,
                 sh_coeffs.shape[1], ptr(sh_coeffs), ptr(viewmats[c]), ptr(Ks[c]), width, height,
-                eps2d, ptr(radii), ptr(conics), int(antialiased), feats.shape[1], ptr(feats),
+                eps2d, ptr(ops.radii_x(radii)), ptr(conics), int(antialiased), feats.shape[1], ptr(feats),
                 ptr(v_feats), ptr(v_means2d), ptr(v_conics), None,
                 ptr(v_opac) if antialiased else None, ptr(v_means), ptr(v_quats), ptr(v_scales),
                 ptr(v_sh), ptr(v_opacities),
@@ -249,8 +251,15 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                   tile_bounds: str = "tight",
                   raster_schedule: str = "latency",
                   lean_meta: bool = False,
-                  backward_segment: int = 256) -> Tuple[Tensor, Tensor, Dict]:
+                  backward_segment: int = 256,
+                  radius_rule: str = "classic") -> Tuple[Tensor, Tensor, Dict]:
     """Render N Gaussians from C cameras.
+
+    radius_rule: "classic" -- gsplat 1.4's single radius ceil(3 sqrt(lambda_1)) per Gaussian (the
+    semantics this build's parity claim is made for) -- or "opacity_aware" -- gsplat >= 1.5's per-axis extents
+    min(3.33, sqrt(2 ln(255 opacity))) sqrt(Sigma_ii): meta["radii"] is then [C,N,2], Gaussians of
+    opacity < 1/255 are culled, n_isect shrinks and pixels change in the corners of the classic square and beyond
+    3 sigma of opaque Gaussians.  A compile-time policy of the projection kernels (both instantiations ship).
 
     backward_segment (SH path, when gradients are wanted): list entries per unit of work of the backward raster
     (a power of two >= 64; 0 = one unit per tile, the whole-list walk).  The training forward stores per-pixel
@@ -288,6 +297,7 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
         raise NotImplementedError(f"tile_size must be {TILE_SIZE}")
     if tile_bounds not in ("tight", "classic"):
         raise ValueError(f"tile_bounds {tile_bounds!r} not in ('tight', 'classic')")
+    rule = ops.radius_rule_id(radius_rule)
     if backward_segment and (backward_segment < 64 or backward_segment & (backward_segment - 1)):
         raise ValueError(f"backward_segment {backward_segment} is not 0 or a power of two >= 64")
     if raster_schedule not in ("latency", "throughput"):
@@ -331,7 +341,7 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, width, height,
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store,
-            tile_bounds == "tight", render_mode in ("RGB+ED", "ED"), raster_schedule == "latency",
+            int(tile_bounds == "tight") | (2 if rule else 0), render_mode in ("RGB+ED", "ED"), raster_schedule == "latency",
             bool(lean_meta), int(backward_segment))
         if depth_only_via_sh:
             render = render[..., 3:4]
@@ -347,7 +357,7 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             return xs[0] if len(xs) == 1 else torch.cat(xs)
         if per_cam[0][0] is not None:        # (a lean frame has none of these)
             meta.update(
-                radii=_stk([p[0] for p in per_cam]),
+                radii=_stk([ops.radii_meta(p[0]) for p in per_cam]),
                 means2d=_stk([p[1] for p in per_cam]),
                 conics=_stk([p[3] for p in per_cam]),
                 tiles_per_gauss=_stk([p[6].tiles_per_gauss for p in per_cam]))
@@ -371,7 +381,8 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                 "(sh_degree given with [N,K,3] coefficients); drop isect_capacity for per-Gaussian features")
         radii, means2d, depths, conics, comps = ops.fully_fused_projection(
             means, None, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
-            radius_clip, calc_compensations=antialiased)
+            radius_clip, calc_compensations=antialiased, opacities=opacities if rule else None,
+            radius_rule=radius_rule)
         opac = opacities.unsqueeze(0).expand(C, N)
         if antialiased:
             opac = opac * comps

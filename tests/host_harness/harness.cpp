@@ -21,6 +21,22 @@ extern "C" void hh_project(int n, const float* means, const float* quats, const 
   }
 }
 
+// the per-axis, opacity-aware radius rule (mgs_math.h MGS_RADIUS_OPACITY_AWARE); opacities nullable
+extern "C" void hh_project_rule(int n, const float* means, const float* quats, const float* scales,
+                                const float* viewmat, const float* K, int W, int H, float eps2d,
+                                float near_plane, float far_plane, float radius_clip, const float* opacities,
+                                int antialiased, int* radii_x, int* radii_y, float* means2d) {
+  CameraParams cam = load_camera(viewmat, K);
+  for (int g = 0; g < n; ++g) {
+    Projected p = project_gaussian(means + 3 * g, quats + 4 * g, scales + 3 * g, cam, (float)W, (float)H, eps2d,
+                                   near_plane, far_plane, radius_clip, MGS_RADIUS_OPACITY_AWARE, opacities != nullptr,
+                                   opacities ? opacities[g] : 1.f, antialiased != 0);
+    radii_x[g] = p.radius;
+    radii_y[g] = p.radius_y;
+    means2d[2 * g] = p.mean2d[0]; means2d[2 * g + 1] = p.mean2d[1];
+  }
+}
+
 extern "C" void hh_project_vjp(int n, const float* means, const float* quats, const float* scales,
                                const float* viewmat, const float* K, int W, int H, float eps2d,
                                const int* radii, const float* conics, const float* comps,

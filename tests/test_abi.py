@@ -118,7 +118,7 @@ def test_host_side_size_queries_need_no_gpu():
     need = {"radii": 4 * N, "means2d": 8 * N, "depths": 4 * N, "conics": 12 * N, "opac_aa": 0, "feats": 4 * ch * N,
             "splats": 48 * N, "tiles_per_gauss": 4 * N, "pair_info": 16 * N, "tile_ids": 4 * cap, "flatten_ids": 4 * cap,
             "tile_offsets": 4 * (tw * th + 1), "group_order": 4 * ((tw * th + 3) // 4), "last_ids": 4 * W * H,
-            "checkpoints": 4 * n, "counts": 8}
+            "checkpoints": 4 * n, "counts": 8, "radii_y": 4 * N}
     names = list(ops.TRAIN_FIELDS)
     for a, b in zip(names, names[1:] + [None]):
         end = o[b] if b else per.value

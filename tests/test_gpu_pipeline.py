@@ -153,8 +153,13 @@ def test_projection_refuses_null_outputs_without_their_substitutes():
     # radii NULL but no splats / bin_info: an argument error, not a fault
     rc = L.mgs_project_color_fwd(4, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, 1, z.data_ptr(),
                                  z.data_ptr(), z.data_ptr(), 16, 16, 0.3, 0.01, 1e10, 0.0, None, None, z.data_ptr(),
-                                 None, None, 3, None, None, 0, None, None, None)
+                                 None, None, 3, None, None, 0, None, None, None, None)
     assert rc == -1 and b"may be NULL only" in L.mgs_last_error_string()
+    # the per-axis radius rule writes two arrays: radii without radii_y is refused as well
+    rc = L.mgs_project_color_fwd(4, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, 1, z.data_ptr(),
+                                 z.data_ptr(), z.data_ptr(), 16, 16, 0.3, 0.01, 1e10, 0.0, z.data_ptr(), z.data_ptr(),
+                                 z.data_ptr(), z.data_ptr(), None, 3, z.data_ptr(), None, 2, None, None, None, None)
+    assert rc == -1 and b"radii_y" in L.mgs_last_error_string()
 
 
 def test_batched_cameras_through_one_call_equal_the_per_camera_frames():

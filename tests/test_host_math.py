@@ -51,6 +51,38 @@ def _run_project(hh, g, cam, w, h):
     return radii, m2d, dep, con, comp
 
 
+@pytest.mark.parametrize("antialiased,with_opacity", [(False, True), (True, True), (False, False)])
+def test_projection_opacity_aware_radius_rule_matches_oracle(hh, antialiased, with_opacity):
+    """the gsplat >= 1.5 radius rule as the device math compiles it -- per-axis extents
+    min(3.33, sqrt(2 ln(255 o))) sqrt(Sigma_ii), cull below 1/255 -- against the NumPy restatement."""
+    g, cam, w, h = _scene(n=4000)
+    n = len(g)
+    op = _f(g.opacities)
+    op[::7] = 0.003                      # below 1/255: culled by the rule
+    op[1::7] = 0.0045                    # barely above: tiny extents
+    rx, ry, m2d = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
+    vm, K = _f(cam.viewmat()), _f(cam.K)
+    hh.hh_project_rule(n, _p(_f(g.means)), _p(_f(g.quats)), _p(_f(g.scales)), _p(vm), _p(K), w, h,
+                       ctypes.c_float(0.3), ctypes.c_float(0.01), ctypes.c_float(1e10), ctypes.c_float(0.0),
+                       _p(op) if with_opacity else None, int(antialiased), _p(rx), _p(ry), _p(m2d))
+    ref = O.project(g.means, g.quats, g.scales, cam.viewmat(), cam.K, w, h, radius_rule="opacity_aware",
+                    opacities=op.astype(np.float64) if with_opacity else None, antialiased=antialiased)
+    rr = ref["radii"]
+    assert rr.shape == (n, 2) and (rr[:, 0] > 0).sum() > 500
+    assert ((rx > 0) == (ry > 0)).all()                              # both extents or neither
+    assert ((rx > 0) != (rr[:, 0] > 0)).sum() <= 1
+    both = (rx > 0) & (rr[:, 0] > 0)
+    assert (np.abs(rx[both] - rr[both, 0]) > 0).sum() + (np.abs(ry[both] - rr[both, 1]) > 0).sum() <= 3   # ceil knife edges
+    assert np.abs(np.stack([rx, ry], -1)[both] - rr[both]).max() <= 1
+    if with_opacity:
+        assert not (rx[::7] > 0).any()                              # opacity < 1/255
+        cl = O.project(g.means, g.quats, g.scales, cam.viewmat(), cam.K, w, h)
+        vis = both & (cl["radii"] > 0)
+        # the opacity-aware box never exceeds 3.33 / 3 of the classic radius (sqrt(Sigma_ii) <= sqrt(lambda_1))
+        assert (np.maximum(rx, ry)[vis] <= np.ceil(cl["radii"][vis] * (3.33 / 3.0)) + 1).all()
+        assert np.maximum(rx, ry)[vis].astype(np.int64).sum() < 0.9 * cl["radii"][vis].astype(np.int64).sum()
+
+
 def test_projection_forward_matches_oracle(hh):
     g, cam, w, h = _scene()
     radii, m2d, dep, con, comp = _run_project(hh, g, cam, w, h)
