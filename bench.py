@@ -431,6 +431,39 @@ def main():
         assert status_given == 0
         del fr
         fr = fr_main
+    # "make the radius rule a compile-time policy so the tighter one can be benchmarked" -- the same frames
+    # with gsplat >= 1.5's per-axis opacity-aware extents instead of A.2 step 5's radius (N = 1 only; a quarter of the span).
+    # NOT the headline: the rule changes edge pixels, the parity claim is made for the classic rule.
+    rule_leg = None
+    if not ring and not a.no_reorder:
+        # (a renderer built late in the process runs ~10 % slower than the first one whatever it renders -- where its
+        #  buffers land --, so the classic rule is timed again beside it, the two renderers built back to back and
+        #  taking turns; scripts/dbg/radius_rule_ab.py does the same over all four rule x bounds combinations)
+        fr_main, keep = fr, a.min_seconds
+        n_classic = max(int(s_["meta"]["n_isects"].max().item()) for s_ in fr._slots)
+        pair = {"opacity_aware": FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap,
+                                               radius_rule="opacity_aware"),
+                "classic": FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap)}
+        a.min_seconds = keep / 8
+        rates = {k: [] for k in pair}
+        for _ in range(2):
+            for k in pair:
+                fr = pair[k]
+                r_regions, _ = time_frames(g_mode)
+                rates[k].append(a.steps / float(np.median(r_regions)))
+        a.min_seconds = keep
+        assert max(int(s_["meta"]["isect_status"].max().item()) for f_ in pair.values() for s_ in f_._slots) == 0
+        rule_leg = {"frames_per_s": round(max(rates["opacity_aware"]), 2),
+                    "frames_per_s_classic_rule_same_harness": round(max(rates["classic"]), 2),
+                    "n_isect": max(int(s_["meta"]["n_isects"].max().item()) for s_ in pair["opacity_aware"]._slots),
+                    "n_isect_classic_rule_tight_rectangles": n_classic, "n_isect_classic_rule_classic_rectangles": n_isect,
+                    "note": "rasterization(radius_rule='opacity_aware'): extents min(3.33, sqrt(2 ln(255 o))) sqrt(Sigma_ii) per axis "
+                            "(gsplat >= 1.5); with opacities the box is the bounding box of the alpha >= 1/255 ellipse, i.e. what "
+                            "the tightened rectangles of the classic rule already cut the lists down to, plus the pairs the "
+                            "classic square never had (beyond 3 sigma of opaque Gaussians); two late-built renderers taking "
+                            "turns, best of two regions each -- compare the two figures with each other, not with `value`"}
+        del pair
+        fr = fr_main
     # single-frame latency (one slot, nothing else in flight), for reference
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -502,6 +535,7 @@ def main():
                                    "FrameRenderer's own copy in Morton order of the means (sorted once at construction; same "
                                    "image except where two Gaussians of a pixel tie in depth to the last bit)"),
                    "frames_per_s_scene_in_given_order": (round(total_frames / given_order, 2) if given_order else None),
+                   "radius_rule_opacity_aware": rule_leg,
                    "timing": f"median of {len(regions)} regions of {a.steps} steps, each bracketed by "
                              f"barrier + synchronize, MAX over ranks (min {min(regions) * 1e3:.2f} ms, "
                              f"max {max(regions) * 1e3:.2f} ms per region)"},
