@@ -436,9 +436,8 @@ def main():
     # NOT the headline: the rule changes edge pixels, the parity claim is made for the classic rule.
     rule_leg = None
     if not ring and not a.no_reorder:
-        # (a renderer built late in the process runs ~10 % slower than the first one whatever it renders -- where its
-        #  buffers land --, so the classic rule is timed again beside it, the two renderers built back to back and
-        #  taking turns; scripts/dbg/radius_rule_ab.py does the same over all four rule x bounds combinations)
+        # (the classic rule is timed again beside it, the two renderers built back to back and taking turns;
+        #  scripts/dbg/radius_rule_ab.py does the same over all four rule x bounds combinations)
         fr_main, keep = fr, a.min_seconds
         n_classic = max(int(s_["meta"]["n_isects"].max().item()) for s_ in fr._slots)
         pair = {"opacity_aware": FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap,
@@ -460,8 +459,8 @@ def main():
                     "note": "rasterization(radius_rule='opacity_aware'): extents min(3.33, sqrt(2 ln(255 o))) sqrt(Sigma_ii) per axis "
                             "(gsplat >= 1.5); with opacities the box is the bounding box of the alpha >= 1/255 ellipse, i.e. what "
                             "the tightened rectangles of the classic rule already cut the lists down to, plus the pairs the "
-                            "classic square never had (beyond 3 sigma of opaque Gaussians); two late-built renderers taking "
-                            "turns, best of two regions each -- compare the two figures with each other, not with `value`"}
+                            "classic square never had (beyond 3 sigma of opaque Gaussians); two renderers taking turns, best of "
+                            "two short regions each"}
         del pair
         fr = fr_main
     # single-frame latency (one slot, nothing else in flight), for reference

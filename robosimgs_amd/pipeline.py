@@ -27,6 +27,64 @@ import torch
 from . import _lib
 from .rendering import rasterization
 
+# ---- streams for the in-flight slots: one hardware queue each, none of them the consumer's -------------------------
+# HIP multiplexes a process's streams onto a few hardware queues (four by default, GPU_MAX_HW_QUEUES).  Two slots whose
+# streams share a queue cannot overlap their frames, and a slot that shares the queue of the CONSUMER stream (the one
+# fetch() makes wait for a frame) cannot start its next frame until the frame being fetched is done: with three slots
+# either collision costs 14 % (3,950 instead of 4,580 frames/s at 1 M Gaussians -- the rate of two frames in flight).
+# Which torch stream lands on which queue depends on how many streams the process made before: the first two renderers
+# of a process happened to get clean sets, the third did not (profiles/r4/00_experiments.md section 15).  So the sets
+# are not left to chance: candidate streams are classed by hardware queue with pairs of spin kernels (two kernels on
+# one queue take twice as long as on two) and the slots get streams of distinct queues other than the consumer's.
+# One probe per device and consumer stream (~10 ms), cached for the life of the process.
+_SLOT_STREAMS: Dict = {}
+_SPIN_CYCLES = 600_000          # ~0.25 ms at the shader clock
+
+
+def _spin_pair_ms(a, b, dev) -> float:
+    """Host-timed: one spin kernel on stream a, one on stream b, until both are done."""
+    import time
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for s in (a, b):
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(_SPIN_CYCLES)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) * 1e3
+
+
+def independent_streams(dev, n: int, candidates: int = 24) -> List:
+    """`n` streams for the in-flight slots of a renderer on device `dev`: on pairwise different hardware queues, none on
+    the queue of the current (consumer) stream, as far as the process's hardware queues allow (then the remaining slots
+    share among themselves, never with the consumer).  Probed once per (device, consumer stream), reused by every
+    renderer of the process."""
+    dev = torch.device(dev)
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream)
+    have = _SLOT_STREAMS.setdefault(key, {"reps": [], "pool": [], "single_ms": None})
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("FrameRenderer cannot be built inside a graph capture")
+    if have["single_ms"] is None:
+        with torch.cuda.stream(cur):
+            torch.cuda._sleep(1000)                       # (first launch of the spin kernel: module load)
+        have["single_ms"] = min(_spin_pair_ms(cur, cur, dev) for _ in range(2)) / 2.0
+
+    def shares_queue(a, b) -> bool:
+        return min(_spin_pair_ms(a, b, dev) for _ in range(2)) > 1.6 * have["single_ms"]
+
+    while len(have["reps"]) < n and len(have["pool"]) < candidates:
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(1000)                       # first use binds the stream to its hardware queue
+        have["pool"].append(s)
+        if shares_queue(cur, s) or any(shares_queue(r, s) for r in have["reps"]):
+            continue
+        have["reps"].append(s)
+    reps = have["reps"]
+    if not reps:                                          # one hardware queue for everything: nothing to choose
+        reps = have["pool"][:1] or [torch.cuda.Stream(dev)]
+    return [reps[i % len(reps)] for i in range(n)]
+
 
 def locality_order(means: torch.Tensor, bits: int = 10) -> torch.Tensor:
     """Permutation (int64 [N]: new position -> index in `means`) that puts the Gaussians in Morton (Z-curve) order of
@@ -97,8 +155,9 @@ class FrameRenderer:
         self.capacity = int(isect_capacity)
         self.n_slots = max(1, int(frames_in_flight))
         self._slots: List[Dict] = []
-        for _ in range(self.n_slots):
-            self._slots.append(self._capture_slot())
+        streams = independent_streams(self.dev, self.n_slots)     # one hardware queue per slot, none the consumer's
+        for i in range(self.n_slots):
+            self._slots.append(self._capture_slot(streams[i]))
         self._next = 0
 
     # -- internals ---------------------------------------------------------------------
@@ -114,8 +173,7 @@ class FrameRenderer:
                              render_mode=self.mode, backgrounds=self.bg, isect_capacity=cap,
                              **self.kw)
 
-    def _capture_slot(self) -> Dict:
-        stream = torch.cuda.Stream(self.dev)
+    def _capture_slot(self, stream) -> Dict:
         # the slot's camera: one 25-float device buffer (viewmat | K), so a submit is ONE small copy
         cam = torch.zeros(32, device=self.dev)
         vm, K = cam[:16].view(1, 4, 4), cam[16:25].view(1, 3, 3)

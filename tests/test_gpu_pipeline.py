@@ -244,3 +244,38 @@ def test_frame_renderer_meta_maps_back_to_the_callers_order():
         got = fr.to_caller_order(f["meta"][key][0])
         assert torch.equal(got, meta[key][0]), key
     assert not torch.equal(f["meta"]["radii"][0], meta["radii"][0])          # (it really was another order)
+
+
+def test_slot_streams_sit_on_distinct_hardware_queues_and_are_reused():
+    """pipeline.independent_streams: the in-flight slots' streams are classed by hardware queue with spin-kernel pairs;
+    the three slots of every renderer of the process get the same three streams, pairwise independent and independent
+    of the consumer (current) stream -- a renderer built late in a process used to land on colliding queues and lose
+    14 % (profiles/r4/00_experiments.md section 15)."""
+    from robosimgs_amd import pipeline, FrameRenderer
+    dev = torch.device(DEV, torch.cuda.current_device())
+    a = pipeline.independent_streams(dev, 3)
+    b = pipeline.independent_streams(dev, 3)
+    assert [s.cuda_stream for s in a] == [s.cuda_stream for s in b]            # probed once, reused
+    assert len({s.cuda_stream for s in a}) == 3
+    cur = torch.cuda.current_stream(dev)
+    assert all(s.cuda_stream != cur.cuda_stream for s in a)
+    one = min(pipeline._spin_pair_ms(cur, cur, dev) for _ in range(3)) / 2.0
+    for i, s in enumerate(a):                   # two spins on independent queues overlap: well under twice one spin
+        assert min(pipeline._spin_pair_ms(cur, s, dev) for _ in range(3)) < 1.5 * one, i
+        for r in a[i + 1:]:
+            assert min(pipeline._spin_pair_ms(s, r, dev) for _ in range(3)) < 1.5 * one
+    # more slots than hardware queues: the extra slots share among themselves, never with the consumer
+    many = pipeline.independent_streams(dev, 6)
+    assert len(many) == 6 and all(s.cuda_stream != cur.cuda_stream for s in many)
+    g = synthetic_scene(2000, math.log(0.05), 1, 2)
+    t = g.to_torch(DEV, 1)
+    cam = camera_ring(1, 96, 64)[0]
+    frs = [FrameRenderer(t, 96, 64, isect_capacity=100_000, frames_in_flight=3) for _ in range(3)]
+    assert all([s["stream"].cuda_stream for s in f._slots] == [s.cuda_stream for s in a] for f in frs)
+    ref = None
+    for f in frs:                               # sharing streams between renderers changes no pixel
+        tk = f.submit(cam.viewmat(), cam.K)
+        out = f.fetch(tk)["colors"].clone()
+        f.release(tk)
+        assert ref is None or torch.equal(out, ref)
+        ref = out
