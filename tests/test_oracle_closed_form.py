@@ -54,6 +54,47 @@ def test_single_isotropic_gaussian_closed_form():
     assert abs(alpha[c[0], c[1], 0] - o) < 0.02          # centre pixel ~ opacity
 
 
+@pytest.mark.parametrize("o", [0.9, 0.05, 0.0041, 0.0039])
+def test_opacity_aware_radius_rule_closed_form(o):
+    """SURVEY.md A.4 (gsplat >= 1.5): per-axis extents ceil(e sqrt(Sigma_ii)), e = min(3.33, sqrt(2 ln(255 o))) -- on an
+    anisotropic, axis-aligned Gaussian in front of the camera: the box is the bounding box of the alpha >= 1/255
+    ellipse, so EVERY pixel the opacity allows is blended (no square cut-off), and below 1/255 nothing is."""
+    W, H = 96, 64
+    f, z = 120.0, 3.0
+    K = _K(f, W, H)
+    sx, sy = 0.25, 0.04
+    means = np.array([[0.0, 0.0, z]])
+    img, alpha, meta = O.render(means, np.array([[1.0, 0, 0, 0]]), np.array([[sx, sy, 0.1]]), np.array([o]),
+                                np.array([[0.3, 0.6, 0.9]]), EYE_VIEW, K, W, H, sh_degree=None, radius_rule="opacity_aware")
+    if o < 1 / 255:
+        assert meta["radii"].shape == (1, 2) and not meta["radii"].any() and meta["n_isect"] == 0 and not alpha.any()
+        return
+    cxx, cyy = (f / z * sx) ** 2 + 0.3, (f / z * sy) ** 2 + 0.3
+    e = min(3.33, math.sqrt(2 * math.log(255 * o)))
+    assert e < 3.33                                        # the cap is out of reach for opacities <= 1
+    assert tuple(meta["radii"][0]) == (math.ceil(e * math.sqrt(cxx)), math.ceil(e * math.sqrt(cyy)))
+    assert meta["radii"][0, 0] > 3 * meta["radii"][0, 1] or o < 0.005
+    py, px = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing="ij")
+    sigma = 0.5 * ((px - W / 2) ** 2 / cxx + (py - H / 2) ** 2 / cyy)
+    a = np.minimum(0.999, o * np.exp(-sigma))
+    a = np.where(a >= 1 / 255, a, 0.0)                     # no rectangle term: the box holds every such pixel
+    np.testing.assert_allclose(alpha[..., 0], a, atol=1e-13)
+    # the classic rule cuts the same Gaussian off at the square of ceil(3 sqrt(lambda_1)) -- for the opaque one that
+    # loses pixels beyond 3 sigma along x, and its tile rectangle is square where the rule's is flat
+    _, alpha_c, meta_c = O.render(means, np.array([[1.0, 0, 0, 0]]), np.array([[sx, sy, 0.1]]), np.array([o]),
+                                  np.array([[0.3, 0.6, 0.9]]), EYE_VIEW, K, W, H, sh_degree=None)
+    assert meta_c["radii"][0] == math.ceil(3 * math.sqrt(cxx))
+    if o == 0.9:
+        assert (alpha[..., 0] > 0).sum() > (alpha_c[..., 0] > 0).sum()
+        assert meta["n_isect"] < meta_c["n_isect"]
+    # the torch restatement agrees (radii as integers, image to rounding)
+    t = lambda x: torch.tensor(x, dtype=torch.float64)
+    it, at, pt = OT.render(t(means), t([[1.0, 0, 0, 0]]), t([[sx, sy, 0.1]]), t([o]), t([[0.3, 0.6, 0.9]]), t(EYE_VIEW), t(K),
+                           W, H, sh_degree=None, radius_rule="opacity_aware")
+    assert np.array_equal(pt["radii"].numpy(), meta["radii"])
+    np.testing.assert_allclose(at.numpy()[..., 0], alpha[..., 0], atol=1e-13)
+
+
 def test_two_gaussians_occlusion_order_and_saturation():
     W = H = 32
     K = _K(80.0, W, H)
