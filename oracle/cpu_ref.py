@@ -65,7 +65,7 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
                with_depth=False, background=None, eps2d=0.3, near_plane=0.01, far_plane=1e10,
                radius_clip=0.0, n_threads=0, margins=True, v_render=None, v_alpha=None,
                want_projected=False, flip_eps=None, want_touched=False, want_budget=False,
-               thresholds=None):
+               thresholds=None, radius_rule="classic"):
     """The frame in fp64 arithmetic on the fp32 inputs the GPU gets (the full-size reference
     answer).  Returns (render[H,W,ch] f32, alpha[H,W] f32, info).  info carries
       margins [4,H,W], edge_mask [H,W] bool, n_edge_gaussians        (margins=True; feed
@@ -80,6 +80,8 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
       g_means2d [N,2], g_conics [N,3], g_feats [N,ch], g_opacities [N]  f64: the blend's backward
           (A.2 step 10) for upstream v_render [H,W,ch] / v_alpha [H,W]
       means2d, conics, feats, radii as projected by the oracle          (want_projected=True).
+    radius_rule: "classic" (A.2 step 5) or "opacity_aware" (per-axis extents; info["radii"] then holds
+    the x extents -- positive exactly for the visible Gaussians).
     thresholds = (a, t): the blend tests alpha >= a / 255 and stops at T' <= t * 1e-4 (default 1, 1) -- a test moves
     them by less than the gate's eps to produce real flips and nothing else."""
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
@@ -115,7 +117,8 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
         p(Km), int(width), int(height), cf(eps2d), cf(near_plane), cf(far_plane), cf(radius_clip),
         ch, p(bg), int(n_threads), p(out), p(alpha), p(counters), p(marg), p(edge), p(n_edge),
         p(vr), p(va), p(gm), p(gc), p(gf), p(go), p(om), p(oc), p(of_), p(orad), p(fw), p(fe), p(tch), p(bud),
-        p(np.array(thresholds, np.float32)) if thresholds is not None else None)
+        p(np.array(thresholds, np.float32)) if thresholds is not None else None,
+        {"classic": 0, "opacity_aware": 1}[radius_rule])
     info = {"n_isect": int(n_isect), "n_vis": int(counters[0]), "pair_evals": int(counters[1])}
     if margins:
         info.update(margins=marg, edge_mask=edge.astype(bool), n_edge_gaussians=int(n_edge[0]))

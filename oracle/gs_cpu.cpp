@@ -36,7 +36,8 @@ template <typename F>
 struct Splat {
   F mx, my, depth, ca, cb, cc, opac;
   float depth32;            // sort key: fp32 depth bits (A.2 step 7), also in the double build
-  int radius;
+  int radius;               // the x extent under the per-axis rule
+  int radius_y;             // == radius under the classic rule
   int x0, y0, x1, y1;
   // knife-edge bookkeeping (margins only): outer / inner tile rectangles under perturbation
   int ox0, oy0, ox1, oy1, ix0, iy0, ix1, iy1;
@@ -54,11 +55,14 @@ inline void mat3mul(const F* A, const F* B, F* C, bool bt) {
 }
 
 // A.2 steps 1-5.  Returns false when culled; `edge` (optional) receives the un-culled
-// intermediates the knife-edge classification needs: {3 sqrt(lambda), mx, my, z, det > 0}.
+// intermediates the knife-edge classification needs: {extent x, mx, my, z, det > 0, extent y, extent factor e}
+// (extent = 3 sqrt(lambda) on both axes under the classic rule).
+// rule 0: A.2 step 5 (gsplat 1.4).  rule 1: SURVEY.md A.4 (gsplat >= 1.5) -- per-axis extents e sqrt(Sigma_ii),
+// e = min(3.33, sqrt(2 ln(255 opacity))), opacity < 1/255 culled, radius_clip culls only when both extents are under it.
 template <typename F>
 bool project_one(const float* mean, const float* quat, const float* scale, const float* Vf,
                  const float* Kf, F W, F H, F eps2d, F near_p, F far_p, F radius_clip,
-                 Splat<F>& s, F& comp, F* edge) {
+                 Splat<F>& s, F& comp, F* edge, int rule = 0, F opacity = 1) {
   F V[12], K[9];
   for (int i = 0; i < 12; ++i) V[i] = Vf[i];
   for (int i = 0; i < 9; ++i) K[i] = Kf[i];
@@ -68,7 +72,7 @@ bool project_one(const float* mean, const float* quat, const float* scale, const
   F x = R[0] * m0 + R[1] * m1 + R[2] * m2 + V[3];
   F y = R[3] * m0 + R[4] * m1 + R[5] * m2 + V[7];
   F z = R[6] * m0 + R[7] * m1 + R[8] * m2 + V[11];
-  if (edge) { edge[0] = 0; edge[1] = 0; edge[2] = 0; edge[3] = z; edge[4] = 0; }
+  if (edge) { edge[0] = 0; edge[1] = 0; edge[2] = 0; edge[3] = z; edge[4] = 0; edge[5] = 0; edge[6] = 0; }
   const bool z_ok = !(z < near_p || z > far_p);
   if (!z_ok && !edge) return false;
   const F zs = z_ok ? z : (z > 0 ? z : F(1));
@@ -104,17 +108,26 @@ bool project_one(const float* mean, const float* quat, const float* scale, const
   if (!det_ok) return false;
   F mid = F(0.5) * (a + c);
   F lam = mid + std::sqrt(std::max(F(0.01), mid * mid - det));
-  F v3 = F(3) * std::sqrt(lam);
-  F radius = std::ceil(v3);
+  F v3 = F(3) * std::sqrt(lam), v3y = v3, efac = 3;
+  bool op_ok = true;
+  if (rule == 1) {
+    op_ok = opacity >= F(1) / F(255);
+    efac = std::min(F(3.33), std::sqrt(F(2) * std::log((op_ok ? opacity : F(1) / F(255)) * F(255))));
+    v3 = efac * std::sqrt(a);
+    v3y = efac * std::sqrt(c);
+  }
+  F radius = std::ceil(v3), radius_y = std::ceil(v3y);
   F mx = fx * x * rz + cx, my = fy * y * rz + cy;
   s.mx = mx; s.my = my; s.depth = z; s.depth32 = (float)z;
   s.ca = c / det; s.cb = -b / det; s.cc = a / det;
   s.radius = (int)radius;
+  s.radius_y = (int)radius_y;
   comp = std::sqrt(std::max(F(0), det0 / det));
-  if (edge) { edge[0] = v3; edge[1] = mx; edge[2] = my; edge[3] = z; edge[4] = 1; }
-  if (!z_ok) return false;
-  if (radius <= radius_clip) return false;
-  if (mx + radius <= 0 || mx - radius >= W || my + radius <= 0 || my - radius >= H) return false;
+  if (edge) { edge[0] = v3; edge[1] = mx; edge[2] = my; edge[3] = z; edge[4] = 1; edge[5] = v3y; edge[6] = efac; }
+  if (!z_ok || !op_ok) return false;
+  if (radius <= radius_clip && radius_y <= radius_clip) return false;
+  if (!(radius > 0) || !(radius_y > 0)) return false;
+  if (mx + radius <= 0 || mx - radius >= W || my + radius_y <= 0 || my - radius_y >= H) return false;
   return true;
 }
 
@@ -193,7 +206,8 @@ struct Extras {            // optional outputs of the double build (all may be n
   double* o_means2d = nullptr;     // [N,2]
   double* o_conics = nullptr;      // [N,3]
   double* o_feats = nullptr;       // [N,ch]
-  int32_t* o_radii = nullptr;      // [N]
+  int32_t* o_radii = nullptr;      // [N]  (the x extents under the per-axis rule)
+  int radius_rule = 0;             // 0: A.2 step 5; 1: SURVEY.md A.4 (per axis, opacity-aware; classic rasterize mode)
 };
 
 template <typename F>
@@ -219,30 +233,40 @@ long long render_impl(int n, const float* means, const float* quats, const float
 #pragma omp parallel for schedule(static) reduction(+ : n_vis, n_edge)
   for (int g = 0; g < n; ++g) {
     F comp;
-    F edge[5];
+    F edge[7];
     Splat<F> s{};
     const bool vis = project_one<F>(means + 3 * g, quats + 4 * g, scales + 3 * g, V, K, (F)width,
                                     (F)height, (F)eps2d, (F)near_p, (F)far_p, (F)radius_clip, s,
-                                    comp, want_edges ? edge : nullptr);
+                                    comp, want_edges ? edge : nullptr, ex.radius_rule, (F)opacities[g]);
     s.opac = opacities[g];
     if (want_edges && edge[4] != 0) {
       // gaussian_edge_mask of oracle/gs_oracle_np.py: rectangles under the perturbations an fp32
       // projection can apply (radius +-1 when 3 sqrt(lambda) is within 3e-5 relative of an integer,
       // mean +-1e-3 px, depth 1e-5 relative around the near / far plane)
-      const F v3 = edge[0], mx = edge[1], my = edge[2], z = edge[3];
-      const F r = std::ceil(v3), fr = v3 - std::floor(v3);
-      const F tol = F(3e-5) * std::max(v3, F(1)) + F(1e-6);
-      const F r_lo = (fr > 0 && fr < tol) ? r - 1 : r;
-      const F r_hi = (1 - fr < tol || fr == 0) ? r + 1 : r;
-      const bool zin = z >= near_p * (1 + 1e-5) && z <= far_p * (1 - 1e-5);
-      const bool zout = z >= near_p * (1 - 1e-5) && z <= far_p * (1 + 1e-5);
-      auto rect = [&](F rr, F d, int& x0, int& y0, int& x1, int& y1) {
-        x0 = std::min(std::max(0, (int)std::floor((mx - rr - d) / T)), tw);
-        x1 = std::min(std::max(0, (int)std::ceil((mx + rr + d) / T)), tw);
-        y0 = std::min(std::max(0, (int)std::floor((my - rr - d) / T)), th);
-        y1 = std::min(std::max(0, (int)std::ceil((my + rr + d) / T)), th);
-        return !(mx + rr + d <= 0 || mx - rr - d >= width || my + rr + d <= 0 || my - rr - d >= height) &&
-               rr > radius_clip;
+      const F mx = edge[1], my = edge[2], z = edge[3];
+      F r_lo[2], r_hi[2];
+      for (int ax = 0; ax < 2; ++ax) {
+        const F v3 = edge[ax ? 5 : 0];
+        const F r = std::ceil(v3), fr = v3 - std::floor(v3);
+        F tol = F(3e-5) * std::max(v3, F(1)) + F(1e-6);
+        if (ex.radius_rule == 1)       // d(extent factor) = d(ln) / e with d(ln) ~ 2e-7 in fp32 (gs_oracle_np.gaussian_edge_mask)
+          tol += v3 * (F(2e-7) / std::max(edge[6] * edge[6], F(1e-12)));
+        r_lo[ax] = (fr > 0 && fr < tol) ? r - 1 : r;
+        r_hi[ax] = (1 - fr < tol || fr == 0) ? r + 1 : r;
+      }
+      bool zin = z >= near_p * (1 + 1e-5) && z <= far_p * (1 - 1e-5);
+      bool zout = z >= near_p * (1 - 1e-5) && z <= far_p * (1 + 1e-5);
+      if (ex.radius_rule == 1) {       // culled below 1/255: present or not is uncertain within 1e-5 of it
+        zin = zin && (F)opacities[g] >= F(1 + 1e-5) / F(255);
+        zout = zout && (F)opacities[g] >= F(1 - 1e-5) / F(255);
+      }
+      auto rect = [&](const F* rr, F d, int& x0, int& y0, int& x1, int& y1) {
+        x0 = std::min(std::max(0, (int)std::floor((mx - rr[0] - d) / T)), tw);
+        x1 = std::min(std::max(0, (int)std::ceil((mx + rr[0] + d) / T)), tw);
+        y0 = std::min(std::max(0, (int)std::floor((my - rr[1] - d) / T)), th);
+        y1 = std::min(std::max(0, (int)std::ceil((my + rr[1] + d) / T)), th);
+        return !(mx + rr[0] + d <= 0 || mx - rr[0] - d >= width || my + rr[1] + d <= 0 || my - rr[1] - d >= height) &&
+               (rr[0] > radius_clip || rr[1] > radius_clip) && rr[0] > 0 && rr[1] > 0;
       };
       const F dmu = F(1e-3);
       bool ion = rect(r_lo, -dmu, s.ix0, s.iy0, s.ix1, s.iy1) && zin;
@@ -253,15 +277,15 @@ long long render_impl(int n, const float* means, const float* quats, const float
       if (s.unsure) ++n_edge;
     }
     if (!vis) {
-      s.radius = 0;
+      s.radius = s.radius_y = 0;
       sp[g] = s;
       continue;
     }
-    F tr = (F)s.radius / T, tx = s.mx / T, ty = s.my / T;
+    F tr = (F)s.radius / T, try_ = (F)s.radius_y / T, tx = s.mx / T, ty = s.my / T;
     s.x0 = std::min(std::max(0, (int)std::floor(tx - tr)), tw);
     s.x1 = std::min(std::max(0, (int)std::ceil(tx + tr)), tw);
-    s.y0 = std::min(std::max(0, (int)std::floor(ty - tr)), th);
-    s.y1 = std::min(std::max(0, (int)std::ceil(ty + tr)), th);
+    s.y0 = std::min(std::max(0, (int)std::floor(ty - try_)), th);
+    s.y1 = std::min(std::max(0, (int)std::ceil(ty + try_)), th);
     cnt[g] = (long long)(s.x1 - s.x0) * (s.y1 - s.y0);
     sh_color<F>(sh_degree, means + 3 * g, campos, sh + (size_t)g * coeff_stride * 3, &feat[(size_t)g * channels]);
     if (channels == 4) feat[(size_t)g * 4 + 3] = s.depth;
@@ -608,8 +632,9 @@ extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* q
                                        double* g_feats, double* g_opac, double* o_means2d,
                                        double* o_conics, double* o_feats, int32_t* o_radii,
                                        float* flip_weight, const float* flip_eps, uint8_t* touched,
-                                       double* budget, const float* thresholds) {
+                                       double* budget, const float* thresholds, int radius_rule) {
   Extras ex;
+  ex.radius_rule = radius_rule;
   ex.thresholds = thresholds;
   ex.touched = touched;
   ex.budget = budget;

@@ -102,21 +102,22 @@ def blend_cotangents(mode, w_render, w_alpha, ref_render, ref_alpha):
     return v_r.astype(np.float32), v_a.astype(np.float32)
 
 
-def oracle_budgets(g, viewmat_f32, K_f32, W, H, deg, mode, w_render, w_alpha, flip_eps, n_threads=0):
+def oracle_budgets(g, viewmat_f32, K_f32, W, H, deg, mode, w_render, w_alpha, flip_eps, n_threads=0, radius_rule="classic"):
     """fp64 port: blend gradients, touched mask and the per-row flip budgets for loss = <w_render, frame> + <w_alpha, alpha>.
     Returns the port's info dict (g_means2d, g_conics, g_feats, g_opacities, budget [N,4], touched, radii, ...)."""
     from oracle import cpu_ref
     with_depth = mode != "RGB"
     ref, ra, _ = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, viewmat_f32, K_f32, W, H, deg,
-                                    with_depth=with_depth, margins=False, n_threads=n_threads)
+                                    with_depth=with_depth, margins=False, n_threads=n_threads, radius_rule=radius_rule)
     v_r, v_a = blend_cotangents(mode, w_render, w_alpha, ref, ra)
     _, _, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, viewmat_f32, K_f32, W, H, deg,
                                     with_depth=with_depth, margins=True, v_render=v_r, v_alpha=v_a, want_projected=True,
-                                    flip_eps=flip_eps, want_touched=True, want_budget=True, n_threads=n_threads)
+                                    flip_eps=flip_eps, want_touched=True, want_budget=True, n_threads=n_threads,
+                                    radius_rule=radius_rule)
     return info
 
 
-def parameter_budgets(g, viewmat_f32, K_f32, W, H, deg, with_depth, budget):
+def parameter_budgets(g, viewmat_f32, K_f32, W, H, deg, with_depth, budget, radius_rule="classic"):
     """Row budgets of d loss / d {means, quats, scales, colors} from the blend's (budget [N,4]: means2d, conics, feats,
     opacity) through the fp64 torch oracle's projection and SH colour (absolute Jacobian, chained_budget)."""
     import torch
@@ -125,8 +126,8 @@ def parameter_budgets(g, viewmat_f32, K_f32, W, H, deg, with_depth, budget):
     P = {"means": d(g.means, True), "quats": d(g.quats, True), "scales": d(g.scales, True),
          "colors": d(g.sh_coeffs[:, :(deg + 1) ** 2], True)}
     vm, K = d(viewmat_f32), d(K_f32)
-    pr = OT.project(P["means"], P["quats"], P["scales"], vm, K, W, H)
-    vis = (pr["radii"] > 0).to(torch.float64)[:, None]
+    pr = OT.project(P["means"], P["quats"], P["scales"], vm, K, W, H, radius_rule=radius_rule, opacities=d(g.opacities))
+    vis = (pr["radii"].reshape(len(g), -1)[:, 0] > 0).to(torch.float64)[:, None]
     campos = -vm[:3, :3].T @ vm[:3, 3]
     rgb = torch.clamp(OT.spherical_harmonics(deg, P["means"] - campos, P["colors"]) + 0.5, min=0.0) * vis
     feats = torch.cat([rgb, pr["depths"][:, None]], dim=-1) if with_depth else rgb

@@ -55,6 +55,36 @@ def test_config2_matches_cpu_port_and_survey_counts(config2):
     assert float(al.min()) >= 0.0 and float(al.max()) < 1.0
 
 
+def test_config2_opacity_aware_radius_rule_matches_fp64_port(config2):
+    """configs[1] under the other radius policy (rasterization(radius_rule="opacity_aware")): the same
+    zero-unexplained-pixel gate against the fp64 port restating that rule, at full size; tightened rectangles on top of
+    it change no bit; what the rule does to the work (2,106 Gaussians under 1/255 culled, 18 % fewer pairs than gsplat
+    1.4's squares, a different image where opaque Gaussians reach beyond 3 sigma)."""
+    from robosimgs_amd import rasterization
+    g, cam, t = config2
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    kw = dict(sh_degree=3, render_mode="RGB+ED", radius_rule="opacity_aware")
+    c, a, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K, 1920, 1080,
+                               tile_bounds="classic", **kw)
+    ct, at, mt = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K, 1920, 1080, **kw)
+    assert torch.equal(ct, c) and torch.equal(at, a)
+    assert meta["radii"].shape == (1, 1_000_000, 2)
+    n_vis, n_isect = int((meta["radii"][0, :, 0] > 0).sum()), int(meta["n_isects"][0])
+    assert abs(n_vis - 762_839) <= 2 and abs(n_isect - 4_105_508) <= 200 and int(mt["n_isects"][0]) <= n_isect
+    ref, ra, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, cam.viewmat(), cam.K,
+                                       1920, 1080, 3, with_depth=True, flip_eps=O.EPS_PATH, radius_rule="opacity_aware")
+    assert abs(info["n_isect"] - n_isect) <= 200 and abs(info["n_vis"] - n_vis) <= 2
+    ref = ref.astype(np.float64)
+    ref[..., 3] /= np.maximum(ra, 1e-10)                              # the port returns the depth sum ("D")
+    st = O.check_frame(c[0].cpu().numpy(), a[0].cpu().numpy(), ref, ra, info["margins"], O.EPS_PATH, info["edge_mask"],
+                       expected_depth=True, what="configs[1], opacity-aware rule", flip_weight=info["flip_weight"],
+                       feat_max=info["feat_max"], require_flip_bound=True)
+    print(f"\nconfigs[1], opacity-aware radius rule vs fp64 port: {st}, knife-edge Gaussians {info['n_edge_gaussians']}")
+    c0, _, m0 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K, 1920, 1080,
+                              sh_degree=3, render_mode="RGB+ED", tile_bounds="classic")
+    assert n_isect < 0.85 * int(m0["n_isects"][0]) and not torch.equal(c0, c)
+
+
 def test_config2_headline_path_frame_renderer_in_morton_order_matches_fp64_port(config2):
     """The path bench.py's `value` is measured on: FrameRenderer with three frames in flight, its resident copy of the
     scene in Morton order, the per-tile raster schedule, "RGB+ED", lean frames through mgs_render_frames -- every frame of

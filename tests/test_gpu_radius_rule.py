@@ -144,8 +144,9 @@ def test_rasterization_opacity_aware_matches_oracle(mode, deg, aa):
 def test_rasterization_opacity_aware_backward(deg, mode, aa, cap):
     """Gradients under the rule vs fp64 autograd of the torch oracle under the rule (the extent is not differentiable:
     only the visible set and the lists change).  cap given: the batched training path (mgs_render_frames_train /
-    _backward), whose state carries radii_y.  The fp64 port prices flip budgets for the classic rule only, so -- like
-    the anti-aliased cases -- these keep the fraction bound: cosine >= 0.999, <= 1 % of the rows over 5e-3."""
+    _backward), whose state carries radii_y.  The gate is the classic rule's: cosine >= 0.999, <= 1 % of the rows over
+    5e-3 and -- the fp64 port restates the rule too -- EVERY row within rounding + 1.5 x its flip budget (the
+    anti-aliased case keeps the fraction bound: the port has no anti-aliased mode)."""
     from robosimgs_amd import rasterization
     from grad_gate import compare
     w, h = 112, 80
@@ -169,10 +170,21 @@ def test_rasterization_opacity_aware_backward(deg, mode, aa, cap):
     ((img * _d(wr)).sum() + (al[..., 0] * _d(wa)).sum()).backward()
     rr = meta["radii"][0].cpu().numpy()
     assert int(((rr[:, 0] > 0) != (p["radii"][:, 0].numpy() > 0)).sum()) <= 1
+    budgets = {k: None for k in names}
+    if not aa:
+        from grad_gate import oracle_budgets, parameter_budgets
+        f32 = lambda m: np.asarray(m, dtype=np.float32)
+        info = oracle_budgets(g, f32(cam.viewmat()), f32(cam.K), w, h, deg, mode, wr, wa, O.EPS_PATH_GRAD,
+                              radius_rule="opacity_aware")
+        bud = info["budget"]
+        assert ((info["radii"] > 0) == (rr[:, 0] > 0)).sum() >= len(g) - 1
+        budgets.update(parameter_budgets(g, f32(cam.viewmat()), f32(cam.K), w, h, deg, mode != "RGB", bud,
+                                         radius_rule="opacity_aware"))
+        budgets["opacities"] = bud[:, 3]
     for k in names:
         ref = r[k].grad.numpy()
         compare("opacity-aware v_" + k, t[k].grad, ref if ref.ndim > 1 else ref.reshape(-1, 1), row_tol=5e-3,
-                bad_frac=1e-2, cos_min=0.999)
+                bad_frac=1e-2, cos_min=0.999, budget=budgets[k])
     # culled by the rule (opacity < 1/255) = no gradient
     culled = rr[:, 0] == 0
     assert culled.any() and float(t["means"].grad[torch.from_numpy(culled).to(DEV)].abs().max()) == 0.0
