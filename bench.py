@@ -94,7 +94,6 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--bwd-steps", type=int, default=30)
-    ap.add_argument("--pg-high-priority", type=int, default=0, help="N > 1: RCCL's stream from the high-priority pool (0 / 1)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step region until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (5 M Gaussians at 3840x2160)")
@@ -193,13 +192,7 @@ def main():
         if debug_gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            opts = None
-            if a.pg_high_priority:
-                # RCCL's stream on a high-priority hardware queue of its own: HIP multiplexes the normal-priority streams
-                # onto four queues, all taken by the consumer stream and the three in-flight slots (pipeline.py), so the
-                # collective's stream would share one with a slot and hold that slot's next frame behind its wait
-                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ring = use_dist                       # the N > 1 workload: configs[3]'s camera ring
 
     W, H, deg = a.width, a.height, a.sh_degree
