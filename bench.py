@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--bwd-steps", type=int, default=30)
+    ap.add_argument("--convert-on-consumer", action="store_true",
+                    help="N > 1: convert frames to the dataset payload on the consumer stream between fetch and release "
+                         "(the round-3 loop) instead of inside the slots' graphs")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step region until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (5 M Gaussians at 3840x2160)")
@@ -253,6 +256,16 @@ def main():
     # the same frames with the scene in the order it was given are timed further down and reported beside `value`
     fr = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap,
                        reorder=None if a.no_reorder else "morton")
+    # N > 1 with a dataset payload: the conversion into the payload is the last node of every slot's graph (on the slot's
+    # stream, beside the other frames), the consumer only copies the 12 - 17 MB frame into the batch it ships
+    fr_by_payload = {}
+    if ring and not a.no_gather:
+        for m_, dt_ in (("dataset16", torch.float16), ("dataset", torch.float32)):
+            if a.gather_dtype == m_ and not a.convert_on_consumer:
+                fr_by_payload[m_] = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap,
+                                                  reorder=None if a.no_reorder else "morton", dataset_output=dt_,
+                                                  dataset_K=K_host)
+    fr_plain = fr
     cam_devs = [FrameRenderer.pack_camera(*[x[0].contiguous() for x in cam_tensors(c)]) for c in cams]
     vm_dev, K_dev = vm[0].contiguous(), K[0].contiguous()
     frames_per_step = len(cam_devs)                    # 1 at N = 1, this rank's share of the ring otherwise
@@ -270,6 +283,8 @@ def main():
         """Warm-up, then regions of K steps until min_seconds are timed; the gathered payload is the dataset frame
         (RGBA8 plane + fp32 ray-distance plane, 8 B per pixel), fp32 RGB + expected depth + alpha, or the 8-bit RGB
         image.  Returns (regions, collectives)."""
+        nonlocal fr
+        fr = fr_by_payload.get(g_mode, fr_plain) if ring else fr
         g_u8 = g_mode == "u8"
         g_ds = g_mode in ("dataset", "dataset16")
         g_dist = torch.float16 if g_mode == "dataset16" else torch.float32
@@ -313,7 +328,9 @@ def main():
                 if j == 0 and pending[cur] is not None:    # the collective that last read this staging buffer
                     pending[cur].wait()                    # (NCCL: the current STREAM waits, not the host)
                     pending[cur] = None
-                if g_ds:                                   # RGBA8 + ray distance, one kernel, inside the timed region
+                if g_ds and "dataset" in f:                # converted in the slot's graph: one copy into the batch
+                    staging[cur][j].view(-1).copy_(f["dataset"], non_blocking=True)
+                elif g_ds:                                 # RGBA8 + ray distance, one kernel, inside the timed region
                     flat = staging[cur][j].view(-1)
                     frame_to_dataset(f["colors"], f["alphas"], K_host, out=(flat[:H * W * 4].view(H, W, 4),
                                                                             flat[H * W * 4:].view(g_dist).view(H, W, 1)))

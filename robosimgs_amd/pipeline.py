@@ -104,11 +104,19 @@ class FrameRenderer:
                  frames_in_flight: int = 3, isect_capacity: Optional[int] = None,
                  capacity_margin: float = 1.5, background: Optional[torch.Tensor] = None,
                  sizing_camera=None, group_ids: Optional[torch.Tensor] = None, n_groups: int = 0,
-                 rotate_sh: bool = True, reorder: Optional[str] = "morton", **raster_kw):
+                 rotate_sh: bool = True, reorder: Optional[str] = "morton", dataset_output=None, dataset_K=None,
+                 **raster_kw):
         """tensors: dict(means, quats, scales, opacities, colors, sh_degree) on the GPU
         (Gaussians.to_torch()); `self.t` is the renderer's own (by default Morton-ordered) copy.  isect_capacity: slots reserved for tile intersections per
         frame; if None it is measured once with `sizing_camera` = (viewmat, K) (required then)
         and multiplied by `capacity_margin`.  A frame that needs more raises on fetch().
+
+        dataset_output (torch.float16 / float32 / float64) with dataset_K (the 3x3 intrinsics every camera of the run
+        shares; render_mode "RGB+ED"): every slot's graph ends with the conversion into the dataset frame the reference
+        reads -- RGBA8 + ray distance (dataset.frame_to_dataset) -- in the slot's own buffer; fetch() then also returns
+        "rgba" [H,W,4] u8, "distance" [H,W,1] and "dataset" (both as one flat byte buffer: ONE copy puts a frame into a
+        gather's staging area).  The conversion runs on the slot's stream with the frame, not on the consumer's between
+        fetch() and release(): a slot held while the consumer converted its frame cost the multi-GPU loop 10 %.
 
         Dynamic scenes (articulated parts, a moving robot): give group_ids (int32 [N] on the GPU,
         -1 = static) and n_groups; submit(..., rotations=, translations=[, scales=]) then poses
@@ -141,6 +149,13 @@ class FrameRenderer:
         self.dev = tensors["means"].device
         self.width, self.height, self.mode = int(width), int(height), render_mode
         self.kw = dict(raster_kw)
+        self.dataset_dtype, self.dataset_K = dataset_output, None
+        if dataset_output is not None:
+            if dataset_K is None or render_mode != "RGB+ED":
+                raise ValueError("dataset_output needs dataset_K (the shared 3x3 intrinsics) and render_mode='RGB+ED'")
+            if dataset_output not in (torch.float16, torch.float32, torch.float64):
+                raise ValueError("dataset_output must be torch.float16, torch.float32 or torch.float64")
+            self.dataset_K = np.asarray(dataset_K, dtype=np.float64).reshape(3, 3)
         # several frames in flight: total work matters, not one launch's duration (rendering.py)
         self.kw.setdefault("raster_schedule", "throughput" if int(frames_in_flight) > 1 else "latency")
         # the slots' frames keep no per-Gaussian arrays nobody reads (rendering.py: lean_meta)
@@ -198,6 +213,14 @@ class FrameRenderer:
                                         out=pose["t"], packed=(pose["x"], pose["r"]))
             return self._raster(vm, K, self.capacity, posed)
 
+        ds = None
+        if self.dataset_dtype is not None:          # the slot's dataset frame: [RGBA8 plane | distance plane] as bytes
+            from .dataset import frame_to_dataset
+            n_px = self.width * self.height
+            flat = torch.empty(n_px * (4 + torch.empty(0, dtype=self.dataset_dtype).element_size()), dtype=torch.uint8,
+                               device=self.dev)
+            ds = {"dataset": flat, "rgba": flat[:n_px * 4].view(self.height, self.width, 4),
+                  "distance": flat[n_px * 4:].view(self.dataset_dtype).view(self.height, self.width, 1)}
         with torch.cuda.stream(stream):
             for _ in range(2):
                 body()
@@ -205,10 +228,12 @@ class FrameRenderer:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 colors, alphas, meta = body()
+                if ds is not None:
+                    frame_to_dataset(colors[0], alphas[0], self.dataset_K, out=(ds["rgba"], ds["distance"]))
         torch.cuda.synchronize(self.dev)
         return {"stream": stream, "vm": vm, "K": K, "cam": cam, "pose": pose, "graph": graph, "colors": colors,
                 "alphas": alphas, "meta": meta, "done": torch.cuda.Event(),
-                "released": torch.cuda.Event(), "state": "free"}
+                "released": torch.cuda.Event(), "state": "free", "ds": ds}
 
     # -- API ---------------------------------------------------------------------------
     @staticmethod
@@ -278,7 +303,10 @@ class FrameRenderer:
             raise _lib.MgsError(f"frame needs {need} tile intersections, capacity is "
                                 f"{self.capacity}: build the FrameRenderer with a larger "
                                 "isect_capacity / capacity_margin")
-        return {"colors": s["colors"][0], "alphas": s["alphas"][0], "meta": s["meta"]}
+        out = {"colors": s["colors"][0], "alphas": s["alphas"][0], "meta": s["meta"]}
+        if s["ds"] is not None:
+            out.update(s["ds"])
+        return out
 
     def release(self, ticket: int) -> None:
         """Hand the slot back: its next frame will start after everything enqueued so far on the

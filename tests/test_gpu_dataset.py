@@ -70,3 +70,35 @@ def test_rendered_frame_through_the_writer_and_back(tmp_path):
         assert np.all(np.abs(z32 - ed.astype(np.float64)) <= np.spacing(np.abs(ed)))
     assert sorted(os.listdir(wr.image_dir)) == [f"frame_{i:05d}.png" for i in range(3)]
     assert sorted(os.listdir(wr.depth_dir)) == [f"frame_{i:05d}.npy.gz" for i in range(3)]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.float32])
+def test_frame_renderer_converts_inside_the_slots_graphs(dt):
+    """FrameRenderer(dataset_output=, dataset_K=): the dataset frame (RGBA8 + ray distance) leaves the slot's own graph --
+    the very bytes frame_to_dataset gives on the fetched float frame, for every frame of a sequence, as three views of
+    one flat buffer (what the multi-GPU loop copies into its gather batch)."""
+    from robosimgs_amd import FrameRenderer, camera_ring, synthetic_scene
+    from robosimgs_amd.dataset import frame_to_dataset
+    W, H = 208, 144
+    g = synthetic_scene(20_000, math.log(0.05), 2, 4)
+    cams = camera_ring(7, W, H)
+    t = g.to_torch(DEV, 2)
+    fr = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=3, isect_capacity=600_000, dataset_output=dt,
+                       dataset_K=cams[0].K)
+    seen = []
+
+    def consume(i, f):
+        rgba, dist = frame_to_dataset(f["colors"], f["alphas"], cams[0].K, distance_dtype=dt)
+        assert torch.equal(f["rgba"], rgba) and torch.equal(f["distance"], dist)
+        n = W * H * 4
+        assert f["dataset"].dtype == torch.uint8 and f["dataset"].numel() == n + W * H * dist.element_size()
+        assert torch.equal(f["dataset"][:n].view(H, W, 4), rgba)
+        assert torch.equal(f["dataset"][n:].view(dt).view(H, W, 1), dist)
+        assert int((rgba[..., 3] > 0).sum()) > 0.2 * W * H
+        seen.append(i)
+    fr.render_sequence(cams, consume)
+    assert seen == list(range(7))
+    with pytest.raises(ValueError):
+        FrameRenderer(t, W, H, render_mode="RGB", isect_capacity=600_000, dataset_output=dt, dataset_K=cams[0].K)
+    with pytest.raises(ValueError):
+        FrameRenderer(t, W, H, render_mode="RGB+ED", isect_capacity=600_000, dataset_output=dt)
