@@ -12,18 +12,18 @@ sys.path.insert(0, ".")
 from robosimgs_amd import FrameRenderer, camera_ring, synthetic_scene  # noqa: E402
 from robosimgs_amd import pipeline  # noqa: E402
 
-W, H, deg, MODE = 1920, 1080, 3, "RGB+ED"
+W, H, deg, MODE = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080)), 3, "RGB+ED"
 dev = torch.device("cuda", 0)
-scene = synthetic_scene(1_000_000, math.log(0.012), deg, seed=0)
+scene = synthetic_scene(int(os.environ.get("N", 1_000_000)), math.log(float(os.environ.get("MU", 0.012))), deg, seed=0)
 t = scene.to_torch(dev, deg)
 cam = camera_ring(1, W, H, thetas=[0.3])[0]
 vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)[None]
 K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)[None]
 cd = FrameRenderer.pack_camera(vm[0].contiguous(), K[0].contiguous())
-CAP = int(3_708_938 * 1.25) + 4096
+CAP = int(int(os.environ.get("NISECT", 3_708_938)) * 1.25) + 4096
 
 
-def run(fr, n_fl, frames=800):
+def run(fr, n_fl, frames=int(os.environ.get("FRAMES", 800))):
     tickets = []
     for _ in range(30):
         tk = fr.submit(cd); fr.fetch(tk, check=False); fr.release(tk)
