@@ -41,8 +41,8 @@ extern "C" {
  * 100 round 1; 200 round 2 (seed / splats / tile_group_order arguments); 300 round 3; 400 round 4 (forward
  * checkpoints + segmented backward, batched training entry points, debug hooks out of the production build);
  * 410 round 4 (the radius rule as a policy: radii_y / radius_rule arguments, MGS_BIN_* / MGS_FRAMES_RADIUS_* flags,
- * one more field in the training state). */
-#define MGS_VERSION 410
+ * one more field in the training state; 420: the dataset frame as an output of the raster forward, ds_* arguments). */
+#define MGS_VERSION 420
 
 #define MGS_OK 0
 #define MGS_ERR_INVALID_ARGUMENT (-1)
@@ -249,6 +249,8 @@ int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const int
  * backgrounds[C,channels] nullable; antialiased != 0 = rasterize_mode "antialiased".
  * out: render[C,H,W,channels], alphas[C,H,W], n_isect[C], status[C] (as mgs_isect_tiles, per camera).
  * The per-camera intermediates live in `workspace` (two-phase size query; 256-byte aligned) and are reused
+ * ds_rgba[C,H,W,4] u8 / ds_distance[C,H,W] / ds_distance_type / ds_Kinv_host: as mgs_rasterize_fwd, per camera (all
+ * cameras share the intrinsics behind K^-1); render and alphas may then both be NULL.
  * from camera to camera, so any batch needs one camera's worth of scratch: ~76 B per Gaussian + 4 B per
  * list slot + the binning's own workspace.  No host read-back: capturable like a single frame.
  * ----------------------------------------------------------------------------------- */
@@ -258,7 +260,8 @@ int mgs_render_frames(int n, const float *means, const float *quats, const float
                       float eps2d, float near_plane, float far_plane, float radius_clip,
                       int antialiased, int channels, int flags, const float *backgrounds,
                       uint32_t isect_capacity, float *render, float *alphas, uint32_t *n_isect,
-                      uint32_t *status, void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
+                      uint32_t *status, uint8_t *ds_rgba, void *ds_distance, int ds_distance_type,
+                      const double *ds_Kinv_host, void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
 
 /* -------------------------------------------------------------------------------------
  * A batch of TRAINING frames (gsplat `rasterization(...)` for C cameras with gradients) behind two calls.
@@ -327,6 +330,13 @@ int mgs_isect_offset_encode(uint32_t n_isect, const int64_t *isect_ids, int n_ca
  *   accumulated channels, (1 + channels) floats per pixel -- for mgs_rasterize_bwd_det, which then walks a tile's
  *   list as independent segments of S entries instead of as one serial job per tile.
  *   checkpoints[mgs_raster_checkpoint_floats(...)] is written only where some pixel is still open.
+ *   ds_rgba[H,W,4] u8 / ds_distance[H,W] (both nullable; ds_distance needs ds_rgba): the DATASET FRAME straight out of
+ *   the raster -- exactly what mgs_frame_to_dataset (no background of its own) makes of the float frame, byte for byte:
+ *   RGBA8 with A = alpha > 0 ? max(1, round(255 alpha)) : 0 and the ray distance expected depth x ||K^-1 (x, y, 1)||
+ *   (ds_distance_type 0: f32, 1: f64, 2: f16; ds_Kinv_host: HOST pointer to the 9 doubles of K^-1, read during the
+ *   call).  Needs 4 channels, MGS_RASTER_EXPECTED_LAST and no last_ids (an "RGB+ED" inference frame).  render and
+ *   alphas may then BOTH be NULL: 6 - 12 bytes per pixel leave the kernel instead of 20 and no conversion pass reads
+ *   the frame back (a data-generation loop that only ships dataset frames).
  * ----------------------------------------------------------------------------------- */
 int mgs_rasterize_fwd(int n, const float *means2d, const float *conics, const float *feats,
                       const float *opacities, const float *splats, const float *background,
@@ -334,7 +344,8 @@ int mgs_rasterize_fwd(int n, const float *means2d, const float *conics, const fl
                       const int32_t *tile_offsets, const int32_t *flatten_ids,
                       const int32_t *tile_group_order, int flags,
                       float *render, float *alphas, int32_t *last_ids, float *checkpoints,
-                      int checkpoint_interval, mgs_stream_t stream);
+                      int checkpoint_interval, uint8_t *ds_rgba, void *ds_distance, int ds_distance_type,
+                      const double *ds_Kinv_host, mgs_stream_t stream);
 /* Floats of the `checkpoints` buffer for lists of up to `isect_capacity` entries (host arithmetic, no GPU work). */
 size_t mgs_raster_checkpoint_floats(uint32_t isect_capacity, int tile_w, int tile_h, int channels,
                                     int checkpoint_interval);

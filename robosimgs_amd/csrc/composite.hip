@@ -12,6 +12,7 @@
 // bg_rgb is the rasteriser's premultiplied accumulation, a its alpha, bg_depth its "ED" channel
 // (z-depth, the convention of nerf2physic_utils.py:120-146).
 #include "mgs_common.h"
+#include "dataset_pixel.h"
 
 namespace mgs {
 namespace {
@@ -69,10 +70,6 @@ extern "C" int mgs_composite_over(int n_px, const float* bg_rgb, const float* bg
 // of the bytes to gather over xGMI or to copy to the host.  HBM-bound: 16 B read, 3 B written.
 namespace mgs {
 namespace {
-__device__ __forceinline__ uint32_t quant8(float v) {
-  return (uint32_t)__float2int_rn(255.f * fminf(fmaxf(v, 0.f), 1.f));
-}
-
 // Four pixels per thread when rgb is packed [P,3]: three 16-byte loads, one 16-byte alpha load,
 // three 4-byte stores (12 output bytes); the generic path (strided rgb, tail) goes pixel by pixel.
 __global__ __launch_bounds__(256) void frame_to_u8_kernel(int n_px, const float* __restrict__ rgb,
@@ -131,8 +128,6 @@ extern "C" int mgs_frame_to_u8(int n_px, const float* rgb, int rgb_stride, const
 // One pass over the frame: 20 B read, 4 + 4 (or 8) B written per pixel.
 namespace mgs {
 namespace {
-struct KInv { double m[9]; };
-
 template <typename DistT>
 __global__ __launch_bounds__(256) void frame_to_dataset_kernel(int width, int height, const float* __restrict__ colors,
                                                                int stride, const float* __restrict__ alpha,
@@ -150,13 +145,8 @@ __global__ __launch_bounds__(256) void frame_to_dataset_kernel(int width, int he
       const uint32_t A = a > 0.f ? max(1u, quant8(a)) : 0u;
       rgba[p] = quant8(c[0] + w * b0) | quant8(c[1] + w * b1) << 8 | quant8(c[2] + w * b2) << 16 | A << 24;
     }
-    if (dist) {
-      const double x = (double)(p % width), y = (double)(p / width);
-      const double rx = (x * ki.m[0] + y * ki.m[1]) + ki.m[2], ry = (x * ki.m[3] + y * ki.m[4]) + ki.m[5],
-                   rz = (x * ki.m[6] + y * ki.m[7]) + ki.m[8];
-      const double norm = sqrt((rx * rx + ry * ry) + rz * rz);
-      dist[p] = (DistT)((double)c[stride - 1] * norm);          // one rounding (fp32 output) or none (fp64)
-    }
+    if (dist)                                                   // one rounding (fp32 / fp16 output) or none (fp64)
+      dist[p] = (DistT)dataset_distance(ki, p % width, p / width, c[stride - 1]);
   }
 }
 }  // namespace

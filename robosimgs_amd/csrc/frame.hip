@@ -38,7 +38,8 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
                                  float eps2d, float near_plane, float far_plane, float radius_clip,
                                  int antialiased, int channels, int flags, const float* backgrounds,
                                  uint32_t isect_capacity, float* render, float* alphas, uint32_t* n_isect,
-                                 uint32_t* status, void* workspace, size_t* workspace_bytes, mgs_stream_t stream) {
+                                 uint32_t* status, uint8_t* ds_rgba, void* ds_distance, int ds_distance_type,
+                                 const double* ds_Kinv_host, void* workspace, size_t* workspace_bytes, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && n_cams >= 1 && width > 0 && height > 0, "render_frames: bad sizes");
   MGS_REQUIRE(channels == 3 || channels == 4, "render_frames: channels must be 3 (RGB) or 4 (RGB + depth), got %d", channels);
   MGS_REQUIRE(workspace_bytes, "render_frames: workspace_bytes is null");
@@ -57,7 +58,11 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
   }
   if (*workspace_bytes < ws.total)
     return mgs::set_error(MGS_ERR_WORKSPACE_TOO_SMALL, "render_frames: workspace %zu < %zu bytes", *workspace_bytes, ws.total);
-  MGS_REQUIRE(viewmats && Ks && render && alphas && n_isect && status, "render_frames: null pointer");
+  MGS_REQUIRE(viewmats && Ks && ((render && alphas) || (ds_rgba && !render && !alphas)) && n_isect && status,
+              "render_frames: null pointer");
+  MGS_REQUIRE(ds_distance_type >= 0 && ds_distance_type <= 2, "render_frames: distance type %d not in {0: f32, 1: f64, 2: f16}",
+              ds_distance_type);
+  const size_t ds_dist_bytes = ds_distance_type == 1 ? 8 : (ds_distance_type == 2 ? 2 : 4);
   MGS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, "render_frames: workspace must be 256-byte aligned");
   char* w = static_cast<char*>(workspace);
   float* depths = reinterpret_cast<float*>(w + ws.depths);
@@ -85,7 +90,10 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
     rc = mgs_rasterize_fwd(n, nullptr, nullptr, nullptr, nullptr, splats, backgrounds ? backgrounds + (size_t)channels * c : nullptr,
                            channels, width, height, tile_w, tile_h, offsets, flatten, order,
                            flags & (MGS_RASTER_EXPECTED_LAST | MGS_RASTER_LATENCY),
-                           render + n_px * channels * c, alphas + n_px * c, nullptr, nullptr, 0, stream);
+                           render ? render + n_px * channels * c : nullptr, alphas ? alphas + n_px * c : nullptr, nullptr, nullptr, 0,
+                           ds_rgba ? ds_rgba + n_px * 4 * c : nullptr,
+                           ds_distance ? static_cast<char*>(ds_distance) + n_px * ds_dist_bytes * c : nullptr, ds_distance_type,
+                           ds_Kinv_host, stream);
     if (rc) return rc;
   }
   return MGS_OK;
@@ -232,7 +240,7 @@ extern "C" int mgs_render_frames_train(int n, const float* means, const float* q
                            backgrounds ? backgrounds + (size_t)channels * c : nullptr, channels, width, height, tile_w, tile_h,
                            I(TF_OFFSETS), I(TF_FLATTEN), I(TF_ORDER), flags & (MGS_RASTER_EXPECTED_LAST | MGS_RASTER_LATENCY),
                            render + n_px * channels * c, alphas + n_px * c, I(TF_LAST_IDS),
-                           checkpoint_interval ? F(TF_CKPT) : nullptr, checkpoint_interval, stream);
+                           checkpoint_interval ? F(TF_CKPT) : nullptr, checkpoint_interval, nullptr, nullptr, 0, nullptr, stream);
     if (rc) return rc;
   }
   return MGS_OK;

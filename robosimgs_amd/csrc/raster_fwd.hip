@@ -11,6 +11,7 @@
 
 #include "raster_common.h"
 #include "tile_order.h"
+#include "dataset_pixel.h"
 
 #ifndef MGS_RASTER_WAVES
 // min waves per SIMD asked of the register allocator (one-wave-per-tile kernel).  5 = at most 96 VGPRs: with the
@@ -253,7 +254,12 @@ __device__ __forceinline__ void blend_pixel_safe_asm(PixelState<CHT>& px, unsign
   if (CHT == 4) px.C[CHT - 1] = c3;
 }
 
-template <int CHT, bool TRACK_LAST>
+// DATASET (4 channels, inference, "ED"): the epilogue writes the dataset frame the reference reads -- RGBA8 + ray distance,
+// dataset_pixel.h -- instead of (or, when render / alphas are given, beside) the float frame: 6 - 12 bytes per pixel leave
+// the kernel instead of 20, and no conversion pass reads them back.  A separate instantiation: the float-frame kernels'
+// code is what it was.
+struct NoDataset {};
+template <int CHT, bool TRACK_LAST, bool DATASET = false>
 __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <= 4 ? MGS_RASTER_WAVES : 1)) void raster_fwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
@@ -261,7 +267,8 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
     float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last, int opts,
-    const int32_t* __restrict__ group_order, float* __restrict__ ckpt, int ckpt_shift) {
+    const int32_t* __restrict__ group_order, float* __restrict__ ckpt, int ckpt_shift,
+    std::conditional_t<DATASET, DatasetOut, NoDataset> ds) {
   constexpr int kWgWaves = TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES;
   __shared__ QueueEntry<CHT> queues[kWgWaves][kQueue + 1];
   QueueEntry<CHT>* queue = queues[threadIdx.x >> 6];
@@ -517,6 +524,20 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
       const float alpha = 1.0f - fabsf(st[k].T);
       // "ED": the last channel (depth sum) leaves as the expected depth, A.2 step 9
       const float inv_alpha = expected_last ? 1.0f / fmaxf(alpha, 1e-10f) : 1.0f;
+      if constexpr (DATASET) {
+        static_assert(CHT == 4 && !TRACK_LAST, "dataset epilogue: RGB + expected depth, inference");
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = st[k].C[c] + (background ? fabsf(st[k].T) * background[c] : 0.f);
+        v[3] *= inv_alpha;
+        dataset_store(ds, p, x, y, v[0], v[1], v[2], v[3], alpha);
+        if (render) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) render[p * 4 + c] = v[c];
+          alphas[p] = alpha;
+        }
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < CHT; ++c)
         if (c < channels) {
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(64 * (TRACK_LAST ? 1 : MGS_RASTER_WG_WAVES), (CHT <
 // quadrant branches in the inner loop, and a quadrant that saturates frees its wave slot at once.
 // The price is that the list is fetched and culled by each of the four waves (L2 hits) and that the
 // pixel offset (2 subtractions) is paid per evaluation instead of per queue entry.
-template <int CHT, bool TRACK_LAST>
+template <int CHT, bool TRACK_LAST, bool DATASET = false>
 __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64 VGPRs / 8 waves per SIMD: 166-172 -> 182 us, left free: 66)
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ feats, const float* __restrict__ opacities,
@@ -546,7 +567,8 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
     int width, int height, int tile_w, int n_tiles, const int32_t* __restrict__ tile_offsets,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
     float* __restrict__ alphas, int32_t* __restrict__ last_ids, int cull, int expected_last,
-    const int32_t* __restrict__ group_order, float* __restrict__ ckpt, int ckpt_shift) {
+    const int32_t* __restrict__ group_order, float* __restrict__ ckpt, int ckpt_shift,
+    std::conditional_t<DATASET, DatasetOut, NoDataset> ds) {
   __shared__ QueueEntry<CHT> queues[4][kQueue];
 #ifdef MGS_RASTER_Q_VGPR_CLOBBER
   // occupancy experiment: naming a high VGPR raises the kernel's register allocation (and lowers its
@@ -726,6 +748,20 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
     const size_t p = (size_t)iy * width + ix;
     const float alpha = 1.0f - fabsf(st.T);
     const float inv_alpha = expected_last ? 1.0f / fmaxf(alpha, 1e-10f) : 1.0f;
+    if constexpr (DATASET) {
+      static_assert(CHT == 4 && !TRACK_LAST, "dataset epilogue: RGB + expected depth, inference");
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = st.C[c] + (background ? fabsf(st.T) * background[c] : 0.f);
+      v[3] *= inv_alpha;
+      dataset_store(ds, p, ix, iy, v[0], v[1], v[2], v[3], alpha);
+      if (render) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) render[p * 4 + c] = v[c];
+        alphas[p] = alpha;
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < CHT; ++c)
       if (c < channels) {
@@ -792,14 +828,29 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
                                  int tile_w, int tile_h, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, const int32_t* tile_group_order, int flags,
                                  float* render, float* alphas, int32_t* last_ids, float* checkpoints,
-                                 int checkpoint_interval, mgs_stream_t stream) {
+                                 int checkpoint_interval, uint8_t* ds_rgba, void* ds_distance, int ds_distance_type,
+                                 const double* ds_Kinv_host, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && width > 0 && height > 0, "rasterize_fwd: bad sizes");
   MGS_REQUIRE(channels >= 1 && channels <= MGS_MAX_CHANNELS, "rasterize_fwd: channels %d outside 1..%d", channels, MGS_MAX_CHANNELS);
   MGS_REQUIRE(tile_w == (width + 15) / 16 && tile_h == (height + 15) / 16,
               "rasterize_fwd: tile grid %dx%d does not match %dx%d at tile size 16", tile_w, tile_h, width, height);
   MGS_REQUIRE(!splats || channels <= 4, "rasterize_fwd: packed splats carry at most 4 channels");
   MGS_REQUIRE((n == 0 || splats || (means2d && conics && feats && opacities)) && tile_offsets &&
-                  flatten_ids && render && alphas, "rasterize_fwd: null pointer");
+                  flatten_ids && ((render && alphas) || (ds_rgba && !render && !alphas)), "rasterize_fwd: null pointer");
+  DatasetOut ds{};
+  if (ds_rgba || ds_distance) {
+    // the dataset frame (RGBA8 + ray distance) straight out of the raster: "RGB+ED" inference frames only
+    MGS_REQUIRE(ds_rgba && channels == 4 && (flags & MGS_RASTER_EXPECTED_LAST) && !last_ids,
+                "rasterize_fwd: the dataset output needs ds_rgba, 4 channels, MGS_RASTER_EXPECTED_LAST and no last_ids");
+    MGS_REQUIRE(((uintptr_t)ds_rgba & 3) == 0, "rasterize_fwd: ds_rgba must be 4-byte aligned");
+    MGS_REQUIRE(!ds_distance || ds_Kinv_host, "rasterize_fwd: the distance map needs K^-1 (host pointer, 9 doubles)");
+    MGS_REQUIRE(ds_distance_type >= 0 && ds_distance_type <= 2, "rasterize_fwd: distance type %d not in {0: f32, 1: f64, 2: f16}",
+                ds_distance_type);
+    ds.rgba = reinterpret_cast<uint32_t*>(ds_rgba);
+    ds.dist = ds_distance;
+    ds.type = ds_distance_type;
+    for (int i = 0; i < 9; ++i) ds.ki.m[i] = ds_Kinv_host ? ds_Kinv_host[i] : 0.0;
+  }
   int ckpt_shift = 0;
   if (checkpoints) {
     MGS_REQUIRE(last_ids, "rasterize_fwd: checkpoints are written by the training variant (last_ids given)");
@@ -819,15 +870,29 @@ extern "C" int mgs_rasterize_fwd(int n, const float* means2d, const float* conic
                      feats, opacities, reinterpret_cast<const float4*>(splats), background,     \
                      channels, width, height, tile_w, n_tiles,                                 \
                      tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull,            \
-                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, g_raster_opts, tile_group_order, checkpoints, ckpt_shift)
+                     (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, g_raster_opts, tile_group_order, checkpoints, ckpt_shift, NoDataset{})
 #define MGS_RQ_LAUNCH_T(C, T)                                                                  \
   hipLaunchKernelGGL((raster_fwd_q_kernel<C, T>), dim3(n_units), dim3(256), (size_t)(g_raster_opts >> 8) * 1024, s, means2d, conics, feats,  \
                      opacities, reinterpret_cast<const float4*>(splats), background, channels, width,      \
                      height, tile_w, n_tiles, tile_offsets, flatten_ids, render, alphas, last_ids,         \
-                     g_raster_cull, (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, tile_group_order, checkpoints, ckpt_shift)
+                     g_raster_cull, (flags & MGS_RASTER_EXPECTED_LAST) ? 1 : 0, tile_group_order, checkpoints, ckpt_shift, NoDataset{})
 #define MGS_RF_LAUNCH(C) do {                                                                      \
     if (per_block && (C) <= 4) { if (last_ids) MGS_RQ_LAUNCH_T(C, true); else MGS_RQ_LAUNCH_T(C, false); } \
     else if (last_ids) MGS_RF_LAUNCH_T(C, true); else MGS_RF_LAUNCH_T(C, false); } while (0)
+  if (ds.rgba) {          // 4 channels, inference, "ED": the dataset instantiations of the two schedules
+    if (per_block)
+      hipLaunchKernelGGL((raster_fwd_q_kernel<4, false, true>), dim3(n_units), dim3(256), (size_t)(g_raster_opts >> 8) * 1024, s,
+                         means2d, conics, feats, opacities, reinterpret_cast<const float4*>(splats), background, channels, width,
+                         height, tile_w, n_tiles, tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull, 1,
+                         tile_group_order, checkpoints, ckpt_shift, ds);
+    else
+      hipLaunchKernelGGL((raster_fwd_kernel<4, false, true>), dim3(div_up(n_units, MGS_RASTER_WG_WAVES)),
+                         dim3(64 * MGS_RASTER_WG_WAVES), (size_t)(g_raster_opts >> 8) * 1024, s, means2d, conics, feats, opacities,
+                         reinterpret_cast<const float4*>(splats), background, channels, width, height, tile_w, n_tiles,
+                         tile_offsets, flatten_ids, render, alphas, last_ids, g_raster_cull, 1, g_raster_opts, tile_group_order,
+                         checkpoints, ckpt_shift, ds);
+    return check_launch("rasterize_fwd");
+  }
   if (channels == 1) MGS_RF_LAUNCH(1);
   else if (channels == 2) MGS_RF_LAUNCH(2);
   else if (channels == 3) MGS_RF_LAUNCH(3);

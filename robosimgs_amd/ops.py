@@ -180,11 +180,14 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
 
 def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height,
                       eps2d, near_plane, far_plane, radius_clip, antialiased, with_depth, capacity,
-                      backgrounds=None, expected_last=False, latency=False, out=None, tight=True, per_axis=False):
+                      backgrounds=None, expected_last=False, latency=False, out=None, tight=True, per_axis=False,
+                      dataset=None, float_frame=True):
     """mgs_render_frames: C inference frames in one C call (no per-Gaussian outputs, scratch reused from camera to
     camera).  viewmats [C,4,4], Ks [C,3,3], backgrounds [C,ch] or None.  Returns (render [C,H,W,ch], alphas [C,H,W],
     n_isects [C] i32, isect_status [C] i32); out = (render, alphas) to write into existing buffers.
-    tight=False: gsplat's classic tile rectangles (MGS_FRAMES_CLASSIC_BOUNDS; same pixels, classic counts)."""
+    tight=False: gsplat's classic tile rectangles (MGS_FRAMES_CLASSIC_BOUNDS; same pixels, classic counts).
+    dataset = (rgba uint8 [C,H,W,4], distance [C,H,W,1] or None, K): the dataset frames straight out of the raster
+    (with_depth and expected_last required); float_frame=False then leaves render / alphas unwritten."""
     dev = means.device
     C, n = viewmats.shape[0], means.shape[0]
     ch = 4 if with_depth else 3
@@ -202,7 +205,10 @@ def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, vie
             int(bool(antialiased)), ch,
             int(bool(expected_last)) | (2 if latency else 0) | (0 if tight else 4) | (8 if per_axis else 0),
             ptr(backgrounds),
-            int(capacity), ptr(render), ptr(alphas), ptr(n_isect), ptr(status)]
+            int(capacity), ptr(render) if (float_frame or dataset is None) else None,
+            ptr(alphas) if (float_frame or dataset is None) else None, ptr(n_isect), ptr(status)]
+    ds = dataset_args(dataset)
+    args += list(ds[:4])
     check(L.mgs_render_frames(*args, None, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames(size query)")
     ws = _workspace(nbytes.value + 256, dev)
     base = ws.data_ptr()
@@ -335,11 +341,30 @@ def render_frames_backward_raw(means, quats, scales, opacities, sh_degree, sh_co
     return v_means, v_quats, v_scales, v_sh, v_opac, v_vm, v_m2d, v_abs
 
 
+def dataset_args(dataset):
+    """(ds_rgba, ds_distance, ds_distance_type, ds_Kinv_host, keep-alive) for the C calls that take a dataset output;
+    dataset = (rgba uint8 [..,H,W,4], distance [..,H,W,1] or None, K [3,3]) or None."""
+    if dataset is None:
+        return None, None, 0, None, None
+    import numpy as np
+    rgba, dist, K = dataset
+    if rgba.dtype != torch.uint8 or not rgba.is_contiguous():
+        raise ValueError("dataset rgba must be a contiguous uint8 tensor [..., H, W, 4]")
+    if dist is not None and (not dist.is_contiguous() or dist.dtype not in (torch.float16, torch.float32, torch.float64)):
+        raise ValueError("dataset distance must be a contiguous float16 / float32 / float64 tensor [..., H, W, 1]")
+    kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(K, dtype=np.float64).reshape(3, 3))) if dist is not None else None
+    dtype_id = {torch.float64: 1, torch.float16: 2}.get(dist.dtype, 0) if dist is not None else 0
+    return ptr(rgba), ptr(dist), dtype_id, (kinv.ctypes.data if kinv is not None else None), kinv
+
+
 def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                       tile_h, tile_offsets, flatten_ids, out=None, track_last=True, splats=None,
                       expected_last=False, latency=False, group_order=None, channels=None,
-                      checkpoints=None, checkpoint_interval=0):
-    """out = (render, alphas, last_ids|None) to write into existing buffers.  With `splats` (<= 4 channels)
+                      checkpoints=None, checkpoint_interval=0, dataset=None):
+    """out = (render, alphas, last_ids|None) to write into existing buffers.
+    dataset = (rgba uint8 [H,W,4], distance [H,W,1] f16 / f32 / f64 or None, K 3x3 numpy): the dataset frame straight
+    out of the raster (include/mgs.h: ds_* arguments; 4 channels, expected_last, inference); out = (None, None, None)
+    then skips the float frame altogether.  With `splats` (<= 4 channels)
     means2d / conics / feats / opacities are not read and may be None; give `channels` then.  track_last=False (or
     last_ids None) is the inference variant: no last_ids, one select less per pair.
     expected_last: the last channel leaves divided by max(alpha, 1e-10) ("ED" modes).
@@ -359,12 +384,13 @@ def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, heig
                     else None)
     else:
         render, alphas, last_ids = out
+    ds = dataset_args(dataset)
     check(_lib.lib().mgs_rasterize_fwd(n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities),
                                        ptr(splats), ptr(background), ch, width, height, tile_w, tile_h,
                                        ptr(tile_offsets), ptr(flatten_ids), ptr(group_order),
                                        int(bool(expected_last)) | (2 if latency else 0),
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(checkpoints),
-                                       int(checkpoint_interval), stream_handle()),
+                                       int(checkpoint_interval), *ds[:4], stream_handle()),
           "mgs_rasterize_fwd")
     return render, alphas, last_ids
 

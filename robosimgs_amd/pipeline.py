@@ -105,18 +105,19 @@ class FrameRenderer:
                  capacity_margin: float = 1.5, background: Optional[torch.Tensor] = None,
                  sizing_camera=None, group_ids: Optional[torch.Tensor] = None, n_groups: int = 0,
                  rotate_sh: bool = True, reorder: Optional[str] = "morton", dataset_output=None, dataset_K=None,
-                 **raster_kw):
+                 dataset_keep_float: bool = False, **raster_kw):
         """tensors: dict(means, quats, scales, opacities, colors, sh_degree) on the GPU
         (Gaussians.to_torch()); `self.t` is the renderer's own (by default Morton-ordered) copy.  isect_capacity: slots reserved for tile intersections per
         frame; if None it is measured once with `sizing_camera` = (viewmat, K) (required then)
         and multiplied by `capacity_margin`.  A frame that needs more raises on fetch().
 
         dataset_output (torch.float16 / float32 / float64) with dataset_K (the 3x3 intrinsics every camera of the run
-        shares; render_mode "RGB+ED"): every slot's graph ends with the conversion into the dataset frame the reference
-        reads -- RGBA8 + ray distance (dataset.frame_to_dataset) -- in the slot's own buffer; fetch() then also returns
-        "rgba" [H,W,4] u8, "distance" [H,W,1] and "dataset" (both as one flat byte buffer: ONE copy puts a frame into a
-        gather's staging area).  The conversion runs on the slot's stream with the frame, not on the consumer's between
-        fetch() and release(): a slot held while the consumer converted its frame cost the multi-GPU loop 10 %.
+        shares; render_mode "RGB+ED"): the frames leave the RASTER as the dataset frames the reference reads -- RGBA8 +
+        ray distance, byte for byte what dataset.frame_to_dataset makes of the float frame -- in the slot's own buffer;
+        fetch() returns "rgba" [H,W,4] u8, "distance" [H,W,1] and "dataset" (both as one flat byte buffer: ONE copy puts a
+        frame into a gather's staging area).  6 - 12 bytes per pixel leave the kernel instead of 20 and no conversion
+        pass reads them back.  dataset_keep_float=False (default): the float frame is not written at all and fetch()
+        returns colors = alphas = None; True writes both.
 
         Dynamic scenes (articulated parts, a moving robot): give group_ids (int32 [N] on the GPU,
         -1 = static) and n_groups; submit(..., rotations=, translations=[, scales=]) then poses
@@ -149,7 +150,7 @@ class FrameRenderer:
         self.dev = tensors["means"].device
         self.width, self.height, self.mode = int(width), int(height), render_mode
         self.kw = dict(raster_kw)
-        self.dataset_dtype, self.dataset_K = dataset_output, None
+        self.dataset_dtype, self.dataset_K, self.dataset_keep_float = dataset_output, None, bool(dataset_keep_float)
         if dataset_output is not None:
             if dataset_K is None or render_mode != "RGB+ED":
                 raise ValueError("dataset_output needs dataset_K (the shared 3x3 intrinsics) and render_mode='RGB+ED'")
@@ -181,12 +182,12 @@ class FrameRenderer:
         Kt = torch.as_tensor(np.asarray(K, dtype=np.float32)).reshape(1, 3, 3).to(self.dev)
         return vm, Kt
 
-    def _raster(self, vm, K, cap, t=None):
+    def _raster(self, vm, K, cap, t=None, dataset_out=None):
         t = self.t if t is None else t
         return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm,
                              K, self.width, self.height, sh_degree=t.get("sh_degree"),
                              render_mode=self.mode, backgrounds=self.bg, isect_capacity=cap,
-                             **self.kw)
+                             dataset_out=dataset_out, **self.kw)
 
     def _capture_slot(self, stream) -> Dict:
         # the slot's camera: one 25-float device buffer (viewmat | K), so a submit is ONE small copy
@@ -205,22 +206,22 @@ class FrameRenderer:
                     "t": {k: (v.clone() if torch.is_tensor(v) and k in ("means", "quats", "scales", "colors") else v)
                           for k, v in self.t.items()}}
 
-        def body():
-            if pose is None:
-                return self._raster(vm, K, self.capacity)
-            from .transform import transform_gaussians
-            posed = transform_gaussians(self.t, group_ids=self.group_ids, rotate_sh=self.rotate_sh,
-                                        out=pose["t"], packed=(pose["x"], pose["r"]))
-            return self._raster(vm, K, self.capacity, posed)
-
-        ds = None
+        ds, ds_out = None, None
         if self.dataset_dtype is not None:          # the slot's dataset frame: [RGBA8 plane | distance plane] as bytes
-            from .dataset import frame_to_dataset
             n_px = self.width * self.height
             flat = torch.empty(n_px * (4 + torch.empty(0, dtype=self.dataset_dtype).element_size()), dtype=torch.uint8,
                                device=self.dev)
             ds = {"dataset": flat, "rgba": flat[:n_px * 4].view(self.height, self.width, 4),
                   "distance": flat[n_px * 4:].view(self.dataset_dtype).view(self.height, self.width, 1)}
+            ds_out = (ds["rgba"].unsqueeze(0), ds["distance"].unsqueeze(0), self.dataset_K, self.dataset_keep_float)
+
+        def body():
+            if pose is None:
+                return self._raster(vm, K, self.capacity, dataset_out=ds_out)
+            from .transform import transform_gaussians
+            posed = transform_gaussians(self.t, group_ids=self.group_ids, rotate_sh=self.rotate_sh,
+                                        out=pose["t"], packed=(pose["x"], pose["r"]))
+            return self._raster(vm, K, self.capacity, posed, dataset_out=ds_out)
         with torch.cuda.stream(stream):
             for _ in range(2):
                 body()
@@ -228,8 +229,6 @@ class FrameRenderer:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 colors, alphas, meta = body()
-                if ds is not None:
-                    frame_to_dataset(colors[0], alphas[0], self.dataset_K, out=(ds["rgba"], ds["distance"]))
         torch.cuda.synchronize(self.dev)
         return {"stream": stream, "vm": vm, "K": K, "cam": cam, "pose": pose, "graph": graph, "colors": colors,
                 "alphas": alphas, "meta": meta, "done": torch.cuda.Event(),
@@ -306,6 +305,8 @@ class FrameRenderer:
         out = {"colors": s["colors"][0], "alphas": s["alphas"][0], "meta": s["meta"]}
         if s["ds"] is not None:
             out.update(s["ds"])
+            if not self.dataset_keep_float:          # the float frame was never written
+                out["colors"] = out["alphas"] = None
         return out
 
     def release(self, ticket: int) -> None:

@@ -57,7 +57,7 @@ class _RenderSH(torch.autograd.Function):
     def forward(ctx, means, quats, scales, opacities, sh_coeffs, viewmats, Ks, backgrounds,
                 width, height, sh_degree, eps2d, near_plane, far_plane, radius_clip,
                 antialiased, with_depth, isect_capacity, absgrad, meta_out, tight, expected_depth,
-                latency, lean, segment):
+                latency, lean, segment, dataset=None):
         C = viewmats.shape[0]
         dev = means.device
         # `tight` carries the binning policy: bit 0 tightened tile rectangles, bit 1 the per-axis (gsplat >= 1.5) radius rule
@@ -74,13 +74,18 @@ class _RenderSH(torch.autograd.Function):
         # records, the binning seed and the depths; radii / means2d / conics / feats / tiles_per_gauss are neither
         # written nor returned (36 + 4 MB of stores per 1 M Gaussians)
         lean = bool(lean) and not training and isect_capacity is not None
+        if dataset is not None and not lean:
+            raise ValueError("dataset_out needs inference frames through the one-call path: lean_meta=True, isect_capacity "
+                             "given, no gradients")
         if lean:
             # the whole batch of cameras behind ONE C call (mgs_render_frames): per-camera scratch is reused, nothing
             # per Gaussian is returned
             _, _, n_isects, status = ops.render_frames_raw(
                 means, quats, scales, opacities, sh_degree, sh_coeffs, viewmats, Ks, width, height, eps2d,
                 near_plane, far_plane, radius_clip, antialiased, with_depth, isect_capacity, backgrounds=backgrounds,
-                expected_last=expected_depth, latency=latency, out=(render, alphas), tight=tight, per_axis=per_axis)
+                expected_last=expected_depth, latency=latency, out=(render, alphas), tight=tight, per_axis=per_axis,
+                dataset=dataset[:3] if dataset is not None else None,
+                float_frame=dataset is None or bool(dataset[3]))
             meta_out["lean"] = dict(n_isects=n_isects, isect_status=status)
             ctx.set_materialize_grads(False)
             return render, alphas.unsqueeze(-1)
@@ -181,7 +186,7 @@ class _RenderSH(torch.autograd.Function):
                 if ctx.expected_depth:
                     vr = torch.cat([vr[..., :-1], (vr[..., -1] / alphas.clamp(min=1e-10)).unsqueeze(-1)], dim=-1)
                 v_bg = (vr * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-            return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 17
+            return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 18
         # "RGB+ED": the raster backward's prologue undoes the divide by max(alpha, 1e-10) itself
         # (expected_render=...); only a background gradient needs the converted cotangent here
         # the first camera overwrites the outputs, later ones accumulate: no zero-fill pass
@@ -237,7 +242,7 @@ class _RenderSH(torch.autograd.Function):
                 v_render = torch.cat([v_render[..., :-1],
                                       (v_render[..., -1] / alphas.clamp(min=1e-10)).unsqueeze(-1)], dim=-1)
             v_bg = (v_render * (1.0 - alphas).unsqueeze(-1)).sum(dim=(1, 2))
-        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 17
+        return (v_means, v_quats, v_scales, v_opacities, v_sh, v_viewmats, None, v_bg) + (None,) * 18
 
 
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor,
@@ -252,8 +257,14 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                   raster_schedule: str = "latency",
                   lean_meta: bool = False,
                   backward_segment: int = 256,
-                  radius_rule: str = "classic") -> Tuple[Tensor, Tensor, Dict]:
+                  radius_rule: str = "classic",
+                  dataset_out=None) -> Tuple[Tensor, Tensor, Dict]:
     """Render N Gaussians from C cameras.
+
+    dataset_out = (rgba uint8 [C,H,W,4], distance [C,H,W,1] float16 / 32 / 64 or None, K [3,3], keep_float_frame):
+    inference frames ("RGB+ED", lean_meta=True, isect_capacity given) leave the raster as the dataset frames the
+    reference's readers open (dataset.frame_to_dataset's bytes) in the caller's buffers; with keep_float_frame False the
+    float frame is not written at all and the returned colours / alphas are unspecified.
 
     radius_rule: "classic" -- gsplat 1.4's single radius ceil(3 sqrt(lambda_1)) per Gaussian (the
     semantics this build's parity claim is made for) -- or "opacity_aware" -- gsplat >= 1.5's per-axis extents
@@ -342,7 +353,7 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
             int(sh_degree), float(eps2d), float(near_plane), float(far_plane),
             float(radius_clip), antialiased, want_depth, isect_capacity, bool(absgrad), store,
             int(tile_bounds == "tight") | (2 if rule else 0), render_mode in ("RGB+ED", "ED"), raster_schedule == "latency",
-            bool(lean_meta), int(backward_segment))
+            bool(lean_meta), int(backward_segment), dataset_out)
         if depth_only_via_sh:
             render = render[..., 3:4]
         if "lean" in store:             # inference frames through mgs_render_frames: counts and status only

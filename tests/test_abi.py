@@ -73,7 +73,8 @@ def test_library_is_gfx950_only_and_links_no_torch():
 def test_argument_errors_are_reported_without_a_gpu():
     from robosimgs_amd import _lib
     L = _lib.lib()
-    rc = L.mgs_rasterize_fwd(1, None, None, None, None, None, None, 99, 16, 16, 1, 1, None, None, None, 0, None, None, None, None, 0, None)
+    rc = L.mgs_rasterize_fwd(1, None, None, None, None, None, None, 99, 16, 16, 1, 1, None, None, None, 0, None, None, None, None, 0,
+                             None, None, 0, None, None)
     assert rc == -1 and b"channels" in L.mgs_last_error_string()
     rc = L.mgs_sh_fwd(4, 7, 16, None, None, None, None, None)
     assert rc == -1 and b"degree" in L.mgs_last_error_string()

@@ -72,32 +72,79 @@ def test_rendered_frame_through_the_writer_and_back(tmp_path):
     assert sorted(os.listdir(wr.depth_dir)) == [f"frame_{i:05d}.npy.gz" for i in range(3)]
 
 
+@pytest.mark.parametrize("dt,sched,bg", [(torch.float16, "throughput", False), (torch.float32, "latency", True),
+                                         (torch.float64, "throughput", True), (None, "latency", False)])
+def test_dataset_frame_straight_out_of_the_raster_equals_the_conversion_kernel(dt, sched, bg):
+    """mgs_rasterize_fwd's ds_* outputs (rasterization(dataset_out=...), through mgs_render_frames): RGBA8 + ray distance
+    written by the raster's epilogue are, byte for byte, what mgs_frame_to_dataset makes of the float frame -- both raster
+    schedules, every distance type, with a background, with and without the float frame beside them, several cameras."""
+    from robosimgs_amd import camera_ring, rasterization, synthetic_scene
+    from robosimgs_amd.dataset import frame_to_dataset
+    W, H, C = 200, 136, 3                       # ragged: not multiples of the 16-pixel tile
+    g = synthetic_scene(20_000, math.log(0.05), 2, 4)
+    cams = camera_ring(C, W, H)
+    t = g.to_torch(DEV, 2)
+    vm = torch.from_numpy(np.stack([c.viewmat() for c in cams]).astype(np.float32)).to(DEV)
+    Ks = torch.from_numpy(np.stack([c.K for c in cams]).astype(np.float32)).to(DEV)
+    bgs = torch.rand(C, 4, device=DEV) * 0.5 if bg else None
+    kw = dict(sh_degree=2, render_mode="RGB+ED", isect_capacity=600_000, lean_meta=True, raster_schedule=sched, backgrounds=bgs)
+    with torch.no_grad():
+        c0, a0, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, W, H, **kw)
+        for keep in (True, False):
+            rgba = torch.zeros(C, H, W, 4, dtype=torch.uint8, device=DEV)
+            dist = torch.zeros(C, H, W, 1, dtype=dt, device=DEV) if dt is not None else None
+            c1, a1, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, W, H,
+                                      dataset_out=(rgba, dist, cams[0].K, keep), **kw)
+            if keep:
+                assert torch.equal(c1, c0) and torch.equal(a1, a0)              # the float frame beside it: the same bits
+            for c in range(C):
+                r_ref, d_ref = frame_to_dataset(c0[c], a0[c], cams[0].K if dt is not None else None, distance_dtype=dt)
+                assert torch.equal(rgba[c], r_ref), (c, keep)
+                if dt is not None:
+                    assert torch.equal(dist[c], d_ref), (c, keep)
+            assert int((rgba[..., 3] > 0).sum()) > 0.2 * C * W * H
+    # what the output needs: "RGB+ED" inference frames through the one-call path
+    rgba = torch.zeros(C, H, W, 4, dtype=torch.uint8, device=DEV)
+    from robosimgs_amd import _lib
+    with pytest.raises(ValueError):
+        rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, W, H, sh_degree=2,
+                      render_mode="RGB+ED", dataset_out=(rgba, None, None, True))          # no capacity: not the lean path
+    with pytest.raises(_lib.MgsError):
+        rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, Ks, W, H, sh_degree=2,
+                      render_mode="RGB+D", isect_capacity=600_000, lean_meta=True, dataset_out=(rgba, None, None, True))
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.float32])
-def test_frame_renderer_converts_inside_the_slots_graphs(dt):
-    """FrameRenderer(dataset_output=, dataset_K=): the dataset frame (RGBA8 + ray distance) leaves the slot's own graph --
-    the very bytes frame_to_dataset gives on the fetched float frame, for every frame of a sequence, as three views of
-    one flat buffer (what the multi-GPU loop copies into its gather batch)."""
+def test_frame_renderer_dataset_frames(dt):
+    """FrameRenderer(dataset_output=, dataset_K=): the slots' graphs write the dataset frame from the raster; every frame
+    of a sequence is, byte for byte, frame_to_dataset of the float frame a plain renderer gives for the same camera --
+    as three views of one flat buffer (what the multi-GPU loop copies into its gather batch)."""
     from robosimgs_amd import FrameRenderer, camera_ring, synthetic_scene
     from robosimgs_amd.dataset import frame_to_dataset
     W, H = 208, 144
     g = synthetic_scene(20_000, math.log(0.05), 2, 4)
     cams = camera_ring(7, W, H)
     t = g.to_torch(DEV, 2)
-    fr = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=3, isect_capacity=600_000, dataset_output=dt,
-                       dataset_K=cams[0].K)
+    plain = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=3, isect_capacity=600_000)
+    ref = {}
+    plain.render_sequence(cams, lambda i, f: ref.__setitem__(i, frame_to_dataset(f["colors"], f["alphas"], cams[0].K,
+                                                                                 distance_dtype=dt)))
     seen = []
+    for keep in (False, True):
+        fr = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=3, isect_capacity=600_000, dataset_output=dt,
+                           dataset_K=cams[0].K, dataset_keep_float=keep)
 
-    def consume(i, f):
-        rgba, dist = frame_to_dataset(f["colors"], f["alphas"], cams[0].K, distance_dtype=dt)
-        assert torch.equal(f["rgba"], rgba) and torch.equal(f["distance"], dist)
-        n = W * H * 4
-        assert f["dataset"].dtype == torch.uint8 and f["dataset"].numel() == n + W * H * dist.element_size()
-        assert torch.equal(f["dataset"][:n].view(H, W, 4), rgba)
-        assert torch.equal(f["dataset"][n:].view(dt).view(H, W, 1), dist)
-        assert int((rgba[..., 3] > 0).sum()) > 0.2 * W * H
-        seen.append(i)
-    fr.render_sequence(cams, consume)
-    assert seen == list(range(7))
+        def consume(i, f):
+            rgba, dist = ref[i]
+            assert torch.equal(f["rgba"], rgba) and torch.equal(f["distance"], dist)
+            n = W * H * 4
+            assert f["dataset"].dtype == torch.uint8 and f["dataset"].numel() == n + W * H * dist.element_size()
+            assert torch.equal(f["dataset"][:n].view(H, W, 4), rgba)
+            assert torch.equal(f["dataset"][n:].view(dt).view(H, W, 1), dist)
+            assert (f["colors"] is None and f["alphas"] is None) if not keep else f["colors"].shape == (H, W, 4)
+            seen.append(i)
+        fr.render_sequence(cams, consume)
+    assert seen == list(range(7)) * 2
     with pytest.raises(ValueError):
         FrameRenderer(t, W, H, render_mode="RGB", isect_capacity=600_000, dataset_output=dt, dataset_K=cams[0].K)
     with pytest.raises(ValueError):
