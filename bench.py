@@ -94,10 +94,10 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--bwd-steps", type=int, default=30)
-    ap.add_argument("--convert-in-graph", action="store_true",
-                    help="N > 1: convert frames to the dataset payload inside the slots' graphs (FrameRenderer(dataset_output=)) "
-                         "instead of on the consumer stream between fetch and release; measured in a world of one: 4,111-4,131 "
-                         "against 4,199-4,219 frames/s, so the consumer-side conversion stays the default")
+    ap.add_argument("--convert-on-consumer", action="store_true",
+                    help="N > 1: render float frames and convert them to the dataset payload on the consumer stream between "
+                         "fetch and release (the round-3 loop) instead of letting the raster write the payload "
+                         "(FrameRenderer(dataset_output=)); world of one: 4,124-4,156 against 4,356-4,380 frames/s")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="repeat the K-step region until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (5 M Gaussians at 3840x2160)")
@@ -257,12 +257,13 @@ def main():
     # the same frames with the scene in the order it was given are timed further down and reported beside `value`
     fr = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap,
                        reorder=None if a.no_reorder else "morton")
-    # N > 1 with a dataset payload and --convert-in-graph: the conversion into the payload is the last node of every slot's
-    # graph (on the slot's stream, beside the other frames), the consumer only copies the 12 - 17 MB frame into the batch
+    # N > 1 with a dataset payload: the raster writes the payload itself (RGBA8 + ray distance from its epilogue: 6 - 8 B per
+    # pixel leave the kernel instead of 20, no conversion pass) and the frame is copied into the gather batch on the slot's
+    # own stream; --convert-on-consumer keeps the float frames and the consumer-side conversion
     fr_by_payload = {}
     if ring and not a.no_gather:
         for m_, dt_ in (("dataset16", torch.float16), ("dataset", torch.float32)):
-            if a.gather_dtype == m_ and a.convert_in_graph:
+            if a.gather_dtype == m_ and not a.convert_on_consumer:
                 fr_by_payload[m_] = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap,
                                                   reorder=None if a.no_reorder else "morton", dataset_output=dt_,
                                                   dataset_K=K_host)
@@ -329,8 +330,8 @@ def main():
                 if j == 0 and pending[cur] is not None:    # the collective that last read this staging buffer
                     pending[cur].wait()                    # (NCCL: the current STREAM waits, not the host)
                     pending[cur] = None
-                if g_ds and "dataset" in f:                # converted in the slot's graph and copied into the batch on the
-                    torch.cuda.current_stream().wait_event(copied.pop(0))     # slot's stream (submit): only wait for it
+                if g_ds and "dataset" in f:                # written by the raster and copied into the batch on the slot's
+                    torch.cuda.current_stream().wait_event(copied.pop(0))     # stream (submit): only wait for it
                 elif g_ds:                                 # RGBA8 + ray distance, one kernel, inside the timed region
                     flat = staging[cur][j].view(-1)
                     frame_to_dataset(f["colors"], f["alphas"], K_host, out=(flat[:H * W * 4].view(H, W, 4),

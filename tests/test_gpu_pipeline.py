@@ -197,7 +197,7 @@ def test_batched_cameras_through_one_call_equal_the_per_camera_frames():
         check_isect_status(m2)
     L = _lib.lib()
     rc = L.mgs_render_frames(4, None, None, None, None, 0, 1, None, 1, None, None, 16, 16, 0.3, 0.01, 1e10, 0.0, 0, 7, 0, None,
-                             100, None, None, None, None, None, None, None)
+                             100, None, None, None, None, None, None, 0, None, None, None, None)
     assert rc == -1 and b"channels" in L.mgs_last_error_string()
 
 
