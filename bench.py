@@ -622,8 +622,8 @@ def main():
         achieved = algo_bytes / (raster_ms * 1e-3) / 1e9
         achieved_walked = walked_bytes / (raster_ms * 1e-3) / 1e9
         traffic, traffic_note = pmc_traffic("raster_fwd_q" if timed_latency else "raster_fwd", (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3))
-        result["roofline"] = {"kernel": (f"raster_fwd_q_kernel<{ch}, false>" if timed_latency
-                                         else f"raster_fwd_kernel<{ch}, false>"), "bound": "hbm",
+        result["roofline"] = {"kernel": (f"raster_fwd_q_kernel<{ch}, false, false>" if timed_latency
+                                         else f"raster_fwd_kernel<{ch}, false, false>"), "bound": "hbm",
                               "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4),
                               "traffic": traffic, "traffic_source": traffic_note,
@@ -635,7 +635,7 @@ def main():
                                                   "frac": round(achieved_walked / HBM_PEAK_GBS, 4),
                                                   "note": "n_isect_binned * 44 + n_px * 20 + tiles * 8: the "
                                                           "tightened lists the kernel walks, no last_ids store"},
-                              "valu": pmc_valu("raster_fwd_q_kernel<4, false>" if timed_latency else "raster_fwd_kernel<4, false>",
+                              "valu": pmc_valu("raster_fwd_q_kernel<4, false, false>" if timed_latency else "raster_fwd_kernel<4, false, false>",
                                                (a.n, W, H, deg) == (1_000_000, 1920, 1080, 3)),
                               "note": "VALU-bound kernel (DESIGN.md 4.3): `valu` says how close it runs to the issue rate "
                                       "of its own instruction mix; the HBM fraction is reported as the contract asks"}

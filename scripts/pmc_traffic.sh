@@ -28,7 +28,7 @@ def agg(d):
             a[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return a
 rec = {"stamp": hip_build.current_stamp(), "workload": "configs[1]: 1M Gaussians, SH 3, 1920x1080, tight lists, 4 channels (RGB+ED)", "kernels": {}, "raw": {}}
-pick = {"raster_inf": ("raster_fwd", "raster_fwd_kernel<4, false>"), "raster_inf_q": ("raster_fwd_q", "raster_fwd_q_kernel<4, false>"), "raster_bwd_split": ("raster_bwd", "raster_bwd_kernel"), "project": ("project", "project_color_fwd_kernel")}
+pick = {"raster_inf": ("raster_fwd", "raster_fwd_kernel<4, false, false>"), "raster_inf_q": ("raster_fwd_q", "raster_fwd_q_kernel<4, false, false>"), "raster_bwd_split": ("raster_bwd", "raster_bwd_kernel"), "project": ("project", "project_color_fwd_kernel")}
 for stage in ("raster_inf", "raster_inf_q", "raster_bwd_split", "project", "binning"):
     F, Wr, S = agg(stage + "_FETCH_SIZE"), agg(stage + "_WRITE_SIZE"), agg(stage + "_SQ_INSTS_VALU")
     for k in set(F) | set(Wr) | set(S):
@@ -37,7 +37,7 @@ for stage in ("raster_inf", "raster_inf_q", "raster_bwd_split", "project", "binn
         row = {"FETCH_SIZE_KiB": m(F, "FETCH_SIZE"), "WRITE_SIZE_KiB": m(Wr, "WRITE_SIZE")}
         for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE"):
             row[c] = m(S, c)
-        rec["raw"][stage + ":" + k[:70]] = row
+        rec["raw"][stage + ":" + k.replace("void ", "").replace("mgs::(anonymous namespace)::", "")[:70]] = row
         if stage in pick and pick[stage][1] in k and row["FETCH_SIZE_KiB"] is not None and row["WRITE_SIZE_KiB"] is not None:
             rec["kernels"][pick[stage][0]] = {
                 "kernel": k[:90], "traffic_bytes": int(2 * row["FETCH_SIZE_KiB"] * 1024 + row["WRITE_SIZE_KiB"] * 1024),
@@ -45,6 +45,6 @@ for stage in ("raster_inf", "raster_inf_q", "raster_bwd_split", "project", "binn
 json.dump(rec, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(rec["kernels"], indent=1))
 for k, v in rec["raw"].items():
-    if k.startswith("raster_inf") and "kernel<4, false>" in k or k.startswith("raster_bwd_split:") and "raster_bwd" in k:
+    if k.startswith("raster_inf") and "kernel<4, false" in k or k.startswith("raster_bwd_split:") and "raster_bwd" in k:
         print(k[:60], {a: (round(b) if b else b) for a, b in v.items()})
 PY

@@ -6,7 +6,7 @@ r = json.load(open(path))
 keep = {}
 for k, v in r["raw"].items():
     st, name = k.split(":", 1)
-    if (st == "raster_inf" and "raster_fwd_kernel<4, false>" in name) or (st == "raster_inf_q" and "raster_fwd_q" in name) \
+    if (st == "raster_inf" and "raster_fwd_kernel<4, false, false>" in name) or (st == "raster_inf_q" and "raster_fwd_q" in name) \
             or (st == "raster_bwd_split" and ("raster_bwd" in name or "reduce_rec" in name or "unit_table" in name)) or (st == "project" and "project_color" in name) \
             or (st == "binning" and "raster" not in name and "project" not in name):
         keep[k] = v
