@@ -302,6 +302,7 @@ def main():
             gather_bufs = [[torch.empty(batch_shape, device=comm_dev, dtype=g_dtype) for _ in range(world)]
                            for _ in range(2)]
         pending = [None, None]
+        last_work = [None, None]
         state = {"cur": 0, "fill": 0, "shipped": 0, "target": 0}
         sizes_all = shard_sizes(RING, world, weights) if ring else [1]
         tickets = []
@@ -314,6 +315,7 @@ def main():
                 host_staging[cur].copy_(src)                           # synchronous host copy
                 src = host_staging[cur]
             pending[cur] = dist.gather(src, gather_bufs[cur] if rank == 0 else None, dst=0, async_op=True)
+            last_work[cur] = pending[cur]                  # (the submit side's copies into this buffer wait for it)
             state["cur"], state["fill"] = cur ^ 1, 0
             state["shipped"] += 1
 
@@ -365,8 +367,8 @@ def main():
                 slot = fr._slots[tickets[-1]]
                 cur, j = (sub["cur0"] + sub["q"] // GB) & 1, sub["q"] % GB
                 with torch.cuda.stream(slot["stream"]):
-                    if j == 0 and pending[cur] is not None:   # the collective that last read this staging buffer (issued by
-                        pending[cur].wait()                   # now: GB >= frames in flight - 1); the slot's stream waits
+                    if last_work[cur] is not None:            # the collective that last read this staging buffer (issued by
+                        last_work[cur].wait()                 # now: GB >= frames in flight - 1): EVERY slot's stream waits
                     staging[cur][j].view(-1).copy_(slot["ds"]["dataset"], non_blocking=True)
                     e_ = torch.cuda.Event()
                     e_.record()
