@@ -350,6 +350,7 @@ def main():
                     ev["convert"].append((c0, c1))
                     ev["last"] = c1
                 if state["fill"] == GB:
+                    state.update(last_buf=cur, last_fill=GB)
                     ship()
             fr.release(tk)
 
@@ -387,6 +388,7 @@ def main():
             while tickets:
                 retire()
             if do_gather and state["fill"] > 0:            # a partial last batch still travels (whole buffer)
+                state.update(last_buf=state["cur"], last_fill=state["fill"])
                 ship()
             if do_gather and world > 1:
                 # unequal shards (weighted, or 64 cameras over e.g. 3 ranks): ranks with fewer frames issue padding
@@ -445,6 +447,24 @@ def main():
             # the collective really delivered every rank's frame (all cameras see the scene)
             for r_ in range(world):
                 assert float(gather_bufs[0][r_][0].float().abs().max()) > 0.0, f"rank {r_}: empty gathered frame"
+        if do_gather and g_ds and cam_devs and "last_buf" in state:
+            # every rank, outside the timed regions, no collective: the batch it shipped last holds, frame by frame and byte
+            # for byte, the dataset frames of the cameras that were due -- the loop's bookkeeping (which frame goes where in
+            # which buffer, who waits for whom) checked against frames rendered afresh
+            torch.cuda.synchronize()
+            total, nl, b = len(cam_devs) * a.steps, state["last_fill"], state["last_buf"]
+            for i in range(nl):
+                tk = fr.submit(cam_devs[(total - nl + i) % len(cam_devs)])
+                f = fr.fetch(tk, check=False)
+                if "dataset" in f:
+                    exp = f["dataset"]
+                else:
+                    exp = torch.empty_like(staging[b][i]).view(-1)
+                    frame_to_dataset(f["colors"], f["alphas"], K_host, out=(exp[:H * W * 4].view(H, W, 4),
+                                                                            exp[H * W * 4:].view(g_dist).view(H, W, 1)))
+                torch.cuda.synchronize()
+                assert torch.equal(staging[b][i].view(-1), exp.view(-1)), f"rank {rank}: frame {i} of the last shipped batch is not the camera's frame"
+                fr.release(tk)
         return regs, state["shipped"]
 
     g_mode = a.gather_dtype
