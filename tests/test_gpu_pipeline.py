@@ -259,11 +259,11 @@ def test_slot_streams_sit_on_distinct_hardware_queues_and_are_reused():
     assert len({s.cuda_stream for s in a}) == 3
     cur = torch.cuda.current_stream(dev)
     assert all(s.cuda_stream != cur.cuda_stream for s in a)
-    one = min(pipeline._spin_pair_ms(cur, cur, dev) for _ in range(3)) / 2.0
-    for i, s in enumerate(a):                   # two spins on independent queues overlap: well under twice one spin
-        assert min(pipeline._spin_pair_ms(cur, s, dev) for _ in range(3)) < 1.5 * one, i
+    one = min(pipeline._spin_pair_ms(cur, cur, dev) for _ in range(5)) / 2.0
+    for i, s in enumerate(a):                   # two spins on independent queues overlap: well under twice one spin (2.0 = one queue)
+        assert min(pipeline._spin_pair_ms(cur, s, dev) for _ in range(5)) < 1.7 * one, i
         for r in a[i + 1:]:
-            assert min(pipeline._spin_pair_ms(s, r, dev) for _ in range(3)) < 1.5 * one
+            assert min(pipeline._spin_pair_ms(s, r, dev) for _ in range(5)) < 1.7 * one
     # more slots than hardware queues: the extra slots share among themselves, never with the consumer
     many = pipeline.independent_streams(dev, 6)
     assert len(many) == 6 and all(s.cuda_stream != cur.cuda_stream for s in many)
