@@ -868,6 +868,148 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
   if (ABSGRAD) reinterpret_cast<float2*>(v_means2d_abs)[g] = make_float2(ab[0], ab[1]);
 }
 
+
+#ifndef MGS_REDUCE_TRIP
+#define MGS_REDUCE_TRIP 4       // slots of a row fetched together (reduce_records_rows_kernel)
+#endif
+#ifndef MGS_REDUCE_ROWS
+// 1: reduce_records_rows_kernel (below) for up to 4 channels and one slot per pair; 0: reduce_records_kernel everywhere
+#define MGS_REDUCE_ROWS 1
+#endif
+// The same sums with the ROWS of the tile rectangles as the units of work.  reduce_records_kernel gives every lane one
+// Gaussian and lets it walk all its slots: a wave takes as long as its largest rectangle (25 trips of four slots where
+// the average lane needs 1-2), one dependent round trip after another -- 14 SIMD-cycles per vector instruction, pure
+// latency.  Here a wave still owns 64 consecutive Gaussians, but their rectangles' rows (2-3 slots each) are dealt out
+// to the lanes, 64 rows per round: every lane does one short trip per round, and the Gaussians then add up their own
+// rows of the round out of LDS, in row order.  The order of additions is fixed by the tiles' coordinates alone -- within
+// a row by column, then the rows by row -- so the result is bit-reproducible and does not depend on which rectangle
+// (classic or tightened: the extra slots are unflagged, the extra rows add exact zeros) lists the tiles.
+template <int CHT, bool ABSGRAD>
+__global__ __launch_bounds__(256) void reduce_records_rows_kernel(
+    int n, const int4* __restrict__ pair_info, const float* __restrict__ records,
+    const uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ means2d,
+    const float* __restrict__ conics, const float* __restrict__ opacities,
+    const float4* __restrict__ splats, int channels, float* __restrict__ v_means2d,
+    float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
+    float* __restrict__ v_feats, float* __restrict__ v_opacities) {
+  constexpr int RSP = record_floats(CHT, ABSGRAD), R4 = RSP / 4, NV = 6 + CHT + (ABSGRAD ? 2 : 0);
+  constexpr int PITCH = NV | 1;                       // odd pitch: the lanes' row sums fall into different banks
+  __shared__ int s_row0[4][64];                       // first row (task) of each Gaussian of the wave
+  __shared__ int4 s_info[4][64];
+  __shared__ float2 s_mean[4][64];
+  __shared__ float s_rows[4][64 * PITCH];
+  const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const int g = blockIdx.x * 256 + (int)threadIdx.x;
+  int4 info = make_int4(0, 0, 0, 0);
+  int h = 0;
+  float mean_x = 0.f, mean_y = 0.f, ca = 1.f, cb = 0.f, cc = 1.f, op = 1.f;
+  if (g < n) {
+    info = pair_info[g];
+    h = (int)((unsigned)info.w >> 16);
+    if ((info.w & 0xffff) == 0) h = 0;
+    if (h > 0) {
+      if (splats) {
+        const float4 p0 = splats[3 * (size_t)g], p1 = splats[3 * (size_t)g + 1];
+        mean_x = p0.x; mean_y = p0.y; ca = p0.z; cb = p0.w; cc = p1.x; op = p1.y;
+      } else {
+        mean_x = means2d[2 * (size_t)g]; mean_y = means2d[2 * (size_t)g + 1];
+        ca = conics[3 * (size_t)g]; cb = conics[3 * (size_t)g + 1]; cc = conics[3 * (size_t)g + 2];
+        op = opacities[g];
+      }
+    }
+  }
+  int incl = h;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  const int row0 = incl - h, n_rows = __shfl(incl, 63);
+  s_row0[wv][lane] = row0;
+  s_info[wv][lane] = info;
+  s_mean[wv][lane] = make_float2(mean_x, mean_y);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float4* rec4 = reinterpret_cast<const float4*>(records);
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  for (int base = 0; base < n_rows; base += 64) {
+    const int t = base + lane;
+    float rs[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) rs[i] = 0.f;
+    if (t < n_rows) {
+      int o = 0;                                      // the last Gaussian whose first row is <= t: the row's owner
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1)
+        if (s_row0[wv][o + step] <= t) o += step;     // (o + step <= 63)
+      const int4 oi = s_info[wv][o];
+      const float2 om = s_mean[wv][o];
+      const int ow = oi.w & 0xffff, r = t - s_row0[wv][o];
+      const uint32_t slot0 = (uint32_t)oi.x + (uint32_t)(r * ow);
+      const float my = om.y - ((float)((oi.z + r) * 16) + 8.f);     // m exactly as the raster kernel formed it
+      constexpr int TR = MGS_REDUCE_TRIP;
+      for (int c0 = 0; c0 < ow; c0 += TR) {
+        // the flags of the trip out of the two aligned words that hold them (slots at or past the capacity --
+        // overflowed lists -- do not exist and lie outside the workspace)
+        const uint32_t s0 = slot0 + (uint32_t)c0, a0 = s0 & ~3u, sh = (s0 & 3u) * 8u;
+        const uint32_t w0 = a0 < capacity ? *reinterpret_cast<const uint32_t*>(flags + a0) : 0u;
+        const uint32_t w1 = (sh && a0 + 4u < capacity) ? *reinterpret_cast<const uint32_t*>(flags + a0 + 4u) : 0u;
+        const uint32_t fw = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
+        bool on[TR];
+        float rr[TR][RSP];
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          on[i] = c0 + i < ow && s0 + (uint32_t)i < capacity && ((fw >> (8 * i)) & 0xffu) != 0;
+#pragma unroll
+          for (int k = 0; k < R4; ++k) {
+            const float4 v = on[i] ? rec4[(size_t)(s0 + (uint32_t)i) * R4 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rr[i][4 * k] = v.x; rr[i][4 * k + 1] = v.y; rr[i][4 * k + 2] = v.z; rr[i][4 * k + 3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const float mx = om.x - ((float)((oi.y + c0 + i) * 16) + 8.f);
+          float P, Q, Vaa, Vab, Vbb;
+          moments_to_mean(mx, my, rr[i][0], rr[i][1], rr[i][2], rr[i][3], rr[i][4], rr[i][5], P, Q, Vaa, Vab, Vbb);
+          rs[0] += P; rs[1] += Q; rs[2] += Vaa; rs[3] += Vab; rs[4] += Vbb; rs[5] += rr[i][0];
+#pragma unroll
+          for (int c = 0; c < CHT; ++c) rs[6 + c] += rr[i][6 + c];
+          if constexpr (ABSGRAD) { rs[6 + CHT] += rr[i][6 + CHT]; rs[7 + CHT] += rr[i][7 + CHT]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s_rows[wv][lane * PITCH + i] = rs[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // every Gaussian adds its rows of this round, in row order
+    const int a = max(row0, base), b = min(row0 + h, base + 64);
+    for (int t2 = a; t2 < b; ++t2) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] += s_rows[wv][(t2 - base) * PITCH + i];
+    }
+    __builtin_amdgcn_wave_barrier();                  // the next round overwrites s_rows
+  }
+  if (g >= n) return;
+  if (h > 0) {      // apply the Gaussian's conic once, here; opacity * d/d opacity = -sum v_sigma
+    finish_geo(ca, cb, cc, acc[0], acc[1], acc[2], acc[4]);
+    acc[5] = op > 0.f ? -acc[5] / op : 0.f;
+  }
+  reinterpret_cast<float2*>(v_means2d)[g] = make_float2(acc[0], acc[1]);
+  v_conics[3 * (size_t)g + 0] = acc[2];
+  v_conics[3 * (size_t)g + 1] = acc[3];
+  v_conics[3 * (size_t)g + 2] = acc[4];
+  v_opacities[g] = acc[5];
+#pragma unroll
+  for (int c = 0; c < CHT; ++c)
+    if (c < channels) v_feats[(size_t)g * channels + c] = acc[6 + c];
+  if constexpr (ABSGRAD) reinterpret_cast<float2*>(v_means2d_abs)[g] = make_float2(acc[6 + CHT], acc[7 + CHT]);
+}
+
 }  // namespace
 }  // namespace mgs
 
@@ -1018,11 +1160,17 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                      (const int32_t*)order, checkpoints, ckpt_shift, (const int32_t*)seg_table, render_out)
 #define MGS_RD_LAUNCH(C, A)                                                                     \
   if (split) MGS_RD_RASTER(C, A, ((C) <= 4 && !kHalf)); else MGS_RD_RASTER(C, A, false);        \
-  if (!records_only)                                                                            \
-  hipLaunchKernelGGL((reduce_records_kernel<C, A, (int)kSlots>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
-                     info, records, flags, (uint32_t)cap, means2d, conics, opacities,          \
-                     reinterpret_cast<const float4*>(splats),                                  \
-                     channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities)
+  if (!records_only) {                                                                          \
+    if constexpr (MGS_REDUCE_ROWS && (C) <= 4 && kSlots == 1)                                   \
+      hipLaunchKernelGGL((reduce_records_rows_kernel<((C) <= 4 ? (C) : 4), A>), dim3(div_up(n, 256)), dim3(256), 0, s, n, \
+                         info, records, flags, (uint32_t)cap, means2d, conics, opacities,      \
+                         reinterpret_cast<const float4*>(splats),                              \
+                         channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities);  \
+    else                                                                                        \
+      hipLaunchKernelGGL((reduce_records_kernel<C, A, (int)kSlots>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
+                         info, records, flags, (uint32_t)cap, means2d, conics, opacities,      \
+                         reinterpret_cast<const float4*>(splats),                              \
+                         channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities); }
 #define MGS_RD(C) if (v_means2d_abs) { MGS_RD_LAUNCH(C, true); } else { MGS_RD_LAUNCH(C, false); }
   if (channels == 1) { MGS_RD(1) }
   else if (channels == 2) { MGS_RD(2) }
