@@ -8,22 +8,27 @@ synthetic scene at 1920x1080 in the mode the north star describes -- RGB + expec
 (`render_mode="RGB+ED"`): projection+SH, tile binning, tile raster, all through the C ABI of
 libmgs.so, replayed as one HIP graph with the scene resident in HBM.
 
-N > 1 (configs[3]; one process per GPU over RCCL -- started by torch.distributed.run as the driver does, or by
-bench.py itself when it is called as plain `python bench.py --gpus N` without WORLD_SIZE in the environment): a step is one
-pass over the 64-camera novel-view ring theta_k = 2 pi k / 64; rank r renders its contiguous block of the ring through
-its FrameRenderer and rank 0 gathers all 64 finished frames.  Rank 0 receives (N - 1) / N of every frame over its seven
-xGMI links, which bounds the whole job at (its inbound rate) / (payload per frame) whatever the renderers do, so
-  * the payload `value` is measured with is the light DATASET frame -- RGBA8 + fp16 ray distance, 6 bytes per pixel =
-    12.4 MB per frame (`--gather-dtype dataset16`; the RGBA image the reference's load_images reads plus the distance map
-    as np.float16), converted on the device inside the timed region (mgs_frame_to_dataset): at an assumed 50 GB/s per
-    link the single root then allows ~32 k frames/s at 8 ranks, above 6 x the one-GPU rate; `dataset` (fp32 distance,
-    8 B per pixel, what DatasetWriter stores: ~24 k), `fp32` (the raw renders, 20 B per pixel: ~9.6 k) and `u8` (8-bit RGB:
-    ~64 k) are the alternates; the same run then times the ring again with the raw fp32 renders and reports that rate
-    beside it (config.gather_other_payload; `--one-payload` skips it); config.root_bound holds the table for the run;
-  * rank 0 renders a smaller block the more ranks send to it: `--root-weight` defaults to max(0.5, 1 - 0.07 (N - 1)), i.e.
-    31 + 33 cameras at 2 ranks, 13 + 17 + 17 + 17 at 4, 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 at 8;
-  * config.per_rank carries each rank's HIP-event split of its last timed region (render span, conversions, what its
-    stream still waited for behind its last conversion), so that a scaling run shows where the time went.
+N > 1 (configs[3] as BASELINE.json writes it; one process per GPU over RCCL -- started by torch.distributed.run as the
+driver does, or by bench.py itself when it is called as plain `python bench.py --gpus N` without WORLD_SIZE in the
+environment): a step is one pass over the 64-camera novel-view ring theta_k = 2 pi k / 64, EQUAL contiguous blocks per rank
+(8 views per GPU at 8 ranks: rank r renders k in [8r, 8r + 8)), and rank 0 gathers all 64 finished frames.
+  * `value` is measured with the payload that carries the north star's 1e-4 to the root: the raw fp32 renders, RGB +
+    expected depth + alpha, 20 bytes per pixel = 41.5 MB per frame (`--gather-dtype fp32`, the default).
+  * Rank 0 receives (N - 1) / N of every frame over its seven xGMI links, which bounds the whole job at (its inbound
+    rate) / (payload per frame) whatever the renderers do: with fp32 frames a single root cannot reach 6 x the one-GPU
+    rate (config.root_bound).  The SAME run therefore times the ring again in three named alternates
+    (config.alternates; `--one-payload` skips them), each a smaller thing to move:
+      dataset                  RGBA8 + fp32 ray distance, 8 B per pixel: the layout DatasetWriter stores and the
+                               reference's load_images / load_depths read (reference-pinned, tests/golden/); equal blocks
+      dataset16                RGBA8 + fp16 ray distance, 6 B per pixel (QUANTISED: 11 significant bits of distance,
+                               ~3 mm at 7 units; outside 1e-4); equal blocks
+      dataset16_weighted_root  the same payload with rank 0 rendering a smaller block the more ranks send to it
+                               (`--alt-root-weight`, default max(0.5, 1 - 0.07 (N - 1)): 31 + 33 cameras at 2 ranks,
+                               13 + 17 + 17 + 17 at 4, 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 at 8) -- the tuned variant, NOT configs[3]'s
+                               "8 views per GPU"
+    Dataset payloads leave the raster itself (FrameRenderer(dataset_output=)); nothing is converted afterwards.
+  * config.per_rank carries, per leg, each rank's HIP-event split of its last timed region (render span, conversions,
+    what its stream still waited for behind its last conversion), so that a scaling run shows where the time went.
 Total work is fixed as N grows: scaling is "strong"; value = frames all ranks rendered / time.
 
 Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier +
@@ -62,16 +67,17 @@ from robosimgs_amd.rendering import rasterization  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
 MODE = "RGB+ED"                # what splatfacto renders and INTEGRATION.md tells users to call
 RING = 64                      # configs[3]: 64 novel-view cameras
-PAYLOADS = {"dataset16": "dataset frames, light: RGBA8 + fp16 ray distance, 6 B per pixel -- the RGBA image load_images reads and a "
-                         "half-precision distance map (np.float16: load_depths / distance_to_depth take it as it is); "
-                         "mgs_frame_to_dataset on the device, inside the timed region",
+PAYLOADS = {"dataset16": "dataset frames, light and QUANTISED: RGBA8 + fp16 ray distance, 6 B per pixel -- the RGBA image load_images "
+                         "reads and a half-precision distance map (np.float16: load_depths / distance_to_depth take it as it is; 11 "
+                         "significant bits, ~3 mm at 7 units: outside the north star's 1e-4); written by the raster's epilogue",
             "dataset": "dataset frames: RGBA8 + fp32 ray distance, 8 B per pixel, the layout DatasetWriter stores and the "
-                       "reference's load_images / load_depths read (mgs_frame_to_dataset on the device, inside the timed region)",
-            "fp32": "fp32 RGB + expected depth + alpha (20 B per pixel)",
+                       "reference's load_images / load_depths read (reference-pinned); written by the raster's epilogue",
+            "fp32": "fp32 RGB + expected depth + alpha (20 B per pixel): the raw renders, the only payload that carries 1e-4 to the root",
             "u8": "8-bit RGB images (frame_to_u8 on the device, inside the timed region)"}
 PAYLOAD_BYTES_PER_PX = {"dataset16": 6, "dataset": 8, "fp32": 20, "u8": 3}
-XGMI_LINK_GBS = 50.0           # what an RCCL point-to-point gather is assumed to sustain per xGMI link and direction
-                               # (peak 153 GB/s per link both ways, MI355X_MICROARCH.md; not measured: no multi-GPU box)
+XGMI_LINK_GBS = 50.0           # ASSUMED: what an RCCL point-to-point gather sustains per xGMI link and direction (the guide's
+                               # peak is 153 GB/s per link both ways = 76.5 per direction; nothing here can measure it: no multi-GPU
+                               # box).  It only feeds the `root_bound` table of the JSON line, no default and no `value`.
 
 
 def root_bound_frames_per_s(mode, W, H, world):
@@ -104,16 +110,16 @@ def parse():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-reorder", action="store_true",
                     help="FrameRenderer keeps the scene in the order it is given (default: its own Morton-ordered copy)")
-    # N > 1: what rank 0 collects.  "dataset" (default) = the frame as the dataset writer stores it and the reference's
-    # load_images / load_depths read it: RGBA8 + fp32 ray distance, 8 B per pixel = 16.6 MB per frame, converted on the
-    # device inside the timed region (mgs_frame_to_dataset); "fp32" = the raw renders, RGB + depth + alpha, 41.5 MB per
-    # frame (332 MB per rank and pass at 8 ranks); "u8" = 8-bit RGB only (6.2 MB per frame).
-    ap.add_argument("--gather-dtype", choices=("dataset16", "dataset", "fp32", "u8"), default="dataset16")
-    # the rank that receives every frame (and converts its own) renders a smaller block of the ring: its share in units
-    # of the other ranks' (1 = equal blocks).
-    # Default: max(0.5, 1 - 0.07 (N - 1)) = 0.93 / 0.79 / 0.51 at 2 / 4 / 8 ranks (31 + 33; 13 + 17 + 17 + 17; 4 + 9 + 9 + 9 + 9 + 8 + 8
-    # + 8 cameras): the more ranks send to it, the smaller its block -- the other ranks' largest block then sets the pass.
-    ap.add_argument("--root-weight", type=float, default=None)
+    # N > 1: what rank 0 collects in the leg `value` is measured on.  "fp32" (default) = the raw renders, RGB + expected depth
+    # + alpha, 41.5 MB per frame (332 MB per rank and pass at 8 ranks) -- the payload that carries the north
+    # star's 1e-4; "dataset" = RGBA8 + fp32 ray distance (8 B per pixel, what DatasetWriter stores); "dataset16" = RGBA8 + fp16
+    # distance (6 B per pixel, quantised); "u8" = 8-bit RGB only.  The payloads not chosen here are timed as named alternates.
+    ap.add_argument("--gather-dtype", choices=("dataset16", "dataset", "fp32", "u8"), default="fp32")
+    # share of the ring the gathering rank renders, in units of the other ranks' (1 = equal blocks: configs[3]'s "8 views per
+    # GPU", the default).  The alternate leg dataset16_weighted_root uses --alt-root-weight (default max(0.5, 1 - 0.07 (N - 1)) =
+    # 0.93 / 0.79 / 0.51 at 2 / 4 / 8 ranks: 31 + 33; 13 + 17 + 17 + 17; 4 + 9 + 9 + 9 + 9 + 8 + 8 + 8 cameras).
+    ap.add_argument("--root-weight", type=float, default=1.0)
+    ap.add_argument("--alt-root-weight", type=float, default=None)
     ap.add_argument("--gather-batch", type=int, default=4, help="frames per collective (N > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inflight", type=int, default=3,
@@ -123,7 +129,7 @@ def parse():
     ap.add_argument("--debug-single-device-gloo", action="store_true")
     # debugging aid: run the N > 1 leg (camera ring + gather) in a world of one
     ap.add_argument("--force-gather", action="store_true")
-    ap.add_argument("--one-payload", action="store_true", help="N > 1: time only --gather-dtype, not the other payload too")
+    ap.add_argument("--one-payload", action="store_true", help="N > 1: time only the headline leg, not the named alternates")
     return ap.parse_args()
 
 
@@ -203,22 +209,32 @@ def main():
     scene = synthetic_scene(a.n, a.log_scale_mean, deg, seed=0)
     t = scene.to_torch(dev, deg)
     tile_w, tile_h = -(-W // 16), -(-H // 16)
-    # cameras: the single theta = 0.3 view of configs[1], or this rank's block of the 64-camera ring
-    if a.root_weight is None:
-        a.root_weight = max(0.5, 1.0 - 0.07 * (world - 1))
-    weights = root_weights(world, a.root_weight) if (ring and world > 1) else None
-    if ring:
-        mine = shard_cameras(RING, world, rank, weights)
-        thetas = [2.0 * math.pi * k / RING for k in mine]
-    else:
-        mine = range(1)
-        thetas = [0.3]
-    cams = camera_ring(len(thetas), W, H, thetas=thetas) if thetas else []
+    # cameras: the single theta = 0.3 view of configs[1], or this rank's block of the 64-camera ring.  Headline: equal blocks
+    # (configs[3]: "sharded 8 views/GPU"); the alternate leg dataset16_weighted_root gives rank 0 a smaller block
+    if a.alt_root_weight is None:
+        a.alt_root_weight = max(0.5, 1.0 - 0.07 * (world - 1))
     sizing_cam = camera_ring(1, W, H, thetas=[0.3])[0]
 
     def cam_tensors(c):
         return (torch.from_numpy(c.viewmat().astype(np.float32)).to(dev)[None],
                 torch.from_numpy(c.K.astype(np.float32)).to(dev)[None])
+
+    def make_shard(root_weight):
+        """This rank's cameras (and everybody's block sizes) for one weighting of the gathering rank."""
+        from robosimgs_amd import FrameRenderer as FR_
+        w_ = root_weights(world, root_weight) if (ring and world > 1) else None
+        mine_ = shard_cameras(RING, world, rank, w_) if ring else range(1)
+        thetas_ = [2.0 * math.pi * k / RING for k in mine_] if ring else [0.3]
+        cams_ = camera_ring(len(thetas_), W, H, thetas=thetas_) if thetas_ else []
+        sizes_ = shard_sizes(RING, world, w_) if ring else [1]
+        return {"root_weight": root_weight if (ring and world > 1) else None, "weights": w_, "mine": mine_, "cams": cams_,
+                "sizes": sizes_, "cam_devs": [FR_.pack_camera(*[x[0].contiguous() for x in cam_tensors(c)]) for c in cams_],
+                # frames per collective: a per-frame collective costs ~80 us of launch / stream hand-over, a quarter of a frame
+                "GB": max(1, min(a.gather_batch, max(1, max(sizes_)))) if ring else 1}
+
+    shard = make_shard(a.root_weight)
+    shard_alt = make_shard(a.alt_root_weight) if (ring and world > 1 and a.alt_root_weight != a.root_weight) else None
+    cams = shard["cams"]
 
     vm, K = cam_tensors(sizing_cam)
 
@@ -239,7 +255,7 @@ def main():
     n_isect_binned = int(meta_t["n_isects"][0])
     del colors_t, alphas_t, meta_t, colors, alphas, meta
     need = n_isect_binned
-    for c in cams:                       # the ring's views differ: size the lists for the largest
+    for c in cams + (shard_alt["cams"] if shard_alt else []):    # the ring's views differ: size the lists for the largest
         v_, k_ = cam_tensors(c)
         need = max(need, int(forward(v_, k_)[2]["n_isects"][0]))
     cap = int(need * 1.25) + 4096
@@ -260,33 +276,38 @@ def main():
     # N > 1 with a dataset payload: the raster writes the payload itself (RGBA8 + ray distance from its epilogue: 6 - 8 B per
     # pixel leave the kernel instead of 20, no conversion pass) and the frame is copied into the gather batch on the slot's
     # own stream; --convert-on-consumer keeps the float frames and the consumer-side conversion
+    do_gather = use_dist and not a.no_gather
+    # the legs of an N > 1 run: (name, payload, shard); the first is the one `value` is measured on
+    legs = [(a.gather_dtype, a.gather_dtype, shard)]
+    if do_gather and not a.one_payload:
+        legs += [(m_, m_, shard) for m_ in ("fp32", "dataset", "dataset16") if m_ != a.gather_dtype]
+        if shard_alt is not None:
+            legs.append(("dataset16_weighted_root", "dataset16", shard_alt))
     fr_by_payload = {}
-    if ring and not a.no_gather:
+    if do_gather and not a.convert_on_consumer:
         for m_, dt_ in (("dataset16", torch.float16), ("dataset", torch.float32)):
-            if a.gather_dtype == m_ and not a.convert_on_consumer:
+            if any(l[1] == m_ for l in legs):
                 fr_by_payload[m_] = FrameRenderer(t, W, H, render_mode=MODE, frames_in_flight=n_fl, isect_capacity=cap,
                                                   reorder=None if a.no_reorder else "morton", dataset_output=dt_,
                                                   dataset_K=K_host)
     fr_plain = fr
-    cam_devs = [FrameRenderer.pack_camera(*[x[0].contiguous() for x in cam_tensors(c)]) for c in cams]
     vm_dev, K_dev = vm[0].contiguous(), K[0].contiguous()
-    frames_per_step = len(cam_devs)                    # 1 at N = 1, this rank's share of the ring otherwise
+    frames_per_step = len(shard["cam_devs"])           # 1 at N = 1, this rank's share of the ring otherwise
 
-    do_gather = use_dist and not a.no_gather
     comm_dev = "cpu" if debug_gloo else dev
     # Frames leave in batches of `gather_batch` through a double-buffered staging area: the frame is
-    # converted (u8) or copied (fp32) into its place in the batch, the slot is released at once, and
-    # every gather_batch-th frame one collective ships the whole batch -- a per-frame collective
-    # costs ~80 us of launch / stream hand-over each, a quarter of a frame time.
-    GB = max(1, min(a.gather_batch, max(1, max(shard_sizes(RING, world, weights))))) if ring else 1
-    per_rank = {}                                  # HIP-event split of this rank's last timed region (N > 1)
+    # converted (u8) or copied (fp32, dataset frames out of the raster) into its place in the batch, the slot is released at
+    # once, and every gather_batch-th frame one collective ships the whole batch.
+    per_rank = {}                                  # HIP-event split of this rank's last timed region, per leg (N > 1)
 
-    def time_frames(g_mode):
+    def time_frames(g_mode, sh=shard, leg=None):
         """Warm-up, then regions of K steps until min_seconds are timed; the gathered payload is the dataset frame
-        (RGBA8 plane + fp32 ray-distance plane, 8 B per pixel), fp32 RGB + expected depth + alpha, or the 8-bit RGB
-        image.  Returns (regions, collectives)."""
+        (RGBA8 plane + ray-distance plane), fp32 RGB + expected depth + alpha, or the 8-bit RGB image; `sh` says which
+        cameras this rank renders (make_shard).  Returns (regions, collectives)."""
         nonlocal fr
         fr = fr_by_payload.get(g_mode, fr_plain) if ring else fr
+        cam_devs, GB, weights = sh["cam_devs"], sh["GB"], sh["weights"]
+        leg = leg or g_mode
         g_u8 = g_mode == "u8"
         g_ds = g_mode in ("dataset", "dataset16")
         g_dist = torch.float16 if g_mode == "dataset16" else torch.float32
@@ -304,7 +325,7 @@ def main():
         pending = [None, None]
         last_work = [None, None]
         state = {"cur": 0, "fill": 0, "shipped": 0, "target": 0}
-        sizes_all = shard_sizes(RING, world, weights) if ring else [1]
+        sizes_all = sh["sizes"]
         tickets = []
 
         def ship():
@@ -420,7 +441,7 @@ def main():
             barrier_sync(use_dist)
             if do_gather:          # this rank's split of the region (HIP events): renders, conversions, the tail behind them
                 s0 = ev["start"]
-                per_rank[g_mode] = {
+                per_rank[leg] = {
                     "frames": len(cam_devs) * k_steps,
                     "render_span_ms": round(s0.elapsed_time(ev["render_done"]), 3) if ev["render_done"] is not None else 0.0,
                     "convert_ms": round(sum(x.elapsed_time(y) for x, y in ev["convert"]), 3),
@@ -471,12 +492,15 @@ def main():
     g_u8 = g_mode == "u8"
     regions, n_collectives = time_frames(g_mode)
     elapsed = float(np.median(regions))
-    # the other payload, timed the same way in the same run (N > 1 only): both are reported
-    other = None
-    if do_gather and not a.one_payload:
-        other_mode = "fp32" if g_mode != "fp32" else "dataset16"
-        o_regions, _ = time_frames(other_mode)
-        other = float(np.median(o_regions))
+    # the named alternates, timed the same way in the same run (N > 1 only): smaller payloads, and the weighted shard
+    alternates = {}
+    for leg_name, leg_mode, leg_shard in legs[1:]:
+        o_regions, _ = time_frames(leg_mode, leg_shard, leg_name)
+        o_el = float(np.median(o_regions))
+        alternates[leg_name] = {"payload": PAYLOADS[leg_mode], "bytes_per_frame": PAYLOAD_BYTES_PER_PX[leg_mode] * W * H,
+                                "frames_per_rank": leg_shard["sizes"], "root_weight": leg_shard["root_weight"],
+                                "frames_per_s": round(RING * a.steps / o_el, 2), "ms_per_step": round(o_el / a.steps * 1e3, 4),
+                                "within_1e-4_at_the_root": leg_mode == "fp32"}
     # the same frames with the renderer keeping the caller's order (N = 1 only; half the timed span)
     given_order = None
     if not ring and not a.no_reorder:
@@ -540,8 +564,8 @@ def main():
 
     if ring:
         workload = (f"configs[3]: {a.n} Gaussians, SH degree {deg}, {RING} novel-view cameras {W}x{H} "
-                    f"(theta_k = 2 pi k / {RING}), sharded {'/'.join(str(x) for x in shard_sizes(RING, world, weights))} views over "
-                    f"{world} GPU(s), RCCL gather to rank 0; one step = one pass over the ring")
+                    f"(theta_k = 2 pi k / {RING}), sharded {'/'.join(str(x) for x in shard['sizes'])} views over "
+                    f"{world} GPU(s), RCCL gather of the {g_mode} frames to rank 0; one step = one pass over the ring")
     else:
         workload = (f"configs[1]: {a.n} Gaussians, SH degree {deg}, {W}x{H} forward render "
                     f"(render_mode {MODE}: RGB + expected depth + alpha), one camera per step")
@@ -567,8 +591,8 @@ def main():
                    "world_size": dist.get_world_size() if use_dist else 1, "rccl_version": nccl_ver,
                    "frames_per_step_all_ranks": RING if ring else 1,
                    "frames_per_step_this_rank": frames_per_step,
-                   "frames_per_rank": shard_sizes(RING, world, weights) if ring else [1],
-                   "root_weight": a.root_weight if (ring and world > 1) else None,
+                   "frames_per_rank": shard["sizes"],
+                   "root_weight": shard["root_weight"],
                    "per_rank": ({m: [r_.get(m) for r_ in all_ranks] for m in all_ranks[0]} if all_ranks else None),
                    "per_rank_note": ("HIP events on each rank over its last timed region: render_span = region start -> the rank's "
                                      "last frame rendered, convert = sum of the payload conversions, after_last_convert = what "
@@ -581,11 +605,13 @@ def main():
                                        "(N - 1) / N of every frame: the ceiling of a single-root gather whatever the renderers do"
                                        if (ring and world > 1) else None),
                    "gather": ((PAYLOADS[g_mode]
-                               + f" to rank 0 (RCCL), {GB} frames per collective, "
+                               + f" to rank 0 (RCCL), {shard['GB']} frames per collective, "
                                  f"{n_collectives} collectives issued") if do_gather else "none"),
-                   "gather_other_payload": ({"payload": PAYLOADS[other_mode],
-                                             "frames_per_s": round(total_frames / other, 2),
-                                             "ms_per_step": round(other / a.steps * 1e3, 4)} if other else None),
+                   "alternates": alternates or None,
+                   "alternates_note": ("the same ring in the same run with a smaller payload and / or a smaller block on the "
+                                       f"gathering rank; `value` is the {g_mode} leg on blocks of {'/'.join(str(x) for x in shard['sizes'])} (configs[3] as written: equal blocks, fp32 frames). With "
+                                       "fp32 frames a single root cannot reach 6 x the one-GPU rate (root_bound): a 6 x claim can "
+                                       "only be made on a dataset leg, and says so" if alternates else None),
                    "launch": f"one HIP graph per frame, no host read-back, {n_fl} independent "
                              "frames in flight on separate HIP streams",
                    "frames_in_flight": n_fl, "single_frame_latency_ms": round(latency_ms, 4),
@@ -1065,7 +1091,8 @@ def cpu_baseline(scene, cam, W, H, deg, budget_s):
     threads = cpu_ref.max_threads()
     args = (scene.means, scene.quats, scene.scales, scene.opacities, scene.sh_coeffs,
             cam.viewmat(), cam.K, W, H, deg)
-    kw = dict(with_depth=True)                              # RGB + depth sum + alpha, like the GPU frames
+    base_lib, base_flags = cpu_ref.baseline_lib()           # the AVX2 + FMA build (x86-64-v3) where this host can run it
+    kw = dict(with_depth=True, library=base_lib)            # RGB + depth sum + alpha, like the GPU frames
     for _ in range(3):                                      # BASELINE.md protocol: 3 warm-ups
         cpu_ref.render(*args, **kw)
     times = []
@@ -1084,8 +1111,8 @@ def cpu_baseline(scene, cam, W, H, deg, budget_s):
     return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{len(times)} full frames of the same 1M-Gaussian 1080p RGB+depth+alpha workload "
                       f"after 3 warm-ups, median {med * 1e3:.1f} ms/frame; oracle/gs_cpu.cpp (fp32 "
-                      f"instantiation), OpenMP, {threads} threads on {model}; built with g++ -O3 WITHOUT "
-                      "-march=native (the .so is compiled in the dev container and must run on any host)",
+                      f"instantiation), OpenMP, {threads} threads on {model}; built with g++ {' '.join(base_flags)} "
+                      "(not -march=native: the .so is compiled in the dev container and must run on the GPU box's host)",
             "pair_evals": info["pair_evals"]}
 
 

@@ -13,26 +13,61 @@ SRC = os.path.join(HERE, "gs_cpu.cpp")
 LIB = os.path.join(HERE, "_build", "libgs_cpu.so")
 
 
+# The same source a second time for bench.py's cpu_baseline leg ONLY: AVX2 + FMA code (x86-64-v3 runs on every host a GPU box
+# can have; -march=native would tie the .so, which is built in the dev container, to this container's CPU).  The CHECKER
+# stays the plain build above it: its fp64 sums must not depend on what the compiler contracts into FMAs on which host.
+LIB_V3 = os.path.join(HERE, "_build", "libgs_cpu_v3.so")
+BASE_FLAGS = ["-O3", "-std=c++17", "-fopenmp", "-shared", "-fPIC"]
+V3_FLAGS = BASE_FLAGS + ["-march=x86-64-v3"]
+
+
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        # no -march=native: the .so is built in the dev container and runs on the GPU box's host
-        subprocess.run(["g++", "-O3", "-std=c++17", "-fopenmp", "-shared", "-fPIC", SRC, "-o", LIB],
-                       check=True)
+    for lib_path, flags in ((LIB, BASE_FLAGS), (LIB_V3, V3_FLAGS)):
+        if force or not os.path.exists(lib_path) or os.path.getmtime(lib_path) < os.path.getmtime(SRC):
+            os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+            subprocess.run(["g++", *flags, SRC, "-o", lib_path], check=True)
     return LIB
 
 
 _lib = None
+_lib_v3 = None
+
+
+def _bind(path):
+    L = ctypes.CDLL(path)
+    L.gs_cpu_render.restype = ctypes.c_longlong
+    L.gs_cpu_render_f64.restype = ctypes.c_longlong
+    L.gs_cpu_max_threads.restype = ctypes.c_int
+    return L
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = ctypes.CDLL(build())
-        _lib.gs_cpu_render.restype = ctypes.c_longlong
-        _lib.gs_cpu_render_f64.restype = ctypes.c_longlong
-        _lib.gs_cpu_max_threads.restype = ctypes.c_int
+        build()
+        _lib = _bind(LIB)
     return _lib
+
+
+def host_has_v3() -> bool:
+    """AVX2 + FMA + BMI2 on this host (what -march=x86-64-v3 code needs)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next(l for l in f if l.startswith("flags")).split()
+        return all(x in flags for x in ("avx2", "fma", "bmi2", "movbe", "f16c", "abm"))
+    except Exception:
+        return False
+
+
+def baseline_lib():
+    """(library, flags it was built with) for the timed CPU baseline: the x86-64-v3 build where the host can run it."""
+    global _lib_v3
+    if not host_has_v3():
+        return lib(), BASE_FLAGS
+    if _lib_v3 is None:
+        build()
+        _lib_v3 = _bind(LIB_V3)
+    return _lib_v3, V3_FLAGS
 
 
 def max_threads() -> int:
@@ -41,8 +76,9 @@ def max_threads() -> int:
 
 def render(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height, sh_degree,
            with_depth=False, background=None, eps2d=0.3, near_plane=0.01, far_plane=1e10,
-           radius_clip=0.0, n_threads=0):
-    """Forward frame on the host.  Returns (render[H,W,ch], alpha[H,W], info dict)."""
+           radius_clip=0.0, n_threads=0, library=None):
+    """Forward frame on the host.  Returns (render[H,W,ch], alpha[H,W], info dict).  library: baseline_lib()[0] for the
+    timed baseline (default: the checker's build)."""
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     means, quats, scales, opacities, sh = f(means), f(quats), f(scales), f(opacities), f(sh_coeffs)
     vm, Km = f(viewmat), f(K)
@@ -53,7 +89,7 @@ def render(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height
     bg = f(background) if background is not None else None
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
     cf = ctypes.c_float
-    n_isect = lib().gs_cpu_render(n, p(means), p(quats), p(scales), p(opacities), int(sh_degree),
+    n_isect = (library or lib()).gs_cpu_render(n, p(means), p(quats), p(scales), p(opacities), int(sh_degree),
                                   sh.shape[1], p(sh), p(vm), p(Km), int(width), int(height),
                                   cf(eps2d), cf(near_plane), cf(far_plane), cf(radius_clip), ch,
                                   p(bg), int(n_threads), p(out), p(alpha), p(counters))

@@ -107,7 +107,9 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
     rank's block otherwise.  as_u8=True gathers 8-bit RGB images instead of fp32 renders
     (compositing.frame_to_u8 with `u8_background`; alphas are then not gathered): a quarter of the
     bytes over xGMI, which is what a dataset writer stores anyway.
-    weights: camera shares per rank (shard_sizes; root_weights(world, 0.5) halves the gathering rank's share)."""
+    weights: camera shares per rank (shard_sizes; root_weights(world, 0.5) halves the gathering rank's share).
+    A `renderer` built with dataset_output= (and the default dataset_keep_float=False) holds no float frame: the two
+    returned tensors are then the dataset frames, rgba uint8 [C,H,W,4] and ray distance [C,H,W,1], gathered alike."""
     from .rendering import rasterization
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -123,7 +125,10 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
                 nxt += 1
             tk = tickets.pop(0)
             f = renderer.fetch(tk)
-            cs[i], als[i] = f["colors"].clone(), f["alphas"].clone()
+            if f["colors"] is None:           # a renderer that writes dataset frames only (dataset_output=): RGBA8 + distance
+                cs[i], als[i] = f["rgba"].clone(), f["distance"].clone()
+            else:
+                cs[i], als[i] = f["colors"].clone(), f["alphas"].clone()
             renderer.release(tk)
         colors, alphas = torch.stack(cs), torch.stack(als)
     elif len(mine):
@@ -131,10 +136,15 @@ def render_sharded(tensors: dict, viewmats: torch.Tensor, Ks: torch.Tensor, widt
                                           tensors["opacities"], tensors["colors"], viewmats[sel],
                                           Ks[sel], width, height,
                                           sh_degree=tensors.get("sh_degree"), **kw)
+    elif renderer is not None and renderer.dataset_dtype is not None and not renderer.dataset_keep_float:
+        colors = torch.zeros(0, height, width, 4, dtype=torch.uint8, device=viewmats.device)
+        alphas = torch.zeros(0, height, width, 1, dtype=renderer.dataset_dtype, device=viewmats.device)
     else:
         d = {"RGB": 3, "D": 1, "ED": 1}.get(kw.get("render_mode", "RGB"), 4)   # RGB+D / RGB+ED: 4
         colors = torch.zeros(0, height, width, d, device=viewmats.device)
         alphas = torch.zeros(0, height, width, 1, device=viewmats.device)
+    if as_u8 and colors.dtype == torch.uint8:
+        raise ValueError("as_u8 quantises float frames; this renderer already returns RGBA8 dataset frames")
     if as_u8:
         from .compositing import frame_to_u8
         colors = (frame_to_u8(colors, alphas, u8_background) if len(mine)

@@ -207,7 +207,7 @@ def render_frames_raw(means, quats, scales, opacities, sh_degree, sh_coeffs, vie
             ptr(backgrounds),
             int(capacity), ptr(render) if (float_frame or dataset is None) else None,
             ptr(alphas) if (float_frame or dataset is None) else None, ptr(n_isect), ptr(status)]
-    ds = dataset_args(dataset)
+    ds = dataset_args(dataset, C, height, width, dev)
     args += list(ds[:4])
     check(L.mgs_render_frames(*args, None, ctypes.byref(nbytes), stream_handle()), "mgs_render_frames(size query)")
     ws = _workspace(nbytes.value + 256, dev)
@@ -341,9 +341,12 @@ def render_frames_backward_raw(means, quats, scales, opacities, sh_degree, sh_co
     return v_means, v_quats, v_scales, v_sh, v_opac, v_vm, v_m2d, v_abs
 
 
-def dataset_args(dataset):
+def dataset_args(dataset, n_frames=None, height=None, width=None, device=None):
     """(ds_rgba, ds_distance, ds_distance_type, ds_Kinv_host, keep-alive) for the C calls that take a dataset output;
-    dataset = (rgba uint8 [..,H,W,4], distance [..,H,W,1] or None, K [3,3]) or None."""
+    dataset = (rgba uint8 [..,H,W,4], distance [..,H,W,1] or None, K [3,3]) or None.  The kernels write
+    n_frames * height * width * 4 bytes of RGBA and as many distances through raw pointers: the buffers must hold exactly
+    that, on the device the frame is rendered on (checked here; one K serves every camera of the call -- the
+    intrinsics a dataset's cameras share)."""
     if dataset is None:
         return None, None, 0, None, None
     import numpy as np
@@ -352,6 +355,19 @@ def dataset_args(dataset):
         raise ValueError("dataset rgba must be a contiguous uint8 tensor [..., H, W, 4]")
     if dist is not None and (not dist.is_contiguous() or dist.dtype not in (torch.float16, torch.float32, torch.float64)):
         raise ValueError("dataset distance must be a contiguous float16 / float32 / float64 tensor [..., H, W, 1]")
+    require_device(rgba, dist)
+    if device is not None and any(x is not None and x.device != device for x in (rgba, dist)):
+        raise ValueError(f"dataset buffers must live on {device}, the device the frame is rendered on")
+    if n_frames is not None:
+        n_px = int(n_frames) * int(height) * int(width)
+        if rgba.numel() != n_px * 4:
+            raise ValueError(f"dataset rgba holds {rgba.numel()} bytes, {n_frames} frame(s) of {width}x{height} need {n_px * 4} "
+                             f"([{n_frames},{height},{width},4] uint8)")
+        if dist is not None and dist.numel() != n_px:
+            raise ValueError(f"dataset distance holds {dist.numel()} values, {n_frames} frame(s) of {width}x{height} need {n_px} "
+                             f"([{n_frames},{height},{width},1])")
+    if dist is not None and K is None:
+        raise ValueError("a dataset distance plane needs K (the 3x3 intrinsics the cameras of the call share)")
     kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(K, dtype=np.float64).reshape(3, 3))) if dist is not None else None
     dtype_id = {torch.float64: 1, torch.float16: 2}.get(dist.dtype, 0) if dist is not None else 0
     return ptr(rgba), ptr(dist), dtype_id, (kinv.ctypes.data if kinv is not None else None), kinv
@@ -384,7 +400,7 @@ def rasterize_fwd_raw(means2d, conics, feats, opacities, background, width, heig
                     else None)
     else:
         render, alphas, last_ids = out
-    ds = dataset_args(dataset)
+    ds = dataset_args(dataset, 1, height, width, dev)
     check(_lib.lib().mgs_rasterize_fwd(n, ptr(means2d), ptr(conics), ptr(feats), ptr(opacities),
                                        ptr(splats), ptr(background), ch, width, height, tile_w, tile_h,
                                        ptr(tile_offsets), ptr(flatten_ids), ptr(group_order),

@@ -209,8 +209,11 @@ class FrameRenderer:
         ds, ds_out = None, None
         if self.dataset_dtype is not None:          # the slot's dataset frame: [RGBA8 plane | distance plane] as bytes
             n_px = self.width * self.height
-            flat = torch.empty(n_px * (4 + torch.empty(0, dtype=self.dataset_dtype).element_size()), dtype=torch.uint8,
-                               device=self.dev)
+            esz = torch.empty(0, dtype=self.dataset_dtype).element_size()
+            # the distance plane starts n_px * 4 bytes into the frame: with float64 distances and an odd pixel count that
+            # is 4 mod 8, so the frame starts 4 bytes into its allocation there (the RGBA plane has no alignment to keep)
+            lead = (-(n_px * 4)) % esz
+            flat = torch.empty(lead + n_px * (4 + esz), dtype=torch.uint8, device=self.dev)[lead:]
             ds = {"dataset": flat, "rgba": flat[:n_px * 4].view(self.height, self.width, 4),
                   "distance": flat[n_px * 4:].view(self.dataset_dtype).view(self.height, self.width, 1)}
             ds_out = (ds["rgba"].unsqueeze(0), ds["distance"].unsqueeze(0), self.dataset_K, self.dataset_keep_float)
@@ -257,6 +260,18 @@ class FrameRenderer:
                                f"({self.n_slots} frames in flight at most)")
         self._next = (slot + 1) % self.n_slots
         packed = None
+        if self.dataset_K is not None:
+            # the dataset epilogue turns depth into ray distance with the intrinsics the renderer was built with (they
+            # are arguments of the captured kernel): a frame submitted with another K would carry wrong distances.
+            # Checked wherever the submitted K is on the host; a K on the device is the caller's to keep equal.
+            k_host = None
+            if K is not None and not (torch.is_tensor(K) and K.is_cuda):
+                k_host = np.asarray(K, dtype=np.float64).reshape(3, 3)
+            elif K is None and torch.is_tensor(viewmat) and not viewmat.is_cuda:
+                k_host = viewmat.reshape(-1)[16:25].double().numpy().reshape(3, 3)
+            if k_host is not None and not np.allclose(k_host, self.dataset_K, rtol=1e-6, atol=0.0):
+                raise ValueError("this FrameRenderer writes dataset frames for the intrinsics dataset_K it was built with; "
+                                 "the submitted K differs (build one renderer per set of intrinsics)")
         if torch.is_tensor(viewmat) and K is None:
             packed = viewmat.reshape(-1)               # pack_camera(): (viewmat | K) already on one tensor
         elif not torch.is_tensor(viewmat) and not torch.is_tensor(K):
@@ -328,10 +343,12 @@ class FrameRenderer:
         return out
 
     def render(self, viewmat, K) -> Dict:
-        """Synchronous convenience: one frame, returned as copies (the slot is released)."""
+        """Synchronous convenience: one frame, returned as copies (the slot is released).  A renderer built with
+        dataset_output= returns "rgba" / "distance" (and colors / alphas only with dataset_keep_float=True, else None)."""
         t = self.submit(viewmat, K)
         f = self.fetch(t)
-        out = {"colors": f["colors"].clone(), "alphas": f["alphas"].clone(), "meta": f["meta"]}
+        out = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in f.items() if k not in ("meta", "dataset")}
+        out["meta"] = f["meta"]
         self.release(t)
         return out
 

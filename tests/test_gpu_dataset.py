@@ -149,3 +149,63 @@ def test_frame_renderer_dataset_frames(dt):
         FrameRenderer(t, W, H, render_mode="RGB", isect_capacity=600_000, dataset_output=dt, dataset_K=cams[0].K)
     with pytest.raises(ValueError):
         FrameRenderer(t, W, H, render_mode="RGB+ED", isect_capacity=600_000, dataset_output=dt)
+
+
+def test_dataset_only_renderer_through_the_convenience_paths_and_its_argument_checks():
+    """A renderer built with dataset_output= (no float frame) through FrameRenderer.render() and
+    render_sharded(renderer=): both return the dataset frames; float64 distances on an odd pixel count (the distance
+    plane is then not 8-byte aligned inside a packed frame); a submitted K that is not dataset_K and output buffers of
+    the wrong size or device are refused before any kernel writes through them."""
+    from robosimgs_amd import FrameRenderer, camera_ring, rasterization, synthetic_scene
+    from robosimgs_amd.dataset import frame_to_dataset
+    from robosimgs_amd.distributed import render_sharded
+    W, H = 203, 131                                   # odd x odd: W * H * 4 is 4 mod 8
+    g = synthetic_scene(20_000, math.log(0.05), 2, 4)
+    cams = camera_ring(4, W, H)
+    t = g.to_torch(DEV, 2)
+    plain = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=2, isect_capacity=600_000)
+    for dt in (torch.float64, torch.float16):
+        fr = FrameRenderer(t, W, H, render_mode="RGB+ED", frames_in_flight=2, isect_capacity=600_000, dataset_output=dt,
+                           dataset_K=cams[0].K)
+        refs = []
+        for cam in cams:
+            f = plain.render(cam.viewmat(), cam.K)
+            assert f["colors"].shape == (H, W, 4) and "rgba" not in f
+            refs.append(frame_to_dataset(f["colors"], f["alphas"], cam.K, distance_dtype=dt))
+        out = fr.render(cams[1].viewmat(), cams[1].K)
+        assert out["colors"] is None and out["alphas"] is None and "dataset" not in out
+        assert torch.equal(out["rgba"], refs[1][0]) and torch.equal(out["distance"], refs[1][1])
+        vms = torch.from_numpy(np.stack([c.viewmat() for c in cams]).astype(np.float32)).to(DEV)
+        Ks = torch.from_numpy(np.stack([c.K for c in cams]).astype(np.float32)).to(DEV)
+        rgba, dist, mine = render_sharded(t, vms, Ks, W, H, gather=False, renderer=fr, render_mode="RGB+ED")
+        assert list(mine) == [0, 1, 2, 3] and rgba.dtype == torch.uint8 and dist.dtype == dt
+        for i in range(4):
+            assert torch.equal(rgba[i], refs[i][0]) and torch.equal(dist[i], refs[i][1]), i
+        with pytest.raises(ValueError):
+            render_sharded(t, vms, Ks, W, H, gather=False, renderer=fr, render_mode="RGB+ED", as_u8=True)
+        K_other = cams[0].K.copy()
+        K_other[0, 0] *= 1.01
+        with pytest.raises(ValueError):
+            fr.submit(cams[0].viewmat(), K_other)
+        with pytest.raises(ValueError):
+            fr.submit(FrameRenderer.pack_camera(cams[0].viewmat(), K_other))          # packed on the host: checked too
+        tk = fr.submit(cams[0].viewmat(), cams[0].K)                                  # (the refusals took no slot)
+        fr.fetch(tk)
+        fr.release(tk)
+    vm, K1 = vms[:2], Ks[:2]
+    kw = dict(sh_degree=2, render_mode="RGB+ED", isect_capacity=600_000, lean_meta=True)
+    good_rgba = torch.zeros(2, H, W, 4, dtype=torch.uint8, device=DEV)
+    good_dist = torch.zeros(2, H, W, 1, dtype=torch.float32, device=DEV)
+    for rgba_, dist_ in ((torch.zeros(H, W, 4, dtype=torch.uint8, device=DEV), good_dist),          # one frame for two cameras
+                         (good_rgba, torch.zeros(H, W, 1, dtype=torch.float32, device=DEV)),
+                         (good_rgba, torch.zeros(2, H, W - 1, 1, dtype=torch.float32, device=DEV))):
+        with pytest.raises(ValueError):
+            rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K1, W, H,
+                          dataset_out=(rgba_, dist_, cams[0].K, False), **kw)
+    from robosimgs_amd import _lib
+    with pytest.raises(_lib.MgsError):
+        rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K1, W, H,
+                      dataset_out=(good_rgba.cpu(), good_dist, cams[0].K, False), **kw)
+    with pytest.raises(ValueError):
+        rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm, K1, W, H,
+                      dataset_out=(good_rgba, good_dist, None, False), **kw)

@@ -250,6 +250,73 @@ def test_config3_backward_matches_fp64_oracle(config2):
                  budget=pb[k].reshape(ref.shape[0], -1))
 
 
+def test_config3_timed_training_step_rgb_ed_l1_matches_fp64_oracle(config2):
+    """configs[2] exactly as bench.py's `fwd_bwd` leg times it: render_mode "RGB+ED" (four channels, the expected-depth
+    divide undone in the backward's prologue), the fused L1 loss to the seed-1 U(0,1) target on all four channels (its
+    cotangent is sign(render - target) / n), a fixed list capacity -- i.e. the batched training calls
+    mgs_render_frames_train / mgs_render_frames_backward -- and the segmented backward walk (backward_segment 256).
+    Every one of the 1 M rows of the nine gradient tensors must lie within rounding + 1.5 x its flip budget of the fp64
+    oracle chain (tests/grad_gate.py; blend: oracle/gs_cpu.cpp, then fp64 autograd through projection, SH and depth)."""
+    from robosimgs_amd import rasterization, l1_loss
+    from oracle import gs_oracle_torch as OT
+    from grad_gate import compare, oracle_budgets, chained_budget
+    g, cam, t = config2
+    W, H, deg, mode = 1920, 1080, 3, "RGB+ED"
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    names = ("means", "quats", "scales", "opacities", "colors")
+    target = torch.rand(1, H, W, 4, device=DEV, generator=torch.Generator(DEV).manual_seed(1))      # bench.py: bench_fwd_bwd
+
+    def step(cap):
+        p = {k: t[k].detach().clone().requires_grad_(True) for k in names}
+        c, a, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, K, W, H,
+                                   sh_degree=deg, render_mode=mode, isect_capacity=cap)
+        l1_loss(c, target).backward()
+        return c.detach(), {k: p[k].grad.detach() for k in names}, meta
+
+    # the timed form (fixed capacity: one HIP-graph-capturable step) and the per-camera entry points, which also publish
+    # the blend stage's own four gradients; the two must agree bit for bit
+    c_cap, got, meta_cap = step(4_700_000)
+    assert int(meta_cap["isect_status"].max()) == 0
+    c_pc, got_pc, meta = step(None)
+    assert torch.equal(c_cap, c_pc)
+    for k in names:
+        assert torch.equal(got[k], got_pc[k]), k
+    got_blend = [x.detach().cpu() for x in meta["blend_grads"][0]]
+    assert torch.equal(meta_cap["means2d_grad"][0].cpu(), got_blend[0])
+    w_img = (torch.sign(c_cap[0] - target[0]) / float(c_cap.numel())).cpu().numpy()      # what mgs_l1_loss_fwd_grad leaves
+    got = {k: v.cpu() for k, v in got.items()}
+    del c_cap, c_pc, got_pc, meta, meta_cap
+    vmf, Kf = np.asarray(cam.viewmat(), np.float32), np.asarray(cam.K, np.float32)
+    info = oracle_budgets(g, vmf, Kf, W, H, deg, mode, w_img, np.zeros((H, W), np.float32), O.EPS_PATH_GRAD)
+    vis, bud = info["radii"] > 0, info["budget"]
+    print(f"\nRGB+ED / L1 step: Gaussians that reach a could-flip pixel: {info['touched'][vis].mean():.1%} of the visible ones")
+    for name, got_b, ref_b, b in (("means2d", got_blend[0], info["g_means2d"], bud[:, 0]),
+                                  ("conics", got_blend[1], info["g_conics"], bud[:, 1]),
+                                  ("feats", got_blend[2], info["g_feats"], bud[:, 2]),
+                                  ("opacities", got_blend[3], info["g_opacities"].reshape(-1, 1), bud[:, 3])):
+        compare(f"RGB+ED L1 v_{name} (blend)", got_b, ref_b, row_tol=5e-3, bad_frac=1e-2, cos_min=0.999, budget=b)
+    compare("RGB+ED L1 v_opacities", got["opacities"], info["g_opacities"].reshape(-1, 1), row_tol=5e-3, bad_frac=1e-2,
+            cos_min=0.999, budget=bud[:, 3])
+    d = lambda x, grad=False: torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=grad)
+    r = {"means": d(g.means, True), "quats": d(g.quats, True), "scales": d(g.scales, True),
+         "colors": d(g.sh_coeffs[:, :(deg + 1) ** 2], True)}
+    vmt, Kt = d(vmf), d(Kf)
+    pr = OT.project(r["means"], r["quats"], r["scales"], vmt, Kt, W, H)
+    assert int((pr["radii"] > 0).sum()) == int(vis.sum())
+    campos = -vmt[:3, :3].T @ vmt[:3, 3]
+    rgb = torch.clamp(OT.spherical_harmonics(deg, r["means"] - campos, r["colors"]) + 0.5, min=0.0)
+    rgb = rgb * torch.tensor(vis, dtype=torch.float64)[:, None]
+    feats = torch.cat([rgb, pr["depths"][:, None]], dim=-1)            # the fourth blended channel is the camera depth
+    pb = chained_budget(r, {"means2d": pr["means2d"], "conics": pr["conics"], "feats": feats},
+                        {"means2d": bud[:, 0], "conics": bud[:, 1], "feats": bud[:, 2]})
+    (pr["means2d"] * d(info["g_means2d"])).sum().add((pr["conics"] * d(info["g_conics"])).sum()) \
+        .add((feats * d(info["g_feats"])).sum()).backward()
+    for k in ("means", "quats", "scales", "colors"):
+        ref = r[k].grad.numpy()
+        compare("RGB+ED L1 v_" + k, got[k], ref.reshape(ref.shape[0], -1), row_tol=5e-3, bad_frac=1e-2, cos_min=0.999,
+                budget=pb[k].reshape(ref.shape[0], -1))
+
+
 def test_config4_block_of_eight_ring_cameras_through_render_sharded(config2):
     """configs[3]'s per-GPU share at its real shape: 8 consecutive cameras of the 64-camera ring at
     1920x1080 through `render_sharded(renderer=FrameRenderer)` (world of one, no collective); two of
