@@ -541,6 +541,42 @@ def check_frame(got, got_alpha, ref, ref_alpha, margins, eps, edge_mask=None, to
     return stats
 
 
+def check_frame_against_fp32_port(got, got_alpha, ref, ref_alpha, fp32_render, fp32_alpha, margins, eps, edge_mask=None,
+                                  tol=1e-4, expected_depth=False, what="frame"):
+    """The forward gate for scenes that are ILL-CONDITIONED FOR FP32 (needle-like Gaussians seen hundreds of pixels from
+    their means, lists of thousands of entries): there a plain fp32 restatement of the reference's own formulas -- the C++
+    port's float instantiation, fp32_render / fp32_alpha (depth SUM in the last channel with expected_depth) -- is itself
+    thousands of pixels away from the fp64 answer (`ref`), because sigma of such a pair is uncertain by percents from fp32
+    means2d / conics alone, and no two fp32 pipelines agree to 1e-4.  check_frame's zero-unexplained-pixels rule cannot
+    hold for ANY fp32 implementation on such a scene; what can be demanded, and is here, is that the frame under test is
+    NO FARTHER from the fp64 answer than that fp32 restatement: no more pixels over `tol`, no more of them unexplained by
+    a near-flip decision (explained_pixels), no larger 99.9th / 99.99th percentile of the error (in units of the tolerance,
+    the expected-depth channel through the divide), a maximum within a factor of two.  Returns the statistics of both."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    ga, ra = np.asarray(got_alpha, dtype=np.float64), np.asarray(ref_alpha, dtype=np.float64)
+    ga, ra = ga.reshape(ga.shape[:2]), ra.reshape(ra.shape[:2])
+    r32 = np.array(fp32_render, dtype=np.float64)
+    a32 = np.asarray(fp32_alpha, dtype=np.float64).reshape(ra.shape)
+    lim = np.full(ref.shape, tol)
+    if expected_depth:
+        r32[..., -1] /= np.maximum(a32, 1e-10)
+        lim[..., -1] = tol * (1.0 + np.abs(ref[..., -1])) / np.maximum(ra, 1e-10)
+    ex = explained_pixels(margins, eps, edge_mask)
+
+    def stats_of(x, xa):
+        e = np.maximum((np.abs(x - ref) / lim).max(-1), np.abs(xa - ra) / tol)      # error in units of the tolerance
+        return {"over_tol": int((e > 1.0).sum()), "unexplained": int(((e > 1.0) & ~ex).sum()),
+                "err_q999": float(np.quantile(e, 0.999)), "err_q9999": float(np.quantile(e, 0.9999)), "err_max": float(e.max())}
+    st, st32 = stats_of(got, ga), stats_of(r32, a32)
+    out = {"could_flip_frac": float(ex.mean())}
+    out.update({k: v for k, v in st.items()})
+    out.update({k + "_fp32_port": v for k, v in st32.items()})
+    for k in st:           # (the maximum is one pixel of 2 M: a factor of two on it; counts and percentiles one to one)
+        assert st[k] <= max((2.0 if k == "err_max" else 1.0) * st32[k], 1.0 if k.startswith("err") else 0), (
+            f"{what}: farther from the fp64 answer than a plain fp32 restatement of the reference's formulas ({k}): {out}")
+    return out
+
+
 def gaussian_edge_mask(p, opacities, width, height, tile_size=16, eps_radius=3e-5, d_mu=1e-3,
                        eps_alpha=1e-3, near_plane=0.01, far_plane=1e10, return_weight=False):
     """bool [H,W]: pixels that a Gaussian reaches with alpha >= (1 - eps_alpha)/255 inside a tile

@@ -9,7 +9,7 @@ from .camera import (Camera, camera_ring, cameras_from_camera_params_json,
                      cameras_from_transforms_json, depth_to_distance, distance_to_depth,
                      unproject_point)
 from .gaussians import (Gaussians, load_dataparser_transforms, load_ply, save_ply,
-                        synthetic_scene)
+                        synthetic_scene, synthetic_scene_heavy_tailed)
 
 __version__ = "0.1.0"
 

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     const uint32_t* __restrict__ table, const uint32_t* __restrict__ tile_count, uint32_t capacity,
     uint32_t* __restrict__ flatten_ids, int32_t* __restrict__ tile_offsets,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status, int32_t* __restrict__ group_order,
-    const uint32_t* __restrict__ scanned_sums, int4* __restrict__ pair_info) {
+    const uint32_t* __restrict__ scanned_sums, int4* __restrict__ pair_info, uint32_t* __restrict__ zero_word) {
   extern __shared__ uint32_t cursor[];
   n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins (see direct_hist_kernel)
   if (group_order && blockIdx.x == gridDim.x - 1) {
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     tile_offsets[n_tiles] = (int32_t)(total < capacity ? (uint32_t)total : capacity);
     *n_isect = total > 0xffffffffull ? 0xffffffffu : (uint32_t)total;
     *status = total > capacity ? MGS_STATUS_ISECT_OVERFLOW : 0u;
+    if (zero_word) *zero_word = 0u;            // the per-tile sort's count of long lists (tile_sort.hip), instead of a memset
   }
   __syncthreads();
   const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
@@ -625,7 +626,7 @@ struct Workspace {
     tile_alt = take(cc * 4); id_alt = take(cc * 4);
     tile_priv = take(cc * 4);          // stands in for the caller's tile_ids when that is null
     radix = take(radix_sort_temp_bytes((uint32_t)cc));
-    tsort = take(tile_depth_sort_temp_bytes((uint32_t)cc));
+    tsort = take(tile_depth_sort_temp_bytes((uint32_t)cc, n_tiles));
     const size_t nt = (size_t)(n_tiles < kDirectMaxTiles ? n_tiles : kDirectMaxTiles);   // bins: tiles or tile groups
     table = take((size_t)direct_blocks((unsigned)nn) * nt * 4);
     tile_count = take(nt * 4);
@@ -731,7 +732,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                          chunk, ginfo, tile_w, n_tiles, gshift, u32(ws.table), u32(ws.tile_count), cap,                   \
                          gshift ? u32(ws.id_alt) : reinterpret_cast<uint32_t*>(flatten_ids),                             \
                          gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status,      \
-                         order_in_scatter ? tile_group_order : nullptr, sums, reinterpret_cast<int4*>(pair_info))
+                         order_in_scatter ? tile_group_order : nullptr, sums, reinterpret_cast<int4*>(pair_info),           \
+                         tile_depth_sort_long_list(w + ws.tsort, cap))
       if (pair_info) MGS_SCATTER(true);
       else MGS_SCATTER(false);
 #undef MGS_SCATTER
@@ -761,7 +763,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
     const bool grouped = direct && gshift > 0;
     rc = tile_depth_sort(n_tiles, tile_offsets, depths, cap, reinterpret_cast<uint32_t*>(flatten_ids),
                          direct && (want_tile_ids || isect_ids) ? tile_ids : nullptr, w + ws.tsort, s, grouped ? u32(ws.id_alt) : nullptr,
-                         grouped ? reinterpret_cast<const int32_t*>(w + ws.group_offsets) : nullptr, gshift);
+                         grouped ? reinterpret_cast<const int32_t*>(w + ws.group_offsets) : nullptr, gshift, /*long_list_zeroed=*/direct);
     if (rc) return rc;
   }
   if (tile_group_order && !order_done) {

@@ -26,7 +26,13 @@
 namespace mgs {
 namespace {
 
-constexpr int kTS = 256;            // threads per tile
+constexpr int kTSMain = 256;        // threads per tile
+// Lists longer than the main kernel's LDS list (kFast entries) are not walked by its 256 threads through global scratch
+// -- 540 us for ONE tile of 31 k entries on a clustered scene, the tail of the whole binning stage -- but handed to a
+// second launch of a few large workgroups: 1024 threads, an LDS list of kFastXL entries, the same algorithm.  The main
+// kernel appends such tiles to a list; on scenes without them (SURVEY 8(d)'s: longest list 1.5 k) the second launch reads
+// a zero and leaves.
+constexpr int kTSLong = 1024, kFastXL = 8192, kLongGrid = 256;
 // buckets of one MSD level
 constexpr int buckets_for(int) { return 1024; }   // (256 for the short-list variant: fewer counters to zero / scan, but ~2 entries per
                                                   //  bucket make the wave's rank loop as long as its fullest bucket: 22.6 M VALU against 21.8 M)
@@ -54,6 +60,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 }
 
 // exclusive scan of one value per thread over the workgroup; *total = sum
+template <int kTS>
 __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_sums, uint32_t* total) {
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // inclusive scan over the wave in six DPP adds: row_shr 1 / 2 / 4 / 8 inside the rows of 16 (zero fill), then lane 15
@@ -86,11 +93,13 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_s
 // of `staging` (entry = id | tile's place in the group << (32 - shift), any order).  The tile's workgroup reads
 // its group's segment (the 2^shift workgroups of a group run side by side: L2 hits), keeps its own entries and
 // counts those of the group's earlier tiles -- which is where its list starts; it stores that offset too.
-template <bool GROUPED, int kFast>
-__global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
-    int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
+// LONG: the second launch (lists over the main kernel's kFast); otherwise such a tile is appended to long_list and left
+template <bool GROUPED, int kFast, int kTS, bool LONG>
+__device__ __forceinline__ void sort_one_tile(
+    const int tile, int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
     uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
-    uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out) {
+    uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out,
+    uint32_t* __restrict__ long_list) {
   constexpr int kBuckets = buckets_for(kFast), kDigitBits = log2i(kBuckets);
   __shared__ uint32_t cnt[kBuckets];
   __shared__ uint32_t cur[kBuckets];
@@ -106,17 +115,6 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
   // reads one ds_read_b64 and makes one 64-bit compare per candidate
   __shared__ unsigned long long lc[kFast];
   uint32_t* li = reinterpret_cast<uint32_t*>(lc);
-  // GROUPED: the 2^shift workgroups of a group all read the group's segment.  Workgroup b runs on XCD b % 8 (observed
-  // placement, used for speed only), each XCD has its own L2: with tile = blockIdx.x the four readers sat on four XCDs
-  // and the segment came out of HBM / Infinity Cache four times (FETCH_SIZE 2 x 39 MB for 15 MB of entries).  Blocks
-  // of 8 * 2^shift consecutive workgroups take 8 groups, one per XCD: b = 8 G q + r -> group 8 q + r % 8, tile r / 8
-  // of it, so a group's readers share one L2 and are dispatched within 8 G workgroups of each other.
-  int tile = blockIdx.x;
-  if (GROUPED) {
-    const int G = 1 << shift, r = blockIdx.x % (8 * G);
-    tile = ((blockIdx.x / (8 * G)) * 8 + (r & 7)) * G + (r >> 3);
-  }
-  if (tile >= n_tiles) return;
   const int tid = threadIdx.x;
   int s, e, gs = 0, ge = 0;
   uint32_t local = 0, id_mask = ~0u;
@@ -167,17 +165,23 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     __syncthreads();
     s = gs + (int)gcount[0];
     e = s + (int)gcount[1];
-    if (tid == 0) {
+    if (tid == 0 && !LONG) {
       offsets_out[tile] = s;
       if (tile == n_tiles - 1) offsets_out[n_tiles] = e;
     }
   } else {
     s = offsets[tile]; e = offsets[tile + 1];
   }
+  if (!LONG && e - s > kFast) {      // (uniform) a long list: the second launch sorts it (its tile ids are filled here)
+    if (tile_ids)
+      for (int i = s + tid; i < e; i += kTS) tile_ids[i] = (uint32_t)tile;
+    if (tid == 0) long_list[1 + atomicAdd(long_list, 1u)] = (uint32_t)tile;
+    return;
+  }
 #if MGS_TSORT_STOP == 1
   return;
 #endif
-  if (tile_ids)
+  if (tile_ids && !LONG)
     for (int i = s + tid; i < e; i += kTS) tile_ids[i] = (uint32_t)tile;
   if (e - s <= 1) {
     if (GROUPED && e - s == 1 && tid == 0) ids_final[s] = li[0];
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
         packed += c4[k] + (c4[k] > (uint32_t)kSmall ? 0x10000u : 0u);
       }
       uint32_t tot;
-      uint32_t exp = block_scan_excl(packed, wave_sums, &tot);
+      uint32_t exp = block_scan_excl<kTS>(packed, wave_sums, &tot);
       uint32_t ex = exp & 0xffffu, hx = exp >> 16;
       htot = tot >> 16;
 #pragma unroll
@@ -334,25 +338,54 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     if (GROUPED) {          // longer than the LDS list: collect again, straight into buffer 0
       if (tid == 0) gcount[1] = 0u;
       __syncthreads();
-      for (int i0 = gs; i0 < ge; i0 += kTS) {
-        const int i = i0 + tid;
-        const uint32_t v = i < ge ? staging[i] : 0u;
-        const bool mine = i < ge && (v >> (32 - shift)) == local;
-        const unsigned long long m = ballot(mine);
-        uint32_t base = 0;
-        if ((tid & 63) == 0 && m) base = atomicAdd(&gcount[1], (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (mine) {
-          const uint32_t pos = base + mask_rank(m), id = v & id_mask;
-          key0[s + pos] = __float_as_uint(depths[id]);
-          id0[s + pos] = id;
+      // (eight segment loads, then the matches' depth gathers, in flight together: one trip was two exposed round trips)
+      constexpr int kIF = 8;
+      for (int i0 = gs; i0 < ge; i0 += kTS * kIF) {
+        uint32_t vv[kIF], pos[kIF], kk[kIF];
+        bool mine[kIF];
+#pragma unroll
+        for (int j = 0; j < kIF; ++j) {
+          const int i = i0 + j * kTS + tid;
+          vv[j] = i < ge ? staging[i] : 0u;
         }
+        unsigned long long mm[kIF];
+        uint32_t run[kIF], wave_total = 0;
+#pragma unroll
+        for (int j = 0; j < kIF; ++j) {
+          const int i = i0 + j * kTS + tid;
+          mine[j] = i < ge && (vv[j] >> (32 - shift)) == local;
+          mm[j] = ballot(mine[j]);
+          run[j] = wave_total;
+          wave_total += (uint32_t)__popcll(mm[j]);
+        }
+        uint32_t base = 0;
+        if ((tid & 63) == 0 && wave_total) base = atomicAdd(&gcount[1], wave_total);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int j = 0; j < kIF; ++j) {
+          pos[j] = base + run[j] + mask_rank(mm[j]);
+          kk[j] = mine[j] ? __float_as_uint(depths[vv[j] & id_mask]) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kIF; ++j)
+          if (mine[j]) {
+            key0[s + pos[j]] = kk[j];
+            id0[s + pos[j]] = vv[j] & id_mask;
+          }
       }
     } else {
-      for (int i = s + tid; i < e; i += kTS) {
-        const uint32_t id = ids_final[i];
-        key0[i] = __float_as_uint(depths[id]);
-        id0[i] = id;
+      constexpr int kIF = 4;
+      for (int i0 = s; i0 < e; i0 += kTS * kIF) {
+        uint32_t id[kIF], kk[kIF];
+#pragma unroll
+        for (int j = 0; j < kIF; ++j) { const int i = i0 + j * kTS + tid; id[j] = i < e ? ids_final[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < kIF; ++j) { const int i = i0 + j * kTS + tid; kk[j] = i < e ? __float_as_uint(depths[id[j]]) : 0u; }
+#pragma unroll
+        for (int j = 0; j < kIF; ++j) {
+          const int i = i0 + j * kTS + tid;
+          if (i < e) { key0[i] = kk[j]; id0[i] = id[j]; }
+        }
       }
     }
     if (tid == 0) {
@@ -362,6 +395,9 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     __syncthreads();
   }
 
+  // (measured and rejected, round 5: pending buckets of up to kFast / waves entries finished by ONE wave each, all waves at
+  //  once, by rank counting out of a slice of the LDS list -- 285 instead of 252 us for the long lists of the clustered
+  //  scene, 189 instead of 102 us for the main kernel: m^2 / 64 candidates per lane lose to one more bucketing level)
   while (true) {
     const int sn = stack_n;                        // uniform: read behind a barrier
     if (sn == 0) break;
@@ -387,11 +423,23 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     }
 
     // highest differing bit of the composites
+    constexpr int kIF = 4;                         // loads in flight per thread in the passes below
     unsigned long long mn = ~0ull, mx = 0ull;
-    for (int i = lo + tid; i < hi; i += kTS) {
-      const unsigned long long c = ((unsigned long long)sk[i] << 32) | si[i];
-      mn = c < mn ? c : mn;
-      mx = c > mx ? c : mx;
+    for (int i0 = lo; i0 < hi; i0 += kTS * kIF) {
+      uint32_t kk[kIF], ii[kIF];
+#pragma unroll
+      for (int j = 0; j < kIF; ++j) {
+        const int i = i0 + j * kTS + tid;
+        kk[j] = i < hi ? sk[i] : 0u;
+        ii[j] = i < hi ? si[i] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < kIF; ++j)
+        if (i0 + j * kTS + tid < hi) {
+          const unsigned long long c = ((unsigned long long)kk[j] << 32) | ii[j];
+          mn = c < mn ? c : mn;
+          mx = c > mx ? c : mx;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -415,7 +463,18 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
       return (unsigned)(c >> shift) & (kBuckets - 1);
     };
 
-    for (int i = lo + tid; i < hi; i += kTS) atomicAdd(&cnt[digit(sk[i], si[i])], 1u);
+    for (int i0 = lo; i0 < hi; i0 += kTS * kIF) {
+      uint32_t kk[kIF], ii[kIF];
+#pragma unroll
+      for (int j = 0; j < kIF; ++j) {
+        const int i = i0 + j * kTS + tid;
+        kk[j] = i < hi ? sk[i] : 0u;
+        ii[j] = i < hi ? si[i] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < kIF; ++j)
+        if (i0 + j * kTS + tid < hi) atomicAdd(&cnt[digit(kk[j], ii[j])], 1u);
+    }
     __syncthreads();
 
     // exclusive scan of the bucket sizes (four consecutive buckets per thread); heavy buckets get their
@@ -429,8 +488,8 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
         heavy += c4[k] > (uint32_t)kSmall ? 1u : 0u;
       }
       uint32_t tot, htot;
-      uint32_t ex = block_scan_excl(sum, wave_sums, &tot);
-      uint32_t hx = block_scan_excl(heavy, wave_sums, &htot);
+      uint32_t ex = block_scan_excl<kTS>(sum, wave_sums, &tot);
+      uint32_t hx = block_scan_excl<kTS>(heavy, wave_sums, &htot);
       const int base = sn - 1;                     // stack height after the pop
 #pragma unroll
       for (int k = 0; k < kBuckets / kTS; ++k) {
@@ -451,52 +510,123 @@ __global__ __launch_bounds__(kTS) void tile_depth_sort_kernel(
     }
     __syncthreads();
 
-    for (int i = lo + tid; i < hi; i += kTS) {
-      const uint32_t k = sk[i], id = si[i];
-      const uint32_t p = atomicAdd(&cur[digit(k, id)], 1u);
-      dk[lo + p] = k;
-      di[lo + p] = id;
+    for (int i0 = lo; i0 < hi; i0 += kTS * kIF) {
+      uint32_t kk[kIF], ii[kIF];
+#pragma unroll
+      for (int j = 0; j < kIF; ++j) {
+        const int i = i0 + j * kTS + tid;
+        kk[j] = i < hi ? sk[i] : 0u;
+        ii[j] = i < hi ? si[i] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < kIF; ++j)
+        if (i0 + j * kTS + tid < hi) {
+          const uint32_t p = atomicAdd(&cur[digit(kk[j], ii[j])], 1u);
+          dk[lo + p] = kk[j];
+          di[lo + p] = ii[j];
+        }
     }
     __syncthreads();                               // the scattered segment is visible to the workgroup
 
-    // cur[d] is now the END of bucket d: every element of a light bucket ranks itself inside it
-    for (int i = lo + tid; i < hi; i += kTS) {
-      const uint32_t k = dk[i], id = di[i];
-      const unsigned d = digit(k, id);
-      const uint32_t craw = cnt[d];
-      const uint32_t b = craw & ~kBrute;
-      if (b > (uint32_t)kSmall && !(craw & kBrute)) continue;     // on the stack
-      const int be = lo + (int)cur[d], bs = be - (int)b;
-      int c = 0;
-      for (int j = bs; j < be; ++j) c += comp_less(dk[j], di[j], k, id) ? 1 : 0;
-      ids_final[bs + c] = id;
+    // cur[d] is now the END of bucket d: every element of a light bucket ranks itself inside it.  The scattered
+    // segment goes through the LDS list in windows of kFast - 2 kSmall entries with kSmall more on either side (a light
+    // bucket holds at most kSmall entries, so the whole bucket of every element of the window is in LDS): one coalesced
+    // load per entry instead of a dependent global load per CANDIDATE -- a 31 k-entry list has ~30 of them per element.
+    constexpr int kWin = kFast - 2 * kSmall;
+    for (int w0 = lo; w0 < hi; w0 += kWin) {
+      const int wa = max(lo, w0 - kSmall), wb = min(hi, w0 + kWin + kSmall), we = min(hi, w0 + kWin);
+      for (int i = wa + tid; i < wb; i += kTS) lc[i - wa] = ((unsigned long long)dk[i] << 32) | di[i];
+      __syncthreads();
+      for (int i = w0 + tid; i < we; i += kTS) {
+        const unsigned long long me = lc[i - wa];
+        const uint32_t k = (uint32_t)(me >> 32), id = (uint32_t)me;
+        const unsigned d = digit(k, id);
+        const uint32_t craw = cnt[d];
+        const uint32_t b = craw & ~kBrute;
+        if (b > (uint32_t)kSmall && !(craw & kBrute)) continue;     // on the stack
+        const int be = lo + (int)cur[d], bs = be - (int)b;
+        int c = 0;
+        if (b <= (uint32_t)kSmall) {
+          for (int j = bs; j < be; ++j) c += lc[j - wa] < me ? 1 : 0;
+        } else {                                                    // past the stack's room: any size, out of global memory
+          for (int j = bs; j < be; ++j) c += comp_less(dk[j], di[j], k, id) ? 1 : 0;
+        }
+        ids_final[bs + c] = id;
+      }
+      __syncthreads();                             // the next window overwrites the list
     }
-    __syncthreads();
+  }
+}
+
+template <bool GROUPED, int kFast>
+__global__ __launch_bounds__(kTSMain) void tile_depth_sort_kernel(
+    int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
+    uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
+    uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out,
+    uint32_t* __restrict__ long_list) {
+  // GROUPED: the 2^shift workgroups of a group all read the group's segment.  Workgroup b runs on XCD b % 8 (observed
+  // placement, used for speed only), each XCD has its own L2: with tile = blockIdx.x the four readers sat on four XCDs
+  // and the segment came out of HBM / Infinity Cache four times (FETCH_SIZE 2 x 39 MB for 15 MB of entries).  Blocks
+  // of 8 * 2^shift consecutive workgroups take 8 groups, one per XCD: b = 8 G q + r -> group 8 q + r % 8, tile r / 8
+  // of it, so a group's readers share one L2 and are dispatched within 8 G workgroups of each other.
+  int tile = blockIdx.x;
+  if (GROUPED) {
+    const int G = 1 << shift, r = blockIdx.x % (8 * G);
+    tile = ((blockIdx.x / (8 * G)) * 8 + (r & 7)) * G + (r >> 3);
+  }
+  if (tile >= n_tiles) return;
+  sort_one_tile<GROUPED, kFast, kTSMain, false>(tile, n_tiles, offsets, depths, ids_final, tile_ids, key0, id0, key1, id1, staging,
+                                                shift, offsets_out, long_list);
+}
+
+// The second launch: the tiles the main kernel listed (long_list[0] of them), one at a time per workgroup.
+template <bool GROUPED>
+__global__ __launch_bounds__(kTSLong) void tile_depth_sort_long_kernel(
+    int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
+    uint32_t* ids_final, uint32_t* key0, uint32_t* id0, uint32_t* key1,
+    uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out,
+    uint32_t* __restrict__ long_list) {
+  const uint32_t n_long = min(long_list[0], (uint32_t)n_tiles);
+  for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
+    sort_one_tile<GROUPED, kFastXL, kTSLong, true>((int)long_list[1 + i], n_tiles, offsets, depths, ids_final, nullptr, key0, id0,
+                                                   key1, id1, staging, shift, offsets_out, long_list);
+    __syncthreads();                 // the LDS of one tile is done with before the next one's first store
   }
 }
 
 }  // namespace
 
-size_t tile_depth_sort_temp_bytes(uint32_t capacity) {
-  return 4 * align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256);
+// temp: four scratch arrays of `capacity` words + the list of long tiles (a counter and up to n_tiles entries)
+size_t tile_depth_sort_temp_bytes(uint32_t capacity, int n_tiles) {
+  return 4 * align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256) +
+         align_up(((size_t)(n_tiles > 0 ? n_tiles : 0) + 1) * sizeof(uint32_t), 256);
 }
 
 // Sorts flatten_ids[offsets[t] .. offsets[t+1]) of every tile by (depth bits, id).  temp:
-// tile_depth_sort_temp_bytes(capacity) bytes.
+// tile_depth_sort_temp_bytes(capacity, n_tiles) bytes.  long_list_zeroed: the caller's earlier kernel has already stored
+// a zero in the first word of the long-tile list (tile_depth_sort_long_list(temp, capacity)); otherwise a memset does.
+uint32_t* tile_depth_sort_long_list(void* temp, uint32_t capacity) {
+  return static_cast<uint32_t*>(temp) + 4 * (align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256) / sizeof(uint32_t));
+}
 int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depths, uint32_t capacity,
                     uint32_t* flatten_ids, uint32_t* tile_ids_fill, void* temp, hipStream_t stream,
-                    const uint32_t* staging, const int32_t* group_offsets, int group_shift) {
+                    const uint32_t* staging, const int32_t* group_offsets, int group_shift, bool long_list_zeroed) {
   if (n_tiles <= 0) return MGS_OK;
   const size_t stride = align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256) / sizeof(uint32_t);
   uint32_t* t = static_cast<uint32_t*>(temp);
+  uint32_t* long_list = tile_depth_sort_long_list(temp, capacity);
+  if (!long_list_zeroed) {
+    hipError_t e = hipMemsetAsync(long_list, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return set_error((int)e, "tile_depth_sort: memset: %s", hipGetErrorString(e));
+  }
   // average list length the capacity allows: short lists -> the fast path with the smaller LDS list
   const bool short_lists = (size_t)capacity <= (size_t)n_tiles * 640;
   // (GROUPED launches are padded to whole blocks of 8 groups: the kernel's XCD-aware tile numbering)
   const int per = 8 << group_shift, n_wg = staging ? (n_tiles + per - 1) / per * per : n_tiles;
 #define MGS_TS_LAUNCH(G, F, OFFS, STG, SH, OUT)                                                              \
-  hipLaunchKernelGGL((tile_depth_sort_kernel<G, F>), dim3(n_wg), dim3(kTS), 0, stream, n_tiles, OFFS,   \
+  hipLaunchKernelGGL((tile_depth_sort_kernel<G, F>), dim3(n_wg), dim3(kTSMain), 0, stream, n_tiles, OFFS,   \
                      depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,    \
-                     STG, SH, OUT)
+                     STG, SH, OUT, long_list)
   if (staging) {
     if (short_lists) MGS_TS_LAUNCH(true, kFastShort, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
     else MGS_TS_LAUNCH(true, kFastLong, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
@@ -505,6 +635,16 @@ int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depth
     else MGS_TS_LAUNCH(false, kFastLong, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
   }
 #undef MGS_TS_LAUNCH
+  // the lists over kFast entries (none on SURVEY 8(d)'s scenes: the workgroups read a zero and leave)
+  const int n_long_wg = n_tiles < kLongGrid ? n_tiles : kLongGrid;
+  if (staging)
+    hipLaunchKernelGGL((tile_depth_sort_long_kernel<true>), dim3(n_long_wg), dim3(kTSLong), 0, stream, n_tiles, group_offsets, depths,
+                       flatten_ids, t, t + stride, t + 2 * stride, t + 3 * stride, staging, group_shift,
+                       const_cast<int32_t*>(tile_offsets), long_list);
+  else
+    hipLaunchKernelGGL((tile_depth_sort_long_kernel<false>), dim3(n_long_wg), dim3(kTSLong), 0, stream, n_tiles, tile_offsets, depths,
+                       flatten_ids, t, t + stride, t + 2 * stride, t + 3 * stride, (const uint32_t*)nullptr, 0, (int32_t*)nullptr,
+                       long_list);
   return check_launch("tile_depth_sort");
 }
 

@@ -264,6 +264,62 @@ def synthetic_scene(n: int, log_scale_mean: float, sh_degree: int = 3, seed: int
     return Gaussians(means, log_scales, quats, logits, dc, rest)
 
 
+def synthetic_scene_heavy_tailed(n: int, log_scale_mean: float = float(np.log(0.0045)), sh_degree: int = 3, seed: int = 0,
+                                 extent: float = 3.0, n_clusters: int = 96, n_screen_filling: int = 6,
+                                 n_needles: int = 4000) -> Gaussians:
+    """A scene shaped like an EXPORT rather than like SURVEY.md 8(d)'s i.i.d. cloud (NOT a BASELINE.json config: a
+    no-cliff check for the per-tile sort's refinement levels, the backward's segment tables and the list capacities):
+      * clustered means: `n_clusters` centres U(-extent, extent)^3 with Zipf-like shares (the largest holds ~1/6 of the
+        scene), each an anisotropic blob -- one axis flattened by up to 10x, spread log-normal around 0.25 -- plus 8 % of
+        uniform floaters;
+      * heavy-tailed extents: log scale = N(mu, 1.2^2) shared by the three axes + N(0, 0.35^2) per axis (the 99.9th
+        percentile is ~40x the median; SURVEY 8(d) draws N(mu, 0.4^2));
+      * `n_needles` needle-like Gaussians (the last rows but `n_screen_filling`): axis ratio 100-400 : 1, opaque;
+      * `n_screen_filling` Gaussians (the last rows) of extent 1.5-4 around the origin, opacity 0.04-0.2: at a camera 7
+        units away each covers (nearly) every tile of the frame.
+    PCG64(seed), draws in the order of the code below; the remaining attributes as in synthetic_scene."""
+    rng = np.random.default_rng(seed)
+    n_special = n_needles + n_screen_filling
+    if n <= n_special:
+        raise ValueError(f"n = {n} must exceed the {n_special} needle-like and screen-filling Gaussians")
+    nb = n - n_special
+    centres = rng.uniform(-extent, extent, size=(n_clusters, 3))
+    share = 1.0 / np.arange(1, n_clusters + 1) ** 0.9
+    share /= share.sum()
+    spread = np.exp(rng.normal(np.log(0.25), 0.6, size=n_clusters))
+    flat_axis = rng.integers(0, 3, size=n_clusters)
+    flat = rng.uniform(0.1, 1.0, size=n_clusters)
+    rot = rng.normal(size=(n_clusters, 3, 3))
+    rot = np.linalg.qr(rot)[0]                                          # a random frame per cluster
+    which = rng.choice(n_clusters, size=nb, p=share)
+    local = rng.normal(size=(nb, 3)) * spread[which, None]
+    local[np.arange(nb), flat_axis[which]] *= flat[which]
+    means = centres[which] + np.einsum("nij,nj->ni", rot[which], local)
+    floaters = rng.random(nb) < 0.08
+    means[floaters] = rng.uniform(-extent, extent, size=(int(floaters.sum()), 3))
+    log_scales = rng.normal(log_scale_mean, 1.2, size=(nb, 1)) + rng.normal(0.0, 0.35, size=(nb, 3))
+    logits = rng.normal(0.0, 1.5, size=nb)
+    # needle-like: one long axis, two thin ones, opaque
+    nd_means = rng.uniform(-0.8 * extent, 0.8 * extent, size=(n_needles, 3))
+    long_axis = np.exp(rng.uniform(np.log(0.15), np.log(0.6), size=n_needles))
+    ratio = rng.uniform(100.0, 400.0, size=n_needles)
+    nd_scales = np.stack([long_axis, long_axis / ratio, long_axis / ratio], axis=1)
+    nd_logits = rng.normal(3.0, 1.0, size=n_needles)
+    # screen-filling: large, faint, around the origin
+    sf_means = rng.normal(0.0, 0.3, size=(n_screen_filling, 3))
+    sf_scales = rng.uniform(1.5, 4.0, size=(n_screen_filling, 3))
+    sf_opac = rng.uniform(0.04, 0.2, size=n_screen_filling)
+    means = np.concatenate([means, nd_means, sf_means])
+    log_scales = np.concatenate([log_scales, np.log(nd_scales), np.log(sf_scales)])
+    logits = np.concatenate([logits, nd_logits, np.log(sf_opac / (1.0 - sf_opac))])
+    quats = rng.normal(0.0, 1.0, size=(n, 4))
+    quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+    dc = rng.normal(0.0, 1.0, size=(n, 3))
+    kr = (sh_degree + 1) ** 2 - 1
+    rest = rng.normal(0.0, 0.1, size=(n, 3, kr)).transpose(0, 2, 1)
+    return Gaussians(means, log_scales, quats, logits, dc, rest)
+
+
 # --------------------------------------------------------------------------------------
 # rotating spherical harmonics (host side; used by the world-frame alignment)
 # --------------------------------------------------------------------------------------

@@ -9,7 +9,11 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n, mu, W, H, deg = int(os.environ.get("N", 1_000_000)), float(os.environ.get("MU", 0.012)), int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080)), 3
 CH = int(os.environ.get("CH", 4))      # 4 = RGB + depth (the headline "RGB+ED" frames), 3 = RGB
 dev = "cuda"
-g = synthetic_scene(n, math.log(mu), deg, 0)
+if os.environ.get("SCENE", "") == "heavy":     # the heavy-tailed scene (not a BASELINE config): bench.py `heavy_tailed`
+    from robosimgs_amd import synthetic_scene_heavy_tailed
+    g = synthetic_scene_heavy_tailed(n, sh_degree=deg, seed=0)
+else:
+    g = synthetic_scene(n, math.log(mu), deg, 0)
 if os.environ.get("MORTON", "1") != "0":      # the order FrameRenderer keeps its resident scene in
     g = g.sorted_by_locality()
 cam = camera_ring(1, W, H, thetas=[0.3])[0]
