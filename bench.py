@@ -908,7 +908,7 @@ def bwd_roofline(t, vm, K, W, H, deg, cap, n_isect, standard_workload, segment=2
         t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W, H, 0.3, 0.01, 1e10, 0.0,
         False, True, want_splats=True, bin_seed="tight")
     tl = ops.isect_tiles_raw(m2d, radii, depths, tile_w, tile_h, cap, want_tiles_per_gauss=False, want_pair_info=True,
-                             seed=seed)
+                             seed=seed, splats=splats)
     ck = ops.checkpoint_buffer(cap, tile_w, tile_h, 4, segment, m2d.device)
     render, alphas, last = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tile_w, tile_h, tl.tile_offsets,
                                                  tl.flatten_ids, splats=splats, expected_last=True, latency=True,
@@ -929,7 +929,7 @@ def bwd_roofline(t, vm, K, W, H, deg, cap, n_isect, standard_workload, segment=2
         p_ = ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], deg, t["colors"], vm[0], K[0], W, H,
                                        0.3, 0.01, 1e10, 0.0, False, True, want_splats=True, bin_seed="tight")
         tl_i = ops.isect_tiles_raw(p_[1], p_[0], p_[2], tile_w, tile_h, cap, want_tiles_per_gauss=False, want_pair_info=True,
-                                   seed=p_[-1])
+                                   seed=p_[-1], splats=p_[6])
         ops.rasterize_fwd_raw(p_[1], p_[3], p_[5], t["opacities"], None, W, H, tile_w, tile_h, tl_i.tile_offsets,
                               tl_i.flatten_ids, out=(render, alphas, last), splats=p_[6], expected_last=True, latency=True,
                               group_order=tl_i.group_order, channels=4, checkpoints=ck, checkpoint_interval=segment)

@@ -42,7 +42,7 @@ extern "C" {
  * checkpoints + segmented backward, batched training entry points, debug hooks out of the production build);
  * 410 round 4 (the radius rule as a policy: radii_y / radius_rule arguments, MGS_BIN_* / MGS_FRAMES_RADIUS_* flags,
  * one more field in the training state; 420: the dataset frame as an output of the raster forward, ds_* arguments). */
-#define MGS_VERSION 420
+#define MGS_VERSION 430
 
 #define MGS_OK 0
 #define MGS_ERR_INVALID_ARGUMENT (-1)
@@ -85,6 +85,8 @@ extern "C" {
 #define MGS_BIN_RADIUS_OPACITY_AWARE 2  /* MGS_RADIUS_OPACITY_AWARE instead of MGS_RADIUS_CLASSIC */
 
 /* mgs_rasterize_bwd_det flags */
+#define MGS_RASTER_BWD_SPLAT_SLOTS 2  /* the splat records carry the pairs' record slots (mgs_isect_tiles: splat_slots): pair_info is
+                                         read by the reduce only, the raster kernel gathers nothing but the record */
 #define MGS_RASTER_BWD_RECORDS_ONLY 1 /* stop after the raster kernel: the workspace then holds one record and one flag
                                          per (tile, Gaussian) slot and the v_* outputs are not touched (measurement
                                          of the raster kernel alone; a consumer that sums the records itself) */
@@ -227,6 +229,11 @@ int mgs_project_color_fwd(int n, const float *means, const float *quats, const f
  * seed's: conics / opacities are ignored then); when given, tile_size must be MGS_TILE_SIZE,
  * means2d / radii / conics / opacities are not read (and may be NULL) and seed_sums -- 16-byte aligned --
  * is overwritten (scanned in place).
+ * splat_slots (nullable, with pair_info): the packed records splats[N,12] mgs_project_color_fwd wrote for this camera
+ * (16-byte aligned).  Words 10 and 11 of every binned Gaussian's record -- padding as far as the forward is concerned --
+ * receive {slot_base, x0 | y0 << 10 | w << 20}: mgs_rasterize_bwd_det(MGS_RASTER_BWD_SPLAT_SLOTS) then finds a pair's
+ * record slot in the record it gathers anyway instead of in pair_info (one scattered 16-byte gather per queued entry
+ * less; the reduce still reads pair_info, sequentially).
  * tile_ids (nullable): an inference frame does not need it; NULL saves the store.
  * radii_y[N] (nullable): per-axis radii as MGS_RADIUS_OPACITY_AWARE produces them (gsplat >= 1.5's radii[N,2] as two
  * arrays): the tile rectangle is mean +- (radii, radii_y) instead of the square mean +- radii.
@@ -237,7 +244,7 @@ int mgs_isect_tiles(int n, const float *means2d, const int32_t *radii, const int
                     uint32_t isect_capacity, int32_t *tiles_per_gauss, uint32_t *n_isect,
                     uint32_t *tile_ids, int32_t *flatten_ids, int64_t *isect_ids,
                     int32_t *tile_offsets, int32_t *pair_info, int32_t *tile_group_order,
-                    uint32_t *status, const uint32_t *seed_info, uint32_t *seed_sums,
+                    uint32_t *status, const uint32_t *seed_info, uint32_t *seed_sums, float *splat_slots,
                     void *workspace, size_t *workspace_bytes, mgs_stream_t stream);
 
 /* -------------------------------------------------------------------------------------
@@ -382,7 +389,7 @@ int mgs_rasterize_bwd(int n, const float *means2d, const float *conics, const fl
  *   forward's checkpoint (its T; colour behind = final - checkpoint).  Same records and slots; against the whole-list
  *   walk the gradients differ by rounding only -- measured against fp64 the segmented walk is the closer one, it
  *   restarts from the forward's exact T -- and stay bit-reproducible run to run.
- *   flags: MGS_RASTER_BWD_RECORDS_ONLY.  4-channel frames (v_render, expected_render, render_out) must be 16-byte
+ *   flags: MGS_RASTER_BWD_RECORDS_ONLY, MGS_RASTER_BWD_SPLAT_SLOTS (needs `splats`, annotated by mgs_isect_tiles).  4-channel frames (v_render, expected_render, render_out) must be 16-byte
  *   aligned (rows are read as one 16-byte piece).
  */
 int mgs_rasterize_bwd_det(int n, const float *means2d, const float *conics, const float *feats,

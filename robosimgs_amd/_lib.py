@@ -19,7 +19,7 @@ DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libmgs_debug.so")
 DEBUG_HOOKS = ["mgs_debug_set_raster_cull", "mgs_debug_set_raster_opts", "mgs_debug_set_sort_opts"]
 
 MGS_STATUS_ISECT_OVERFLOW = 1
-MGS_VERSION = 420          # include/mgs.h this binding was written against (parameter lists change with it)
+MGS_VERSION = 430          # include/mgs.h this binding was written against (parameter lists change with it)
 
 
 class MgsError(RuntimeError):
@@ -49,7 +49,7 @@ def _load(path: str = None, hooks: bool = False) -> ctypes.CDLL:
         "mgs_sh_bwd": ([i, i, i, p, p, p, p, p, p, p], c_int),
         "mgs_project_color_fwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, f, f, f, p, p, p, p, p, i, p, p, i, p, p, p, p], c_int),
         "mgs_project_color_bwd": ([i, p, p, p, p, i, i, p, p, p, i, i, f, p, p, i, i, p, p, p, p, p, p, p, p, p, p, p, p, i, p], c_int),
-        "mgs_isect_tiles": ([i, p, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
+        "mgs_isect_tiles": ([i, p, p, p, p, p, p, i, i, i, i, i, u32, p, p, p, p, p, p, p, p, p, p, p, p, p, POINTER(c_size_t), p], c_int),
         "mgs_isect_offset_encode": ([u32, p, i, i, i, p, p], c_int),
         "mgs_render_frames": ([i, p, p, p, p, i, i, p, i, p, p, i, i, f, f, f, f, i, i, i, p, u32, p, p, p, p, p, p, i, p, p, POINTER(c_size_t), p], c_int),
         "mgs_train_state_layout": ([i, i, i, i, u32, i, i, POINTER(c_size_t), POINTER(c_size_t)], c_int),

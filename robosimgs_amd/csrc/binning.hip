@@ -131,9 +131,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_blocksums_kernel(
 // Slots for the deterministic backward, Gaussian-index-major: Gaussian g owns the slots
 // [base, base + w*h) with base = exclusive scan of the tile counts in INDEX order, so that the
 // per-Gaussian reduction reads contiguous memory from consecutive lanes.
+// splat_slots (nullable): the packed 48-byte splat records [N,12]; words 10 and 11 of a Gaussian's record -- padding of the
+// forward -- receive its slot base and its tile rectangle x0 | y0 << 10 | w << 20, so that the raster backward, which has
+// the record in registers anyway, needs no gather of pair_info (16 bytes out of a 128-byte line per queued entry).
+__device__ __forceinline__ void store_splat_slots(float* __restrict__ splat_slots, int g, uint32_t slot_base, uint32_t rect) {
+  if (splat_slots)
+    *reinterpret_cast<uint2*>(splat_slots + 12 * (size_t)g + 10) = make_uint2(slot_base, rect & 0x3fffffffu);
+}
+
 __global__ __launch_bounds__(kBlock) void pair_info_kernel(
     int n, const uint2* __restrict__ ginfo, int tile_h, const uint32_t* __restrict__ blockbase,
-    int4* __restrict__ pair_info) {
+    int4* __restrict__ pair_info, float* __restrict__ splat_slots) {
   __shared__ uint32_t ws[kBlock / 64];
   const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int g = blockIdx.x * kBlock + threadIdx.x;
@@ -152,9 +160,11 @@ __global__ __launch_bounds__(kBlock) void pair_info_kernel(
     if ((unsigned)w < wave) off += ws[w];
   if (g < n) {
     const uint32_t w = info.x >> 20;
-    pair_info[g] = cnt ? make_int4((int)(blockbase[blockIdx.x * (kBlock / kSum)] + off + incl - cnt), (int)(info.x & 1023u),
+    const uint32_t slot_base = blockbase[blockIdx.x * (kBlock / kSum)] + off + incl - cnt;
+    pair_info[g] = cnt ? make_int4((int)slot_base, (int)(info.x & 1023u),
                                    (int)((info.x >> 10) & 1023u), (int)(w | ((cnt / w) << 16)))
                        : make_int4(0, 0, 0, 0);
+    if (cnt) store_splat_slots(splat_slots, g, slot_base, info.x);
   }
 }
 
@@ -428,7 +438,8 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     const uint32_t* __restrict__ table, const uint32_t* __restrict__ tile_count, uint32_t capacity,
     uint32_t* __restrict__ flatten_ids, int32_t* __restrict__ tile_offsets,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status, int32_t* __restrict__ group_order,
-    const uint32_t* __restrict__ scanned_sums, int4* __restrict__ pair_info, uint32_t* __restrict__ zero_word) {
+    const uint32_t* __restrict__ scanned_sums, int4* __restrict__ pair_info, uint32_t* __restrict__ zero_word,
+    float* __restrict__ splat_slots) {
   extern __shared__ uint32_t cursor[];
   n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins (see direct_hist_kernel)
   if (group_order && blockIdx.x == gridDim.x - 1) {
@@ -510,6 +521,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
           pair_info[g] = cnt ? make_int4((int)(sbase[i] + incl - cnt), (int)(info[i].x & 1023u), (int)((info[i].x >> 10) & 1023u),
                                          (int)(w | ((cnt / w) << 16)))
                              : make_int4(0, 0, 0, 0);
+          if (cnt) store_splat_slots(splat_slots, g, sbase[i] + incl - cnt, info[i].x);
         }
       }
     }
@@ -655,7 +667,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                                int32_t* flatten_ids, int64_t* isect_ids, int32_t* tile_offsets,
                                int32_t* pair_info, int32_t* tile_group_order, uint32_t* status,
                                const uint32_t* seed_info,
-                               uint32_t* seed_sums, void* workspace,
+                               uint32_t* seed_sums, float* splat_slots, void* workspace,
                                size_t* workspace_bytes, mgs_stream_t stream) {
   MGS_REQUIRE(n >= 0 && tile_size > 0 && tile_w > 0 && tile_h > 0, "isect_tiles: bad sizes");
   MGS_REQUIRE(tile_w <= 1023 && tile_h <= 1023, "isect_tiles: tile grid %dx%d exceeds 1023x1023", tile_w, tile_h);
@@ -680,6 +692,8 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   // in place with 16-byte accesses
   MGS_REQUIRE(!seed_info || tile_size == MGS_TILE_SIZE, "isect_tiles: a seed is for tile_size %d, got %d", MGS_TILE_SIZE, tile_size);
   MGS_REQUIRE(!seed_sums || (reinterpret_cast<uintptr_t>(seed_sums) & 15u) == 0, "isect_tiles: seed_sums must be 16-byte aligned");
+  MGS_REQUIRE(!splat_slots || pair_info, "isect_tiles: splat_slots are written with pair_info");
+  MGS_REQUIRE(!splat_slots || (reinterpret_cast<uintptr_t>(splat_slots) & 15u) == 0, "isect_tiles: splat_slots must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   char* w = static_cast<char*>(workspace);
   auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(w + off); };
@@ -733,7 +747,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                          gshift ? u32(ws.id_alt) : reinterpret_cast<uint32_t*>(flatten_ids),                             \
                          gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status,      \
                          order_in_scatter ? tile_group_order : nullptr, sums, reinterpret_cast<int4*>(pair_info),           \
-                         tile_depth_sort_long_list(w + ws.tsort, cap))
+                         tile_depth_sort_long_list(w + ws.tsort, cap), pair_info ? splat_slots : nullptr)
       if (pair_info) MGS_SCATTER(true);
       else MGS_SCATTER(false);
 #undef MGS_SCATTER
@@ -751,7 +765,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                          a_i, tiles_per_gauss);
       if (pair_info)     // training only: the record slots of the backward are the same index-order scan
         hipLaunchKernelGGL(pair_info_kernel, dim3(nblk), dim3(kBlock), 0, s, n, ginfo, tile_h, sums,
-                           reinterpret_cast<int4*>(pair_info));
+                           reinterpret_cast<int4*>(pair_info), splat_slots);
       rc = radix_sort_pairs(n_isect, cap, tile_bits, a_t, a_i, b_t, b_i, w + ws.radix, s);
       if (rc) return rc;
     }

@@ -49,7 +49,7 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
   size_t isect_ws = 0;
   int rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
                            isect_capacity, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, nullptr, &isect_ws, stream);
+                           nullptr, nullptr, nullptr, nullptr, nullptr, &isect_ws, stream);
   if (rc) return rc;
   const FrameWs ws(n, isect_capacity, n_tiles, antialiased != 0, isect_ws);
   if (!workspace) {
@@ -85,7 +85,7 @@ extern "C" int mgs_render_frames(int n, const float* means, const float* quats, 
     size_t iw = ws.isect_bytes;
     rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, depths, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
                          isect_capacity, nullptr, n_isect + c, nullptr, flatten, nullptr, offsets, nullptr, order,
-                         status + c, bin_info, bin_sums, w + ws.isect, &iw, stream);
+                         status + c, bin_info, bin_sums, nullptr, w + ws.isect, &iw, stream);
     if (rc) return rc;
     rc = mgs_rasterize_fwd(n, nullptr, nullptr, nullptr, nullptr, splats, backgrounds ? backgrounds + (size_t)channels * c : nullptr,
                            channels, width, height, tile_w, tile_h, offsets, flatten, order,
@@ -198,7 +198,7 @@ extern "C" int mgs_render_frames_train(int n, const float* means, const float* q
   size_t isect_ws = 0;
   int rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, 0, 1,
                            isect_capacity, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, nullptr, &isect_ws, stream);
+                           nullptr, nullptr, nullptr, nullptr, nullptr, &isect_ws, stream);
   if (rc) return rc;
   const TrainWs ws(n, isect_ws);
   if (!workspace) {
@@ -233,8 +233,8 @@ extern "C" int mgs_render_frames_train(int n, const float* means, const float* q
     size_t iw = isect_ws;
     rc = mgs_isect_tiles(n, nullptr, nullptr, nullptr, F(TF_DEPTHS), nullptr, nullptr, MGS_TILE_SIZE, tile_w, tile_h, c, n_cams,
                          isect_capacity, I(TF_TILES_PER_GAUSS), U(TF_COUNTS), U(TF_TILE_IDS), I(TF_FLATTEN), nullptr,
-                         I(TF_OFFSETS), I(TF_PAIR_INFO), I(TF_ORDER), U(TF_COUNTS) + 1, bin_info, bin_sums, w + ws.isect, &iw,
-                         stream);
+                         I(TF_OFFSETS), I(TF_PAIR_INFO), I(TF_ORDER), U(TF_COUNTS) + 1, bin_info, bin_sums, F(TF_SPLATS),
+                         w + ws.isect, &iw, stream);
     if (rc) return rc;
     rc = mgs_rasterize_fwd(n, nullptr, nullptr, nullptr, nullptr, F(TF_SPLATS),
                            backgrounds ? backgrounds + (size_t)channels * c : nullptr, channels, width, height, tile_w, tile_h,
@@ -311,7 +311,7 @@ extern "C" int mgs_render_frames_backward(int n, const float* means, const float
                                tile_h, I(TF_OFFSETS), I(TF_FLATTEN), alphas + n_px * c, I(TF_LAST_IDS),
                                v_render + n_px * channels * c, v_alphas ? v_alphas + n_px * c : nullptr, ed ? frame : nullptr,
                                I(TF_PAIR_INFO), I(TF_ORDER), isect_capacity, checkpoint_interval ? frame : nullptr,
-                               checkpoint_interval ? F(TF_CKPT) : nullptr, checkpoint_interval, 0, g_m2d, g_abs, g_con, g_feat,
+                               checkpoint_interval ? F(TF_CKPT) : nullptr, checkpoint_interval, MGS_RASTER_BWD_SPLAT_SLOTS, g_m2d, g_abs, g_con, g_feat,
                                g_opac, w + ws.raster, &rw, stream);
     if (rc) return rc;
     rc = mgs_project_color_bwd(n, means, quats, scales, opacities, sh_degree, coeff_stride, sh_coeffs,

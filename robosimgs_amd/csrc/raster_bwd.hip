@@ -228,7 +228,7 @@ __device__ __forceinline__ void raster_bwd_unit(const int unit,
     const int4* __restrict__ pair_info, float* __restrict__ records,
     uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ expected_render,
     const int32_t* __restrict__ tile_order, const float* __restrict__ ckpt, int ckpt_shift,
-    const int32_t* __restrict__ seg_table, const float* __restrict__ render_out) {
+    const int32_t* __restrict__ seg_table, const float* __restrict__ render_out, int splat_slots) {
   constexpr bool WIDE = ABSGRAD || !RECORDS;
   constexpr int NVR = 6 + CHT + (ABSGRAD ? 2 : 0);      // values reduced over the wave per list entry
   constexpr int kRedRows = !RECORDS ? 1 : (NVR > 8 && NVR <= 16) ? NVR : 8;
@@ -453,6 +453,7 @@ __device__ __forceinline__ void raster_bwd_unit(const int unit,
     float2 xy = make_float2(0.f, 0.f);
     float ca = 1.f, cb = 0.f, cc = 1.f, op = 0.f;
     float pf[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t slot_base = 0u, slot_rect = 0u;          // splat_slots: the pair's record slot out of the record itself
     const bool packed = CHT <= 4 && splats != nullptr;
     if (idx <= hi) {
       g = flatten_ids[idx];
@@ -461,6 +462,7 @@ __device__ __forceinline__ void raster_bwd_unit(const int unit,
         xy = make_float2(p0.x, p0.y);
         ca = p0.z; cb = p0.w; cc = p1.x; op = p1.y;
         pf[0] = p1.z; pf[1] = p1.w; pf[2] = p2.x; pf[3] = p2.y;
+        slot_base = __float_as_uint(p2.z); slot_rect = __float_as_uint(p2.w);
       } else {
         xy = reinterpret_cast<const float2*>(means2d)[g];
         ca = conics[3 * (size_t)g + 0];
@@ -489,8 +491,12 @@ __device__ __forceinline__ void raster_bwd_unit(const int unit,
       e.geo1 = make_float4(sB, sC, __uint_as_float(qmask), __int_as_float(idx));
       int gid = g;
       if (RECORDS) {
-        const int4 info = pair_info[g];
-        gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
+        if (packed && splat_slots) {        // (uniform) mgs_isect_tiles left {slot base, x0 | y0 << 10 | w << 20} in the record
+          gid = (int)slot_base + (ty - (int)((slot_rect >> 10) & 1023u)) * (int)(slot_rect >> 20) + (tx - (int)(slot_rect & 1023u));
+        } else {
+          const int4 info = pair_info[g];
+          gid = info.x + (ty - info.z) * (info.w & 0xffff) + (tx - info.y);   // the pair's slot
+        }
       }
       e.geo2 = make_float4(__int_as_float(gid), m_x, m_y, L);
       if constexpr (WIDE) e.geo3[0] = make_float4(ca, cb, cc, 0.f);
@@ -691,10 +697,10 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
     const int4* __restrict__ pair_info, float* __restrict__ records,
     uint8_t* __restrict__ flags, uint32_t capacity, const float* __restrict__ expected_render,
     const int32_t* __restrict__ tile_order, const float* __restrict__ ckpt, int ckpt_shift,
-    const int32_t* __restrict__ seg_table, const float* __restrict__ render_out) {
+    const int32_t* __restrict__ seg_table, const float* __restrict__ render_out, int splat_slots) {
 #define MGS_RB_ARGS means2d, conics, feats, opacities, splats, background, channels, width, height, tile_w, n_tiles, \
     tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, v_means2d, v_means2d_abs, v_conics, v_feats,    \
-    v_opacities, pair_info, records, flags, capacity, expected_render, tile_order, ckpt, ckpt_shift, seg_table, render_out
+    v_opacities, pair_info, records, flags, capacity, expected_render, tile_order, ckpt, ckpt_shift, seg_table, render_out, splat_slots
   int unit = blockIdx.x * MGS_RASTER_BWD_WG_WAVES + (int)(threadIdx.x >> 6);
   if constexpr (SPLIT && MGS_RASTER_BWD_XCD_RUN > 1 && MGS_RASTER_BWD_WG_WAVES == 1) {
     // a tile's whole segments are neighbours in the unit table and re-read the same 10 KB of frame state; workgroup b
@@ -1052,7 +1058,7 @@ extern "C" int mgs_rasterize_bwd(int n, const float* means2d, const float* conic
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities,                 \
                      (const int4*)nullptr, (float*)nullptr, (uint8_t*)nullptr, 0u, (const float*)nullptr, \
-                     (const int32_t*)nullptr, (const float*)nullptr, 0, (const int32_t*)nullptr, (const float*)nullptr)
+                     (const int32_t*)nullptr, (const float*)nullptr, 0, (const int32_t*)nullptr, (const float*)nullptr, 0)
 #define MGS_RB(C) if (v_means2d_abs) MGS_RB_LAUNCH(C, true); else MGS_RB_LAUNCH(C, false)
   if (channels == 1) { MGS_RB(1); }
   else if (channels == 2) { MGS_RB(2); }
@@ -1122,6 +1128,8 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                                   reinterpret_cast<uintptr_t>(render_out)) & 15u) == 0),
               "rasterize_bwd_det: 4-channel frames (v_render, expected_render, render_out) must be 16-byte aligned");
   const bool records_only = (call_flags & MGS_RASTER_BWD_RECORDS_ONLY) != 0;
+  const int splat_slots = (call_flags & MGS_RASTER_BWD_SPLAT_SLOTS) != 0 ? 1 : 0;
+  MGS_REQUIRE(!splat_slots || splats, "rasterize_bwd_det: MGS_RASTER_BWD_SPLAT_SLOTS needs the splat records");
   MGS_REQUIRE((splats || (means2d && conics && feats && opacities)) && tile_offsets && flatten_ids &&
                   alphas && last_ids && v_render && pair_info &&
                   (records_only || (v_means2d && v_conics && v_feats && v_opacities)), "rasterize_bwd_det: null pointer");
@@ -1157,7 +1165,7 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
                      n_tiles, tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,       \
                      (float*)nullptr, info, records, flags, (uint32_t)cap, expected_render,    \
-                     (const int32_t*)order, checkpoints, ckpt_shift, (const int32_t*)seg_table, render_out)
+                     (const int32_t*)order, checkpoints, ckpt_shift, (const int32_t*)seg_table, render_out, splat_slots)
 #define MGS_RD_LAUNCH(C, A)                                                                     \
   if (split) MGS_RD_RASTER(C, A, ((C) <= 4 && !kHalf)); else MGS_RD_RASTER(C, A, false);        \
   if (!records_only) {                                                                          \

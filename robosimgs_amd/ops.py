@@ -119,7 +119,7 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
 class TileLists:
     """Depth-ordered per-tile lists of one camera (device resident, capacity sized)."""
     __slots__ = ("n_isect", "tile_ids", "flatten_ids", "tile_offsets", "tiles_per_gauss",
-                 "isect_ids", "status", "capacity", "pair_info", "group_order")
+                 "isect_ids", "status", "capacity", "pair_info", "group_order", "splat_slots")
 
 
 _workspaces: dict = {}
@@ -140,12 +140,15 @@ def _workspace(nbytes: int, device) -> Tensor:
 def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_id=0, n_cams=1,
                     want_isect_ids=False, want_tiles_per_gauss=True,
                     want_pair_info=False, conics=None, opacities=None, seed=None,
-                    want_tile_ids=True, want_group_order=True) -> TileLists:
+                    want_tile_ids=True, want_group_order=True, splats=None) -> TileLists:
     """conics + opacities given: tile rectangles tightened to the tiles a Gaussian can reach with
     alpha >= 1/255 (shorter lists, bit-identical render); None: gsplat's classic rectangles.
     seed = (seed_info, seed_sums) from project_color_fwd_raw(bin_seed=...): the rectangles come from
     there (means2d / radii / conics / opacities are then not read and may be None; seed_sums is consumed).
-    radii: [N], or planar [2,N] per-axis extents (gsplat >= 1.5's rule)."""
+    radii: [N], or planar [2,N] per-axis extents (gsplat >= 1.5's rule).
+    splats (with want_pair_info): the packed records [N,12] of project_color_fwd_raw; the pairs' record slots are left in
+    their padding words (include/mgs.h: splat_slots) and the lists say so (`splat_slots`): rasterize_bwd_det_raw then
+    gathers nothing but the record."""
     n = depths.shape[0]
     dev = depths.device
     L = _lib.lib()
@@ -168,7 +171,9 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
             tile_w, tile_h, cam_id, n_cams,
             capacity, ptr(out.tiles_per_gauss), ptr(out.n_isect), ptr(out.tile_ids),
             ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.pair_info),
-            ptr(out.group_order), ptr(out.status), ptr(seed[0]) if seed else None, ptr(seed[1]) if seed else None]
+            ptr(out.group_order), ptr(out.status), ptr(seed[0]) if seed else None, ptr(seed[1]) if seed else None,
+            ptr(splats) if (splats is not None and want_pair_info) else None]
+    out.splat_slots = splats is not None and want_pair_info
     check(L.mgs_isect_tiles(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_isect_tiles(size query)")
     ws = _workspace(nbytes.value, dev)
@@ -279,6 +284,7 @@ class TrainState:
         tl.n_isect, tl.status = v["counts"][0:1], v["counts"][1:2]
         tl.tile_ids, tl.flatten_ids, tl.tile_offsets = v["tile_ids"], v["flatten_ids"], v["tile_offsets"]
         tl.tiles_per_gauss, tl.pair_info, tl.group_order, tl.isect_ids = v["tiles_per_gauss"], v["pair_info"], v["group_order"], None
+        tl.splat_slots = True              # mgs_render_frames_train annotates the state's splat records
         return tl
 
 
@@ -460,7 +466,8 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
             ch, width, height, tile_w, tile_h, ptr(tl.tile_offsets), ptr(tl.flatten_ids), ptr(alphas),
             ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(expected_render), ptr(tl.pair_info),
             ptr(getattr(tl, "group_order", None)), tl.capacity,
-            ptr(render_out), ptr(checkpoints), int(checkpoint_interval), int(bool(records_only)),
+            ptr(render_out), ptr(checkpoints), int(checkpoint_interval),
+            int(bool(records_only)) | (2 if (splats is not None and getattr(tl, "splat_slots", False)) else 0),
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det(size query)")

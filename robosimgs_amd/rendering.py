@@ -126,7 +126,7 @@ class _RenderSH(torch.autograd.Function):
                                      want_isect_ids=False, want_tiles_per_gauss=not lean,
                                      want_pair_info=training, want_tile_ids=not lean,
                                      conics=conics if tight else None,
-                                     opacities=opac if tight else None, seed=seed)
+                                     opacities=opac if tight else None, seed=seed, splats=splats if training else None)
             # training: the forward leaves per-pixel checkpoints every `segment` list entries, so that the backward
             # can walk a tile's list as independent segments (include/mgs.h: mgs_rasterize_fwd)
             ckpt = ops.checkpoint_buffer(cap, tile_w, tile_h, ch, segment, dev) if (training and segment) else None

@@ -31,7 +31,9 @@ tkw = dict(conics=con, opacities=t["opacities"]) if TIGHT else {}
 tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, 40_000_000 if n > 2_000_000 else 8_000_000, want_tiles_per_gauss=False, want_pair_info=True, **tkw)
 # the list capacity bench.py gives its frames (it decides which instantiation of the per-tile sort runs)
 CAP = int(os.environ.get("CAP", int(int(tl.n_isect) * 1.25) + 4096))
-tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, CAP, want_tiles_per_gauss=False, want_pair_info=True, **tkw)
+# (SLOTS=0: the raster backward gathers the pairs' record slots from pair_info, as before round 5)
+tl = ops.isect_tiles_raw(m2d, radii, dep, tw, th, CAP, want_tiles_per_gauss=False, want_pair_info=True,
+                         splats=splats if os.environ.get("SLOTS", "1") != "0" else None, **tkw)
 seed = project(lean=True)[-1]
 out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats)
 torch.cuda.synchronize()
