@@ -64,24 +64,68 @@ def decode_png_rgba(data: bytes) -> np.ndarray:
     return rows[:, 1:].reshape(h, w, 4).copy()
 
 
-def encode_npy_gz(a: np.ndarray) -> bytes:
-    """np.save of `a` inside a gzip stream without a time stamp (the bytes depend on the array only)."""
+def encode_npy_gz(a: np.ndarray, level: int = 9) -> bytes:
+    """np.save of `a` inside a gzip stream without a time stamp (the bytes depend on the array and the level only;
+    9 is gzip's default and what the golden files hold)."""
     raw = io.BytesIO()
     np.save(raw, np.ascontiguousarray(a))
     out = io.BytesIO()
-    with gzip.GzipFile(fileobj=out, mode="wb", mtime=0, filename="") as f:
+    with gzip.GzipFile(fileobj=out, mode="wb", mtime=0, filename="", compresslevel=level) as f:
         f.write(raw.getvalue())
     return out.getvalue()
 
 
 class DatasetWriter:
     """`<root>/images/<stem>_%05d.png` (RGBA) and `<root>/depth/<stem>_%05d.npy.gz` ([H,W,1] ray distance): the two
-    directories the reference's load_images / load_depths list and sort."""
+    directories the reference's load_images / load_depths list and sort.
 
-    def __init__(self, root: str, image_dir: str = "images", depth_dir: str = "depth", stem: str = "frame"):
+    The files are zlib streams: at 1080p one frame is ~0.25 s of host time (level 6 PNG + level 9 gzip of the fp32 distance
+    map), i.e. 4 frames/s on one thread behind a renderer that makes 4,300 (INTEGRATION.md has the measured table).
+    workers > 0 encodes and writes on a thread pool (zlib releases the GIL): write() returns as soon as the frame is on
+    the host, flush() / close() wait for the files; at most `max_pending` frames are held in memory.  png_level /
+    gz_level trade file size for time; the defaults give the very bytes of tests/golden/."""
+
+    def __init__(self, root: str, image_dir: str = "images", depth_dir: str = "depth", stem: str = "frame",
+                 workers: int = 0, png_level: int = 6, gz_level: int = 9, max_pending: int = 64):
         self.image_dir, self.depth_dir, self.stem = os.path.join(root, image_dir), os.path.join(root, depth_dir), stem
         os.makedirs(self.image_dir, exist_ok=True)
         os.makedirs(self.depth_dir, exist_ok=True)
+        self.png_level, self.gz_level = int(png_level), int(gz_level)
+        self._pool, self._pending, self._max_pending = None, [], max(1, int(max_pending))
+        if workers and workers > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=int(workers))
+
+    def _put(self, path: str, encode, array) -> None:
+        def job():
+            with open(path, "wb") as f:
+                f.write(encode(array))
+        if self._pool is None:
+            job()
+            return
+        if isinstance(array, np.ndarray):                   # the caller may reuse its buffer before the worker gets to it
+            array = np.array(array, copy=True)
+        while len(self._pending) >= self._max_pending:      # bound the frames held in memory
+            self._pending.pop(0).result()
+        self._pending.append(self._pool.submit(job))
+
+    def flush(self) -> None:
+        """Wait until every frame handed to write() is on disk (re-raises the first failure)."""
+        while self._pending:
+            self._pending.pop(0).result()
+
+    def close(self) -> None:
+        self.flush()
+        if self._pool is not None:
+            self._pool.shutdown()
+            self._pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def paths(self, index: int) -> Tuple[str, str]:
         name = f"{self.stem}_{int(index):05d}"
@@ -91,8 +135,10 @@ class DatasetWriter:
         """rgba: uint8 [H,W,4]; distance: [H,W] or [H,W,1] float32 / float64 (None: image only).  Tensors are
         copied to the host first."""
         img_path, dep_path = self.paths(index)
-        with open(img_path, "wb") as f:
-            f.write(encode_png_rgba(_to_numpy(rgba)))
+        a = _to_numpy(rgba)
+        if a.ndim != 3 or a.shape[2] != 4:
+            raise ValueError(f"expected uint8 [H,W,4], got {a.shape}")
+        self._put(img_path, lambda x: encode_png_rgba(x, self.png_level), a)
         if distance is None:
             return img_path, None
         d = _to_numpy(distance)
@@ -100,8 +146,7 @@ class DatasetWriter:
             d = d[:, :, None]
         if d.ndim != 3 or d.shape[2] != 1:
             raise ValueError(f"distance must be [H,W] or [H,W,1], got {d.shape}")
-        with open(dep_path, "wb") as f:
-            f.write(encode_npy_gz(d))
+        self._put(dep_path, lambda x: encode_npy_gz(x, self.gz_level), d)
         return img_path, dep_path
 
 
@@ -119,7 +164,7 @@ def read_dataset_frame(img_path: str, dep_path: Optional[str] = None):
 def _to_numpy(x) -> np.ndarray:
     if isinstance(x, np.ndarray):
         return x
-    return x.detach().cpu().numpy()          # a torch tensor
+    return x.detach().cpu().numpy()          # a torch tensor: a fresh host copy (safe to encode later on a worker thread)
 
 
 def unnormalize_points(points: np.ndarray, transform: np.ndarray, scale: float) -> np.ndarray:

@@ -129,7 +129,10 @@ class _RenderSH(torch.autograd.Function):
                                      opacities=opac if tight else None, seed=seed, splats=splats if training else None)
             # training: the forward leaves per-pixel checkpoints every `segment` list entries, so that the backward
             # can walk a tile's list as independent segments (include/mgs.h: mgs_rasterize_fwd)
-            ckpt = ops.checkpoint_buffer(cap, tile_w, tile_h, ch, segment, dev) if (training and segment) else None
+            # (without a fixed capacity `cap` is the loose bound read back above -- several times the lists: the checkpoints
+            #  are then sized by the count the binning has just written, one more read-back on a path that reads back anyway)
+            ckpt_cap = cap if isect_capacity is not None else min(cap, int(tl.n_isect.item()) + 1)
+            ckpt = ops.checkpoint_buffer(ckpt_cap, tile_w, tile_h, ch, segment, dev) if (training and segment) else None
             ops.rasterize_fwd_raw(means2d, conics, feats, opac,
                                   backgrounds[c] if backgrounds is not None else None, width,
                                   height, tile_w, tile_h, tl.tile_offsets, tl.flatten_ids,

@@ -10,7 +10,7 @@ two Gaussians that tie in depth to the last bit is blended first.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict, Iterable, Optional
 
 import torch
 
@@ -19,20 +19,45 @@ from .pipeline import locality_order
 
 @torch.no_grad()
 def reorder_parameters(params: Dict[str, torch.Tensor], optimizer: Optional[torch.optim.Optimizer] = None,
-                       key: str = "means", bits: int = 10) -> torch.Tensor:
-    """Permute every tensor of `params` whose first dimension is the Gaussian count into Morton order of params[key], in
-    place (the tensors stay the same objects, so an optimiser keeps its references), together with the per-parameter
-    state tensors of `optimizer` that have that first dimension (Adam's exp_avg / exp_avg_sq ...).  Returns the
-    permutation (new position -> old index)."""
+                       key: str = "means", bits: int = 10, per_gaussian: Optional[Iterable[str]] = None,
+                       extra_state: Iterable[torch.Tensor] = ()) -> torch.Tensor:
+    """Permute the per-Gaussian tensors of `params` into Morton order of params[key], in place (the tensors stay the same
+    objects, so an optimiser keeps its references), together with the per-parameter state tensors of `optimizer` that
+    have the Gaussian count as their first dimension (Adam's exp_avg / exp_avg_sq ...).  Returns the permutation (new
+    position -> old index).
+
+    per_gaussian: the keys of `params` that are per-Gaussian (first dimension = the Gaussian count).  None (default)
+    takes every tensor whose first dimension equals the count -- a heuristic that also catches an unrelated parameter which
+    happens to have N rows, so name the keys where that can be.  A tensor object listed under two keys is permuted once.
+    extra_state: further per-Gaussian tensors that must follow -- a densification strategy's accumulators (gsplat's
+    `grad2d`, `count`, `radii` ...), anything indexed like the Gaussians that lives outside `params` and the optimiser.
+    Whatever is NOT handed over keeps the old order and no longer matches: permute it with the returned `order`."""
     n = params[key].shape[0]
     order = locality_order(params[key], bits)
-    for p in params.values():
-        if torch.is_tensor(p) and p.dim() >= 1 and p.shape[0] == n:
-            p.data.copy_(p.data.index_select(0, order))
-            if p.grad is not None:
-                p.grad.copy_(p.grad.index_select(0, order))
-            if optimizer is not None and p in optimizer.state:
-                for name, st in optimizer.state[p].items():
-                    if torch.is_tensor(st) and st.dim() >= 1 and st.shape[0] == n:
-                        st.copy_(st.index_select(0, order))
+    keys = list(per_gaussian) if per_gaussian is not None else [k for k, p in params.items()
+                                                                  if torch.is_tensor(p) and p.dim() >= 1 and p.shape[0] == n]
+    seen = set()                                   # (by storage: the same tensor under two keys is permuted once)
+
+    def permute(t_):
+        if not torch.is_tensor(t_) or (t_.data_ptr(), t_.device) in seen:
+            return
+        if t_.dim() < 1 or t_.shape[0] != n:
+            raise ValueError(f"a tensor of shape {tuple(t_.shape)} is not per-Gaussian (first dimension {n})")
+        seen.add((t_.data_ptr(), t_.device))
+        t_.copy_(t_.index_select(0, order.to(t_.device)))
+
+    for k in keys:
+        p = params[k]
+        first = (p.data_ptr(), p.device) not in seen
+        permute(p.data)
+        if not first:
+            continue
+        if p.grad is not None:
+            permute(p.grad)
+        if optimizer is not None and p in optimizer.state:
+            for st in optimizer.state[p].values():
+                if torch.is_tensor(st) and st.dim() >= 1 and st.shape[0] == n:
+                    permute(st)
+    for t_ in extra_state:
+        permute(t_)
     return order

@@ -69,3 +69,25 @@ def test_unnormalize_points_is_load_ns_point_cloud_algebra():
     cam = np.load(os.path.join(HERE, "golden", "camera_reference.npz"))
     got = unnormalize_points(cam["dp_points_ns"], cam["dp_transform"], float(cam["dp_scale"]))
     assert np.allclose(got, cam["dp_points_world"], rtol=1e-13, atol=1e-13)
+
+
+def test_writer_with_a_thread_pool_writes_the_same_files(tmp_path):
+    """DatasetWriter(workers=4): encoding and writing on a pool changes when the files appear, not a byte of them."""
+    from robosimgs_amd.dataset import DatasetWriter
+    rng = np.random.default_rng(3)
+    frames = [(rng.integers(0, 256, size=(48, 64, 4), dtype=np.uint8), rng.random((48, 64, 1)).astype(np.float32) * 9) for _ in range(9)]
+    a = DatasetWriter(str(tmp_path / "sync"))
+    with DatasetWriter(str(tmp_path / "pool"), workers=4, max_pending=3) as b:
+        for i, (rgba, dist) in enumerate(frames):
+            pa = a.write(i, rgba, dist)
+            buf = rgba.copy()
+            pb = b.write(i, buf, dist)
+            buf[:] = 0                                   # the caller's buffer is its own again at once
+    for i in range(len(frames)):
+        for x, y in zip(a.paths(i), b.paths(i)):
+            assert open(x, "rb").read() == open(y, "rb").read()
+    fast = DatasetWriter(str(tmp_path / "fast"), png_level=1, gz_level=1)
+    p_img, p_dep = fast.write(0, *frames[0])
+    from robosimgs_amd.dataset import read_dataset_frame
+    rgba, dist = read_dataset_frame(p_img, p_dep)
+    assert np.array_equal(rgba, frames[0][0]) and np.array_equal(dist, frames[0][1][:, :, 0])
