@@ -842,7 +842,7 @@ def pmc_valu(kernel_name, standard_workload, stage_prefix="raster_inf", floor=No
                 "note": "the floor is the blend loop's mix; fetch, cull and queue instructions are mostly of the cheaper "
                         "class, so a kernel at the bound can read slightly above 1",
                 "source": "rocprofv3 --pmc SQ_INSTS_VALU, GRBM_GUI_ACTIVE in the run that took `traffic` "
-                          "(profiles/pmc_traffic.json, profiles/r4/06_pmc_counters.md); floor: "
+                          "(profiles/pmc_traffic.json, profiles/r5/06_pmc_counters.md); floor: "
                           "scripts/ubench/valu_issue.hip"}
     except Exception:
         return None

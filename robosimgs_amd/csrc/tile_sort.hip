@@ -38,6 +38,10 @@ constexpr int buckets_for(int) { return 1024; }   // (256 for the short-list var
                                                   //  bucket make the wave's rank loop as long as its fullest bucket: 22.6 M VALU against 21.8 M)
 constexpr int log2i(int v) { return v <= 1 ? 0 : 1 + log2i(v >> 1); }
 constexpr int kSmall = 48;          // buckets up to this size are finished by rank counting
+#ifndef MGS_TSORT_SMALL_LONG
+#define MGS_TSORT_SMALL_LONG 256
+#endif
+constexpr int kSmallLong = MGS_TSORT_SMALL_LONG;   // ... in the kernel of the long lists (sort_one_tile)
 constexpr int kStack = 96;          // pending heavy buckets; beyond it a bucket is rank-counted whatever its size
 #ifndef MGS_TSORT_STOP
 #define MGS_TSORT_STOP 0      // measurement only: leave the kernel after phase 1..4 (filter / keys / scan / scatter)
@@ -101,6 +105,11 @@ __device__ __forceinline__ void sort_one_tile(
     uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out,
     uint32_t* __restrict__ long_list) {
   constexpr int kBuckets = buckets_for(kFast), kDigitBits = log2i(kBuckets);
+  // buckets up to kSm entries are finished by rank counting.  The long lists' kernel takes far larger ones: its candidates
+  // come out of LDS (the fast path's list, the generic path's windows), and every bucket it does NOT rank is one more
+  // level taken by the whole 1024-thread workgroup, one bucket after the other -- a clustered scene's 31 k-entry list
+  // had dozens of buckets of 50-500 near-identical depths
+  constexpr int kSm = LONG ? kSmallLong : kSmall;
   __shared__ uint32_t cnt[kBuckets];
   __shared__ uint32_t cur[kBuckets];
   __shared__ unsigned long long red_min[kTS / 64], red_max[kTS / 64];
@@ -272,7 +281,7 @@ __device__ __forceinline__ void sort_one_tile(
 #pragma unroll
       for (int k = 0; k < kBuckets / kTS; ++k) {
         c4[k] = cnt[tid * (kBuckets / kTS) + k];
-        packed += c4[k] + (c4[k] > (uint32_t)kSmall ? 0x10000u : 0u);
+        packed += c4[k] + (c4[k] > (uint32_t)kSm ? 0x10000u : 0u);
       }
       uint32_t tot;
       uint32_t exp = block_scan_excl<kTS>(packed, wave_sums, &tot);
@@ -282,7 +291,7 @@ __device__ __forceinline__ void sort_one_tile(
       for (int k = 0; k < kBuckets / kTS; ++k) {
         const int d = tid * (kBuckets / kTS) + k;
         cur[d] = ex;
-        if (c4[k] > (uint32_t)kSmall) {            // the generic loop below takes it from buffer 1
+        if (c4[k] > (uint32_t)kSm) {            // the generic loop below takes it from buffer 1
           if ((int)hx < kStack) {
             stack_lo[hx] = s + (int)ex; stack_hi[hx] = s + (int)(ex + c4[k]); stack_src[hx] = 1;
           } else {
@@ -320,7 +329,7 @@ __device__ __forceinline__ void sort_one_tile(
         const unsigned d = digit(k, id);
         const uint32_t craw = cnt[d];
         const uint32_t b = craw & ~kBrute;
-        if (b > (uint32_t)kSmall && !(craw & kBrute)) {   // heavy: hand it to the generic loop
+        if (b > (uint32_t)kSm && !(craw & kBrute)) {   // heavy: hand it to the generic loop
           key1[s + i] = k;
           id1[s + i] = id;
         } else {
@@ -411,7 +420,7 @@ __device__ __forceinline__ void sort_one_tile(
     uint32_t* di = src ? id0 : id1;
     const int m = hi - lo;
 
-    if (m <= kSmall) {                             // whole segment by rank counting
+    if (m <= kSm) {                             // whole segment by rank counting
       for (int i = lo + tid; i < hi; i += kTS) {
         const uint32_t k = sk[i], id = si[i];
         int c = 0;
@@ -485,7 +494,7 @@ __device__ __forceinline__ void sort_one_tile(
       for (int k = 0; k < kBuckets / kTS; ++k) {
         c4[k] = cnt[tid * (kBuckets / kTS) + k];
         sum += c4[k];
-        heavy += c4[k] > (uint32_t)kSmall ? 1u : 0u;
+        heavy += c4[k] > (uint32_t)kSm ? 1u : 0u;
       }
       uint32_t tot, htot;
       uint32_t ex = block_scan_excl<kTS>(sum, wave_sums, &tot);
@@ -495,7 +504,7 @@ __device__ __forceinline__ void sort_one_tile(
       for (int k = 0; k < kBuckets / kTS; ++k) {
         const int d = tid * (kBuckets / kTS) + k;
         cur[d] = ex;
-        if (c4[k] > (uint32_t)kSmall) {
+        if (c4[k] > (uint32_t)kSm) {
           const int slot = base + (int)hx;
           if (slot < kStack) {
             stack_lo[slot] = lo + (int)ex; stack_hi[slot] = lo + (int)(ex + c4[k]); stack_src[slot] = (uint8_t)(src ^ 1);
@@ -529,12 +538,12 @@ __device__ __forceinline__ void sort_one_tile(
     __syncthreads();                               // the scattered segment is visible to the workgroup
 
     // cur[d] is now the END of bucket d: every element of a light bucket ranks itself inside it.  The scattered
-    // segment goes through the LDS list in windows of kFast - 2 kSmall entries with kSmall more on either side (a light
-    // bucket holds at most kSmall entries, so the whole bucket of every element of the window is in LDS): one coalesced
+    // segment goes through the LDS list in windows of kFast - 2 kSm entries with kSm more on either side (a light
+    // bucket holds at most kSm entries, so the whole bucket of every element of the window is in LDS): one coalesced
     // load per entry instead of a dependent global load per CANDIDATE -- a 31 k-entry list has ~30 of them per element.
-    constexpr int kWin = kFast - 2 * kSmall;
+    constexpr int kWin = kFast - 2 * kSm;
     for (int w0 = lo; w0 < hi; w0 += kWin) {
-      const int wa = max(lo, w0 - kSmall), wb = min(hi, w0 + kWin + kSmall), we = min(hi, w0 + kWin);
+      const int wa = max(lo, w0 - kSm), wb = min(hi, w0 + kWin + kSm), we = min(hi, w0 + kWin);
       for (int i = wa + tid; i < wb; i += kTS) lc[i - wa] = ((unsigned long long)dk[i] << 32) | di[i];
       __syncthreads();
       for (int i = w0 + tid; i < we; i += kTS) {
@@ -543,10 +552,10 @@ __device__ __forceinline__ void sort_one_tile(
         const unsigned d = digit(k, id);
         const uint32_t craw = cnt[d];
         const uint32_t b = craw & ~kBrute;
-        if (b > (uint32_t)kSmall && !(craw & kBrute)) continue;     // on the stack
+        if (b > (uint32_t)kSm && !(craw & kBrute)) continue;     // on the stack
         const int be = lo + (int)cur[d], bs = be - (int)b;
         int c = 0;
-        if (b <= (uint32_t)kSmall) {
+        if (b <= (uint32_t)kSm) {
           for (int j = bs; j < be; ++j) c += lc[j - wa] < me ? 1 : 0;
         } else {                                                    // past the stack's room: any size, out of global memory
           for (int j = bs; j < be; ++j) c += comp_less(dk[j], di[j], k, id) ? 1 : 0;

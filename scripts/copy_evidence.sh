@@ -1,7 +1,7 @@
 #!/bin/bash
 # After `gpurun -- bash scripts/refresh_evidence.sh`: copy what profiles/ quotes from gpurun_out/refresh/ (run from anywhere).
 cd "$(dirname "$0")/.." || exit 1
-R=gpurun_out/refresh; P=profiles/r4
+R=gpurun_out/refresh; P=profiles/r5
 cp $R/refresh_default_line.json $P/03_bench_line.json
 cp $R/refresh_default_stats.md $P/03_kernel_stats_default_3_in_flight.md
 cp $R/bench_no_profiler.json $P/03b_bench_line_no_profiler.json

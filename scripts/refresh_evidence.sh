@@ -8,10 +8,10 @@ cd $REPO
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 bash scripts/pmc_traffic.sh > $OUT/pmc_traffic_stdout.txt 2>&1
-cp gpurun_out/pmc_r4/pmc_traffic.json profiles/pmc_traffic.json     # so that the bench lines below carry `traffic`
-cp gpurun_out/pmc_r4/pmc_traffic.json $OUT/pmc_traffic.json
+cp gpurun_out/pmc_r5/pmc_traffic.json profiles/pmc_traffic.json     # so that the bench lines below carry `traffic`
+cp gpurun_out/pmc_r5/pmc_traffic.json $OUT/pmc_traffic.json
 python scripts/summarize_pmc.py > $OUT/pmc_summary_stdout.txt 2>&1
-cp profiles/r4/06_pmc_counters.md $OUT/06_pmc_counters.md
+cp profiles/r5/06_pmc_counters.md $OUT/06_pmc_counters.md
 python bench.py > $OUT/bench_no_profiler.json 2> $OUT/bench_no_profiler.err
 bash scripts/profile_bench.sh refresh_default
 bash scripts/profile_bench.sh refresh_inflight1 --inflight 1 --no-cpu-baseline --no-stress

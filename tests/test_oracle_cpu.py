@@ -4,6 +4,7 @@ import math
 import os
 
 import numpy as np
+import pytest
 
 from oracle import cpu_ref
 from oracle import gs_oracle_np as O
@@ -188,3 +189,36 @@ def test_gradient_budget_covers_real_flips_and_rejects_rows_the_old_gate_let_thr
         compare(name + " (old gate)", bad, r, row_tol=2e-3, bad_frac=1e-2, cos_min=0.9, touched=touched, verbose=False)
         with pytest.raises(AssertionError, match="flip budget"):
             compare(name + " (new gate)", bad, r, row_tol=2e-3, bad_frac=1e-2, cos_min=0.9, budget=b, verbose=False)
+
+
+def test_heavy_tailed_scene_generator_and_the_fp32_restatement_gate():
+    """synthetic_scene_heavy_tailed (NOT a BASELINE config): deterministic, shaped as documented, and -- at a size the port
+    finishes in seconds -- ill-conditioned for fp32 the way the full-size GPU test relies on: the port's float
+    instantiation is pixels away from its fp64 one where check_frame finds no near-flip decision, and
+    check_frame_against_fp32_port accepts a frame that is as close as that restatement and rejects one that is farther."""
+    import math
+    from robosimgs_amd import synthetic_scene_heavy_tailed, camera_ring
+    n = 60_000
+    g = synthetic_scene_heavy_tailed(n, math.log(0.02), 1, 3, n_needles=1500, n_screen_filling=3)
+    g2 = synthetic_scene_heavy_tailed(n, math.log(0.02), 1, 3, n_needles=1500, n_screen_filling=3)
+    assert np.array_equal(g.means, g2.means) and np.array_equal(g.log_scales, g2.log_scales) and len(g) == n
+    s = np.sort(g.scales, axis=1)
+    assert (s[-1503:-3, 2] / s[-1503:-3, 0]).min() >= 99.0                       # the needles: 100-400 : 1
+    assert g.scales[-3:].min() >= 1.5 and g.opacities[-3:].max() <= 0.2          # the screen-filling ones: large and faint
+    assert np.std(g.log_scales[:-1503].mean(axis=1)) > 1.0                       # heavy-tailed extents (SURVEY 8(d): 0.4 / sqrt 3)
+    with pytest.raises(ValueError):
+        synthetic_scene_heavy_tailed(100)
+    W, H = 480, 272
+    cam = camera_ring(1, W, H, thetas=[0.3])[0]
+    vm32, K32 = np.asarray(cam.viewmat(), np.float32), np.asarray(cam.K, np.float32)
+    ref, ra, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vm32, K32, W, H, 1, with_depth=True,
+                                       flip_eps=O.EPS_PATH)
+    r32, a32, i32 = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vm32, K32, W, H, 1, with_depth=True)
+    assert i32["n_vis"] > 0.3 * n and info["n_isect"] > 2 * i32["n_vis"]
+    st = O.check_frame_against_fp32_port(r32, a32, ref, ra, r32, a32, info["margins"], O.EPS_PATH, info["edge_mask"], what="fp32 port vs itself")
+    assert st["over_tol"] == st["over_tol_fp32_port"]
+    print(f"\nheavy-tailed scene at {n} Gaussians, {W}x{H}: fp32 port vs fp64 port {st}")
+    worse = r32.copy()
+    worse[::7, ::5, 0] += 3e-4                                                    # a frame that is farther off than the restatement
+    with pytest.raises(AssertionError):
+        O.check_frame_against_fp32_port(worse, a32, ref, ra, r32, a32, info["margins"], O.EPS_PATH, info["edge_mask"], what="corrupted")
