@@ -14,7 +14,7 @@ cp $R/pytest_gpu.txt $P/08_pytest_gpu.txt
 cp $R/bwd_timeline_0.txt $P/11_bwd_timeline_whole_list.txt
 cp $R/bwd_timeline_256.txt $P/11_bwd_timeline_segments_256.txt
 cp $R/bwd_split_ab.txt $P/12_bwd_split_ab.txt
-cp $R/ab_close_branch.txt $P/13_ab_close_branch.txt
+cp $R/pmc_bwd_matrix.md $P/06b_pmc_backward_traffic_by_order_and_walk_after_splat_slots.md
 cp $R/pmc_traffic.json profiles/pmc_traffic.json
 python -c "
 import json; from robosimgs_amd.csrc import build as B

@@ -8,6 +8,7 @@ cd $REPO
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $OUT/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1
 bash scripts/pmc_traffic.sh > $OUT/pmc_traffic_stdout.txt 2>&1
+bash scripts/pmc_bwd_matrix.sh > $OUT/pmc_bwd_matrix.md 2>&1
 cp gpurun_out/pmc_r5/pmc_traffic.json profiles/pmc_traffic.json     # so that the bench lines below carry `traffic`
 cp gpurun_out/pmc_r5/pmc_traffic.json $OUT/pmc_traffic.json
 python scripts/summarize_pmc.py > $OUT/pmc_summary_stdout.txt 2>&1
@@ -22,5 +23,4 @@ MGS_RASTER_BWD_FLAGS="-DMGS_RASTER_BWD_TIMING" python robosimgs_amd/csrc/build.p
 for s in 0 256; do MGS_RASTER_BWD_FLAGS="-DMGS_RASTER_BWD_TIMING" SEG=$s timeout 300 python scripts/dbg/bwd_timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/bwd_timeline_$s.txt; done
 python robosimgs_amd/csrc/build.py > /dev/null 2>&1
 SEGS=128,256 timeout 300 python scripts/raster_bwd_split_ab.py 2>&1 | grep segment > $OUT/bwd_split_ab.txt
-timeout 600 python scripts/ab_builds.py raster_fwd.hip "-DMGS_RASTER_CLOSE_BRANCH=1" 2>&1 | grep -v amdgpu.ids | tail -3 > $OUT/ab_close_branch.txt
 cat $OUT/pytest_gpu.txt; tail -3 $OUT/smoke.txt; cat $OUT/bwd_split_ab.txt
