@@ -38,6 +38,10 @@ seed = project(lean=True)[-1]
 out = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl.tile_offsets, tl.flatten_ids, splats=splats)
 torch.cuda.synchronize()
 print("n_isect", int(tl.n_isect))
+if os.environ.get("STATS"):
+    ln = (tl.tile_offsets[1:] - tl.tile_offsets[:-1]).float()
+    print("list length: mean %.0f median %.0f p99 %.0f max %d; tiles over 2048: %d, over 8192: %d, over 16384: %d" % (
+        float(ln.mean()), float(ln.median()), float(torch.quantile(ln, 0.99)), int(ln.max()), int((ln > 2048).sum()), int((ln > 8192).sum()), int((ln > 16384).sum())))
 vr = torch.rand(H, W, CH, device=dev); va = torch.rand(H, W, device=dev)
 for _ in range(reps):
     if stage == "raster":
