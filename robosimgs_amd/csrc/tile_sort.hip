@@ -30,8 +30,8 @@ constexpr int kTSMain = 256;        // threads per tile
 // Lists longer than the main kernel's LDS list (kFast entries) are not walked by its 256 threads through global scratch
 // -- 540 us for ONE tile of 31 k entries on a clustered scene, the tail of the whole binning stage -- but handed to a
 // second launch of a few large workgroups: 1024 threads, an LDS list of kFastXL entries, the same algorithm.  The main
-// kernel appends such tiles to a list; on scenes without them (SURVEY 8(d)'s: longest list 1.5 k) the second launch reads
-// a zero and leaves.
+// kernel appends such tiles to a list.  The second launch costs 4.6 us even when the list is empty, so it exists only where
+// the capacity says lists are long (tile_depth_sort below).
 constexpr int kTSLong = 1024, kFastXL = 8192, kLongGrid = 256;
 // buckets of one MSD level
 constexpr int buckets_for(int) { return 1024; }   // (256 for the short-list variant: fewer counters to zero / scan, but ~2 entries per
@@ -97,8 +97,9 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_s
 // of `staging` (entry = id | tile's place in the group << (32 - shift), any order).  The tile's workgroup reads
 // its group's segment (the 2^shift workgroups of a group run side by side: L2 hits), keeps its own entries and
 // counts those of the group's earlier tiles -- which is where its list starts; it stores that offset too.
-// LONG: the second launch (lists over the main kernel's kFast); otherwise such a tile is appended to long_list and left
-template <bool GROUPED, int kFast, int kTS, bool LONG>
+// LONG: the second launch (lists over the main kernel's kFast).  DEFER (main kernel): such a tile is appended to long_list and
+// left to that launch; without it the main kernel walks the list itself through global scratch (the generic path below).
+template <bool GROUPED, int kFast, int kTS, bool LONG, bool DEFER = true>
 __device__ __forceinline__ void sort_one_tile(
     const int tile, int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
     uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
@@ -181,7 +182,7 @@ __device__ __forceinline__ void sort_one_tile(
   } else {
     s = offsets[tile]; e = offsets[tile + 1];
   }
-  if (!LONG && e - s > kFast) {      // (uniform) a long list: the second launch sorts it (its tile ids are filled here)
+  if (!LONG && DEFER && e - s > kFast) {      // (uniform) a long list: the second launch sorts it (its tile ids are filled here)
     if (tile_ids)
       for (int i = s + tid; i < e; i += kTS) tile_ids[i] = (uint32_t)tile;
     if (tid == 0) long_list[1 + atomicAdd(long_list, 1u)] = (uint32_t)tile;
@@ -567,7 +568,7 @@ __device__ __forceinline__ void sort_one_tile(
   }
 }
 
-template <bool GROUPED, int kFast>
+template <bool GROUPED, int kFast, bool DEFER>
 __global__ __launch_bounds__(kTSMain) void tile_depth_sort_kernel(
     int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
     uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
@@ -584,8 +585,8 @@ __global__ __launch_bounds__(kTSMain) void tile_depth_sort_kernel(
     tile = ((blockIdx.x / (8 * G)) * 8 + (r & 7)) * G + (r >> 3);
   }
   if (tile >= n_tiles) return;
-  sort_one_tile<GROUPED, kFast, kTSMain, false>(tile, n_tiles, offsets, depths, ids_final, tile_ids, key0, id0, key1, id1, staging,
-                                                shift, offsets_out, long_list);
+  sort_one_tile<GROUPED, kFast, kTSMain, false, DEFER>(tile, n_tiles, offsets, depths, ids_final, tile_ids, key0, id0, key1, id1,
+                                                       staging, shift, offsets_out, long_list);
 }
 
 // The second launch: the tiles the main kernel listed (long_list[0] of them), one at a time per workgroup.
@@ -624,27 +625,35 @@ int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depth
   const size_t stride = align_up((size_t)(capacity ? capacity : 1) * sizeof(uint32_t), 256) / sizeof(uint32_t);
   uint32_t* t = static_cast<uint32_t*>(temp);
   uint32_t* long_list = tile_depth_sort_long_list(temp, capacity);
-  if (!long_list_zeroed) {
+  if (!long_list_zeroed) {       // (only the two-launch form reads the counter; four bytes)
     hipError_t e = hipMemsetAsync(long_list, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return set_error((int)e, "tile_depth_sort: memset: %s", hipGetErrorString(e));
   }
-  // average list length the capacity allows: short lists -> the fast path with the smaller LDS list
+  // average list length the capacity allows: short lists -> the fast path with the smaller LDS list, and NO second launch:
+  // where the capacity leaves 640 entries per tile on average a list over 1,024 entries is the rare exception and takes the
+  // main kernel's generic path, while the launch of 256 empty 1,024-thread workgroups would cost every frame 4.6 us
+  // (bench.py's headline: 4,313 against 4,345 frames/s).  Scenes whose capacity says lists are long get both launches.
+#ifdef MGS_TSORT_FORCE_LONG     // measurement (scripts/ab_builds.py): the two-launch form whatever the capacity says
+  const bool short_lists = false;
+#else
   const bool short_lists = (size_t)capacity <= (size_t)n_tiles * 640;
+#endif
   // (GROUPED launches are padded to whole blocks of 8 groups: the kernel's XCD-aware tile numbering)
   const int per = 8 << group_shift, n_wg = staging ? (n_tiles + per - 1) / per * per : n_tiles;
-#define MGS_TS_LAUNCH(G, F, OFFS, STG, SH, OUT)                                                              \
-  hipLaunchKernelGGL((tile_depth_sort_kernel<G, F>), dim3(n_wg), dim3(kTSMain), 0, stream, n_tiles, OFFS,   \
+#define MGS_TS_LAUNCH(G, F, D, OFFS, STG, SH, OUT)                                                              \
+  hipLaunchKernelGGL((tile_depth_sort_kernel<G, F, D>), dim3(n_wg), dim3(kTSMain), 0, stream, n_tiles, OFFS,   \
                      depths, flatten_ids, tile_ids_fill, t, t + stride, t + 2 * stride, t + 3 * stride,    \
                      STG, SH, OUT, long_list)
   if (staging) {
-    if (short_lists) MGS_TS_LAUNCH(true, kFastShort, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
-    else MGS_TS_LAUNCH(true, kFastLong, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
+    if (short_lists) MGS_TS_LAUNCH(true, kFastShort, false, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
+    else MGS_TS_LAUNCH(true, kFastLong, true, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
   } else {
-    if (short_lists) MGS_TS_LAUNCH(false, kFastShort, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
-    else MGS_TS_LAUNCH(false, kFastLong, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
+    if (short_lists) MGS_TS_LAUNCH(false, kFastShort, false, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
+    else MGS_TS_LAUNCH(false, kFastLong, true, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
   }
 #undef MGS_TS_LAUNCH
-  // the lists over kFast entries (none on SURVEY 8(d)'s scenes: the workgroups read a zero and leave)
+  if (short_lists) return check_launch("tile_depth_sort");
+  // the lists over kFast entries, listed by the main kernel
   const int n_long_wg = n_tiles < kLongGrid ? n_tiles : kLongGrid;
   if (staging)
     hipLaunchKernelGGL((tile_depth_sort_long_kernel<true>), dim3(n_long_wg), dim3(kTSLong), 0, stream, n_tiles, group_offsets, depths,
