@@ -511,7 +511,7 @@ def main():
         g_regions, _ = time_frames(g_mode)
         a.min_seconds = keep
         given_order = float(np.median(g_regions))
-        status_given = max(int(s_["meta"]["isect_status"].max().item()) for s_ in fr._slots)
+        status_given = fr.isect_status_max()
         assert status_given == 0
         del fr
         fr = fr_main
@@ -535,7 +535,7 @@ def main():
                 r_regions, _ = time_frames(g_mode)
                 rates[k].append(a.steps / float(np.median(r_regions)))
         a.min_seconds = keep
-        assert max(int(s_["meta"]["isect_status"].max().item()) for f_ in pair.values() for s_ in f_._slots) == 0
+        assert max(f_.isect_status_max() for f_ in pair.values()) == 0
         rule_leg = {"frames_per_s": round(max(rates["opacity_aware"]), 2),
                     "frames_per_s_classic_rule_same_harness": round(max(rates["classic"]), 2),
                     "n_isect": max(int(s_["meta"]["n_isects"].max().item()) for s_ in pair["opacity_aware"]._slots),
@@ -556,8 +556,7 @@ def main():
         fr.release(tk)
         torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / 20 * 1e3
-    outs = [(None, None, s["meta"]) for s in fr._slots]
-    status = max(int(o[2]["isect_status"].max().item()) for o in outs)
+    status = fr.isect_status_max()
     assert status == 0, "tile-intersection capacity overflow inside the timed region"
     total_frames = (RING if ring else 1) * a.steps     # all ranks together, per region
     frames_per_s = total_frames / elapsed
@@ -1079,7 +1078,7 @@ def stress_4k(dev, deg, n_fl, frames=20):
         fr.release(tk)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (3 * frames)
-    status = max(int(s_["meta"]["isect_status"].max().item()) for s_ in fr._slots)
+    status = fr.isect_status_max()
     return {"workload": f"configs[4]: {n} Gaussians, SH degree {deg}, {W}x{H} forward render ({MODE}), theta = 0.3",
             "n_visible": n_vis, "n_isect": n_isect, "n_isect_binned": n_binned, "tiles": n_tiles,
             "list_length_mean": round(lmean, 1), "list_length_max": lmax, "stages": stages,
@@ -1176,7 +1175,7 @@ def heavy_tailed_leg(a, dev, deg, n_fl, frames=20):
         fr.release(tk)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (5 * frames)
-    status = max(int(s_["meta"]["isect_status"].max().item()) for s_ in fr._slots)
+    status = fr.isect_status_max()
     step = bench_fwd_bwd(a, t, vm[None], K[None], W, H, deg, cap, dev)
     return {"workload": f"NOT a BASELINE config: {n} Gaussians, heavy-tailed synthetic scene (synthetic_scene_heavy_tailed, seed 0), SH degree "
                         f"{deg}, {W}x{H} ({MODE}), theta = 0.3",

@@ -157,7 +157,11 @@ class FrameRenderer:
             if dataset_output not in (torch.float16, torch.float32, torch.float64):
                 raise ValueError("dataset_output must be torch.float16, torch.float32 or torch.float64")
             self.dataset_K = np.asarray(dataset_K, dtype=np.float64).reshape(3, 3)
-        # several frames in flight: total work matters, not one launch's duration (rendering.py)
+        # several frames in flight: total work matters, not one launch's duration (rendering.py) -- but a frame that is
+        # submitted while NO other frame is in flight (a synchronous render(), the first frame of a burst) has the GPU to
+        # itself and takes the other schedule: every slot holds both graphs (one memory pool), submit() picks.  The two
+        # schedules give the same pixels bit for bit.  A caller who names a raster_schedule gets that one only.
+        self._both = "raster_schedule" not in self.kw and int(frames_in_flight) > 1
         self.kw.setdefault("raster_schedule", "throughput" if int(frames_in_flight) > 1 else "latency")
         # the slots' frames keep no per-Gaussian arrays nobody reads (rendering.py: lean_meta)
         self.kw.setdefault("lean_meta", True)
@@ -182,12 +186,13 @@ class FrameRenderer:
         Kt = torch.as_tensor(np.asarray(K, dtype=np.float32)).reshape(1, 3, 3).to(self.dev)
         return vm, Kt
 
-    def _raster(self, vm, K, cap, t=None, dataset_out=None):
+    def _raster(self, vm, K, cap, t=None, dataset_out=None, schedule=None):
         t = self.t if t is None else t
+        kw = self.kw if schedule is None else dict(self.kw, raster_schedule=schedule)
         return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["colors"], vm,
                              K, self.width, self.height, sh_degree=t.get("sh_degree"),
                              render_mode=self.mode, backgrounds=self.bg, isect_capacity=cap,
-                             dataset_out=dataset_out, **self.kw)
+                             dataset_out=dataset_out, **kw)
 
     def _capture_slot(self, stream) -> Dict:
         # the slot's camera: one 25-float device buffer (viewmat | K), so a submit is ONE small copy
@@ -218,24 +223,29 @@ class FrameRenderer:
                   "distance": flat[n_px * 4:].view(self.dataset_dtype).view(self.height, self.width, 1)}
             ds_out = (ds["rgba"].unsqueeze(0), ds["distance"].unsqueeze(0), self.dataset_K, self.dataset_keep_float)
 
-        def body():
+        def body(schedule):
             if pose is None:
-                return self._raster(vm, K, self.capacity, dataset_out=ds_out)
+                return self._raster(vm, K, self.capacity, dataset_out=ds_out, schedule=schedule)
             from .transform import transform_gaussians
             posed = transform_gaussians(self.t, group_ids=self.group_ids, rotate_sh=self.rotate_sh,
                                         out=pose["t"], packed=(pose["x"], pose["r"]))
-            return self._raster(vm, K, self.capacity, posed, dataset_out=ds_out)
-        with torch.cuda.stream(stream):
-            for _ in range(2):
-                body()
+            return self._raster(vm, K, self.capacity, posed, dataset_out=ds_out, schedule=schedule)
+        variants, pool = {}, None
+        for schedule in (("throughput", "latency") if self._both else (self.kw["raster_schedule"],)):
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    body(schedule)
+                torch.cuda.synchronize(self.dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream, pool=pool):       # (a slot's graphs never run together: one pool)
+                    colors, alphas, meta = body(schedule)
+                pool = graph.pool()
             torch.cuda.synchronize(self.dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                colors, alphas, meta = body()
-        torch.cuda.synchronize(self.dev)
-        return {"stream": stream, "vm": vm, "K": K, "cam": cam, "pose": pose, "graph": graph, "colors": colors,
-                "alphas": alphas, "meta": meta, "done": torch.cuda.Event(),
-                "released": torch.cuda.Event(), "state": "free", "ds": ds}
+            variants[schedule] = {"graph": graph, "colors": colors, "alphas": alphas, "meta": meta}
+        first = variants[self.kw["raster_schedule"]]
+        return {"stream": stream, "vm": vm, "K": K, "cam": cam, "pose": pose, "variants": variants, "variant": self.kw["raster_schedule"],
+                "graph": first["graph"], "colors": first["colors"], "alphas": first["alphas"], "meta": first["meta"],
+                "done": torch.cuda.Event(), "released": torch.cuda.Event(), "state": "free", "ds": ds}
 
     # -- API ---------------------------------------------------------------------------
     @staticmethod
@@ -259,6 +269,11 @@ class FrameRenderer:
             raise RuntimeError(f"slot {slot} still holds a frame that was not released "
                                f"({self.n_slots} frames in flight at most)")
         self._next = (slot + 1) % self.n_slots
+        # nothing else in flight: this frame has the GPU to itself -- the schedule with the shortest launch
+        want = "latency" if (self._both and all(o["state"] == "free" for o in self._slots)) else self.kw["raster_schedule"]
+        if s["variant"] != want:
+            v = s["variants"][want]
+            s.update(variant=want, graph=v["graph"], colors=v["colors"], alphas=v["alphas"], meta=v["meta"])
         packed = None
         if self.dataset_K is not None:
             # the dataset epilogue turns depth into ray distance with the intrinsics the renderer was built with (they
@@ -323,6 +338,11 @@ class FrameRenderer:
             if not self.dataset_keep_float:          # the float frame was never written
                 out["colors"] = out["alphas"] = None
         return out
+
+    def isect_status_max(self) -> int:
+        """Largest overflow status word over every slot and both of its graphs (reads them back: call it outside timed
+        regions).  0 = no frame rendered so far needed more tile intersections than the capacity."""
+        return max(int(v["meta"]["isect_status"].max().item()) for s in self._slots for v in s["variants"].values())
 
     def release(self, ticket: int) -> None:
         """Hand the slot back: its next frame will start after everything enqueued so far on the

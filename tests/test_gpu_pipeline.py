@@ -279,3 +279,37 @@ def test_slot_streams_sit_on_distinct_hardware_queues_and_are_reused():
         f.release(tk)
         assert ref is None or torch.equal(out, ref)
         ref = out
+
+
+def test_a_frame_submitted_alone_takes_the_latency_schedule_and_the_same_pixels():
+    """Every slot of a renderer with several frames in flight holds both raster schedules as graphs (one memory pool): a
+    frame submitted while nothing else is in flight -- a synchronous render(), the first frame of a burst -- runs one wave
+    per 8x8 block (the shortest launch), the frames behind it one wave per tile (the fewest instructions).  Same pixels bit
+    for bit whichever graph ran; the overflow word is read over both graphs; naming a schedule pins it."""
+    from robosimgs_amd import FrameRenderer, _lib
+    g = synthetic_scene(60_000, math.log(0.05), 2, 11)
+    cams = camera_ring(6, 352, 208)
+    t = g.to_torch(DEV, 2)
+    fr = FrameRenderer(t, 352, 208, render_mode="RGB+ED", frames_in_flight=3, sizing_camera=(cams[0].viewmat(), cams[0].K))
+    assert all(set(s["variants"]) == {"throughput", "latency"} for s in fr._slots)
+    alone = [fr.render(c.viewmat(), c.K) for c in cams]                     # one at a time: each has the GPU to itself
+    assert all(s["variant"] == "latency" for s in fr._slots[:3])
+    used, piped = [], {}
+    tickets = [fr.submit(c.viewmat(), c.K) for c in cams[:3]]
+    used = [fr._slots[tk]["variant"] for tk in tickets]
+    assert used == ["latency", "throughput", "throughput"]                 # the first of the burst was alone
+    for i, tk in enumerate(tickets):
+        f = fr.fetch(tk)
+        piped[i] = (f["colors"].clone(), f["alphas"].clone())
+        fr.release(tk)
+    for i in range(3):
+        assert torch.equal(piped[i][0], alone[i]["colors"]) and torch.equal(piped[i][1], alone[i]["alphas"]), i
+    assert fr.isect_status_max() == 0
+    pinned = FrameRenderer(t, 352, 208, render_mode="RGB+ED", frames_in_flight=3, isect_capacity=fr.capacity, raster_schedule="throughput")
+    assert all(set(s["variants"]) == {"throughput"} for s in pinned._slots)
+    f = pinned.render(cams[4].viewmat(), cams[4].K)
+    assert torch.equal(f["colors"], alone[4]["colors"])
+    tiny = FrameRenderer(t, 352, 208, render_mode="RGB+ED", frames_in_flight=3, isect_capacity=1000)
+    with pytest.raises(_lib.MgsError):
+        tiny.render(cams[0].viewmat(), cams[0].K)
+    assert tiny.isect_status_max() != 0
