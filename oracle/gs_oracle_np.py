@@ -541,6 +541,9 @@ def check_frame(got, got_alpha, ref, ref_alpha, margins, eps, edge_mask=None, to
     return stats
 
 
+REL_SLACK = 1.5       # check_frame_against_fp32_port: how much worse than the fp32 restatement a frame may be
+
+
 def check_frame_against_fp32_port(got, got_alpha, ref, ref_alpha, fp32_render, fp32_alpha, margins, eps, edge_mask=None,
                                   tol=1e-4, expected_depth=False, what="frame"):
     """The forward gate for scenes that are ILL-CONDITIONED FOR FP32 (needle-like Gaussians seen hundreds of pixels from
@@ -548,10 +551,11 @@ def check_frame_against_fp32_port(got, got_alpha, ref, ref_alpha, fp32_render, f
     port's float instantiation, fp32_render / fp32_alpha (depth SUM in the last channel with expected_depth) -- is itself
     thousands of pixels away from the fp64 answer (`ref`), because sigma of such a pair is uncertain by percents from fp32
     means2d / conics alone, and no two fp32 pipelines agree to 1e-4.  check_frame's zero-unexplained-pixels rule cannot
-    hold for ANY fp32 implementation on such a scene; what can be demanded, and is here, is that the frame under test is
-    NO FARTHER from the fp64 answer than that fp32 restatement: no more pixels over `tol`, no more of them unexplained by
-    a near-flip decision (explained_pixels), no larger 99.9th / 99.99th percentile of the error (in units of the tolerance,
-    the expected-depth channel through the divide), a maximum within a factor of two.  Returns the statistics of both."""
+    hold for ANY fp32 implementation on such a scene; what can be demanded, and is here, is that the frame under test is in
+    the SAME NOISE CLASS as that fp32 restatement against the fp64 answer: at most REL_SLACK times its pixels over `tol`
+    (+ 8), its pixels unexplained by a near-flip decision (explained_pixels), its 99.9th / 99.99th percentile of the error
+    (in units of the tolerance, the expected-depth channel through the divide), a maximum within a factor of two of its
+    maximum or 50 tolerances (what one flipped decision is worth).  Returns the statistics of both."""
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     ga, ra = np.asarray(got_alpha, dtype=np.float64), np.asarray(ref_alpha, dtype=np.float64)
     ga, ra = ga.reshape(ga.shape[:2]), ra.reshape(ra.shape[:2])
@@ -571,9 +575,19 @@ def check_frame_against_fp32_port(got, got_alpha, ref, ref_alpha, fp32_render, f
     out = {"could_flip_frac": float(ex.mean())}
     out.update({k: v for k, v in st.items()})
     out.update({k + "_fp32_port": v for k, v in st32.items()})
-    for k in st:           # (the maximum is one pixel of 2 M: a factor of two on it; counts and percentiles one to one)
-        assert st[k] <= max((2.0 if k == "err_max" else 1.0) * st32[k], 1.0 if k.startswith("err") else 0), (
-            f"{what}: farther from the fp64 answer than a plain fp32 restatement of the reference's formulas ({k}): {out}")
+    # two fp32 realisations of the same noise are compared, not a bound with its subject: over random heavy-tailed scenes the
+    # HIP path is sometimes the closer one (315 pixels against 589 at 1 M / 1080p) and sometimes the other way round (583
+    # against 480; scripts/soak_heavy.py) -- the same noise class.  The frame may be worse than the restatement by REL_SLACK
+    # (+ a few pixels where the counts are tiny); the maximum is one pixel of the frame and gets a factor of two.
+    for k in st:
+        if k.startswith("err"):
+            # (err_max is ONE pixel: a single near-flip decision going the other way is worth up to ~5e-3 = 50 tolerances
+            #  whichever implementation takes it; a wrong pixel is worth thousands)
+            lim = max(2.0 * st32[k], 50.0) if k == "err_max" else max(REL_SLACK * st32[k], 1.0)
+        else:
+            lim = REL_SLACK * st32[k] + 8
+        assert st[k] <= lim, (
+            f"{what}: farther from the fp64 answer than a plain fp32 restatement of the reference's formulas allows ({k}: {st[k]} > {lim}): {out}")
     return out
 
 
