@@ -37,7 +37,13 @@ constexpr int kTSLong = 1024, kFastXL = 8192, kLongGrid = 256;
 constexpr int buckets_for(int) { return 1024; }   // (256 for the short-list variant: fewer counters to zero / scan, but ~2 entries per
                                                   //  bucket make the wave's rank loop as long as its fullest bucket: 22.6 M VALU against 21.8 M)
 constexpr int log2i(int v) { return v <= 1 ? 0 : 1 + log2i(v >> 1); }
-constexpr int kSmall = 48;          // buckets up to this size are finished by rank counting
+#ifndef MGS_TSORT_SMALL
+// buckets up to this size are finished by rank counting out of LDS; larger ones are bucketed again, one after the other, through
+// global scratch.  48 until round 5; on a clustered scene most tiles of 1-2 k entries hold a few dozen buckets of 50-150
+// near-identical depths: at 128 the main kernel takes 75 instead of 104 us there (256: 90), on SURVEY 8(d)'s scene 33.0 either way
+#define MGS_TSORT_SMALL 128
+#endif
+constexpr int kSmall = MGS_TSORT_SMALL;
 #ifndef MGS_TSORT_SMALL_LONG
 #define MGS_TSORT_SMALL_LONG 256
 #endif
