@@ -174,6 +174,11 @@ def barrier_sync(use_dist):
 
 def main():
     a = parse()
+    if os.environ.get("BENCH_WATCHDOG_S"):
+        # debugging aid for a stuck multi-rank run: every process dumps its Python stacks to stderr and exits after this
+        # many seconds (the launcher then reports the ranks' exit code)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG_S"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -21,7 +21,11 @@ VAR = os.path.join(B.HERE, "libmgs_variant.so")
 subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs.values(), "-o", VAR], check=True)
 libs = {"A (shipped)": _lib._load(), "B (variant)": _lib._load(VAR)}
 
-n, mu, W, H, deg = 1_000_000, 0.012, 1920, 1080, 3
+# (SCENE=4k: configs[4] -- 5 M Gaussians at 3840x2160, the capacity bench.py's leg uses there)
+if os.environ.get("SCENE") == "4k":
+    n, mu, W, H, deg = 5_000_000, 0.008, 3840, 2160, 3
+else:
+    n, mu, W, H, deg = 1_000_000, 0.012, 1920, 1080, 3
 dev = "cuda"
 g = synthetic_scene(n, math.log(mu), deg, 0)
 if os.environ.get("MORTON", "1") != "0":
@@ -31,7 +35,7 @@ t = g.to_torch(dev, deg)
 vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)
 K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)
 tw, th = -(-W // 16), -(-H // 16)
-CAP = 4_700_000
+CAP = int(os.environ.get("CAP", 30_100_000 if os.environ.get("SCENE") == "4k" else 4_700_000))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 def timed(fn, reps):
@@ -64,7 +68,7 @@ n_is = int(a["tl"].n_isect)
 print("identical lists:", torch.equal(a["lists"][0][:n_is], b["lists"][0][:n_is]) and torch.equal(a["lists"][1], b["lists"][1]),
       " identical frames:", torch.equal(a["out"][0], b["out"][0]) and torch.equal(a["out"][1], b["out"][1]))
 
-def fps(st, frames=150):
+def fps(st, frames=60 if os.environ.get("SCENE") == "4k" else 150):
     fr, tickets = st["fr"], []
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(frames):
