@@ -792,6 +792,13 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+        if world > 1:
+            # the ranks leave without the interpreter's teardown: everything is printed and the group is gone, and the
+            # teardown of HIP graphs / streams / communicators beside the other ranks' is the one place a finished run
+            # could still get stuck (a two-rank run was once seen not to return; not reproduced in eight repeats)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
 
 
 def pmc_traffic(kernel_key, standard_workload):

@@ -179,6 +179,9 @@ __device__ __forceinline__ void finish_geo(float ca, float cb, float cc, float& 
 #ifndef MGS_RASTER_BWD_PIPE
 #define MGS_RASTER_BWD_PIPE 0
 #endif
+#ifndef MGS_RASTER_BWD_QUAD
+#define MGS_RASTER_BWD_QUAD 1
+#endif
 #ifndef MGS_RASTER_BWD_XCD_RUN
 #define MGS_RASTER_BWD_XCD_RUN 4       // segmented launch: consecutive units per XCD (see raster_bwd_kernel); 1 = plain numbering.  FETCH_SIZE 422 / 387 / 360 / 344 MiB for 1 / 2 / 4 / 8, same time
 #endif
@@ -403,11 +406,27 @@ __device__ __forceinline__ void raster_bwd_unit(const int unit,
 
   constexpr int NV = 6 + CHT + (ABSGRAD ? 2 : 0);      // values reduced over the wave per list entry
   constexpr bool PIPE = RECORDS && MGS_RASTER_BWD_PIPE != 0 && NV > 8 && NV <= 16;
+  // QUAD (9..16 reduced values): FOUR lanes finish a value -- each adds a quarter of the value's row, two DPP steps, and
+  // the NV totals leave in one store instruction; the other form gives eight lanes a value and takes two groups of
+  // eight values side by side (the second group mostly idle at 10 values): 4 + 15 + 2 + 1 instead of 4 + 14 + 6 + 2
+  constexpr bool QUAD = MGS_RASTER_BWD_QUAD != 0 && NV > 8 && NV <= 16;
   constexpr int RSP = record_floats(CHT, ABSGRAD);     // floats per record (stride)
   // record position of value j: the values in the order they are reduced (padding channels hold zeros)
   auto rec_pos = [&](int j) { return j; };
   // the two halves of the 9..16-value reduction (see below): read back the parked partial sums ...
   auto red_load = [&](float4& a0, float4& b0, float4& a1, float4& b1) {
+    if constexpr (QUAD) {
+      // the lane's quarter of its value's row, 16-byte piece ((value & 3) ^ step) at each step: in every step the 16
+      // lanes the LDS serves together -- four values x four quarters -- read 16 different columns of the 64 banks
+      // (rows are 256 bytes apart: all rows alias, only the column tells lanes apart)
+      const int qv = (int)(lane >> 2), x = qv & 3;
+      const float* q = &red[qv < NV ? qv : NV - 1][16 * (lane & 3)];
+      a0 = *reinterpret_cast<const float4*>(q + 4 * x);
+      b0 = *reinterpret_cast<const float4*>(q + 4 * (x ^ 1));
+      a1 = *reinterpret_cast<const float4*>(q + 4 * (x ^ 2));
+      b1 = *reinterpret_cast<const float4*>(q + 4 * (x ^ 3));
+      return;
+    }
     const int v1 = 8 + (int)(lane >> 3);                          // second group's value for this lane
     const float4* s0 = reinterpret_cast<const float4*>(&red[lane >> 3][(lane & 7) * 8]);
     const float4* s1 = reinterpret_cast<const float4*>(&red[v1 < NV ? v1 : 8][(lane & 7) * 8]);
@@ -415,6 +434,17 @@ __device__ __forceinline__ void raster_bwd_unit(const int unit,
   };
   // ... and finish the sums and store the record
   auto red_finish = [&](size_t rslot, const float4& a0, const float4& b0, const float4& a1, const float4& b1) {
+    if constexpr (QUAD) {
+      float t = (((a0.x + a0.y) + (a0.z + a0.w)) + ((b0.x + b0.y) + (b0.z + b0.w))) +
+                (((a1.x + a1.y) + (a1.z + a1.w)) + ((b1.x + b1.y) + (b1.z + b1.w)));
+      // (as text, see below: the compiler sinks the last add into the storing lanes' branch and unfolds its DPP move)
+      asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                   "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(t));
+      float* rec = records + rslot * RSP;
+      if ((lane & 3) == 0 && (int)(lane >> 2) < NV) rec[lane >> 2] = t;      // one store: NV consecutive words
+      if (lane == 0) flags[rslot] = 1;
+      return;
+    }
     const int v1 = 8 + (int)(lane >> 3);
     float t0 = ((a0.x + a0.y) + (a0.z + a0.w)) + ((b0.x + b0.y) + (b0.z + b0.w));
     float t1 = ((a1.x + a1.y) + (a1.z + a1.w)) + ((b1.x + b1.y) + (b1.z + b1.w));

@@ -58,6 +58,10 @@ constexpr int kStack = 96;          // pending heavy buckets; beyond it a bucket
 constexpr int kFastLong = MGS_TSORT_FAST;   // longest list of the LDS-resident fast path (8 KiB of LDS per 1024) ...
 constexpr int kFastShort = 1024;            // ... and where the capacity says lists are short on average: 17 instead of
                                             // 25 KiB of LDS per workgroup = 8 instead of 6 workgroups per CU
+constexpr int kFastMid = 1536;              // ... and in between (up to 1,000 entries per tile on average: configs[4] has 806,
+                                            // its longest list 1,479): 21 KiB, 7 workgroups per CU -- the stage 428 -> 414 us at
+                                            // 4K, 1,024 -> 1,049 frames/s with three in flight (1,280 entries: 443 us, the
+                                            // long-list launch gets work); lists over it go to the second launch as ever
 constexpr uint32_t kBrute = 0x80000000u;
 
 __device__ __forceinline__ bool comp_less(uint32_t ka, uint32_t ia, uint32_t kb, uint32_t ib) {
@@ -640,9 +644,10 @@ int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depth
   // main kernel's generic path, while the launch of 256 empty 1,024-thread workgroups would cost every frame 4.6 us
   // (bench.py's headline: 4,313 against 4,345 frames/s).  Scenes whose capacity says lists are long get both launches.
 #ifdef MGS_TSORT_FORCE_LONG     // measurement (scripts/ab_builds.py): the two-launch form whatever the capacity says
-  const bool short_lists = false;
+  const bool short_lists = false, mid_lists = false;
 #else
   const bool short_lists = (size_t)capacity <= (size_t)n_tiles * 640;
+  const bool mid_lists = !short_lists && (size_t)capacity <= (size_t)n_tiles * 1000;
 #endif
   // (GROUPED launches are padded to whole blocks of 8 groups: the kernel's XCD-aware tile numbering)
   const int per = 8 << group_shift, n_wg = staging ? (n_tiles + per - 1) / per * per : n_tiles;
@@ -652,9 +657,11 @@ int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depth
                      STG, SH, OUT, long_list)
   if (staging) {
     if (short_lists) MGS_TS_LAUNCH(true, kFastShort, false, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
+    else if (mid_lists) MGS_TS_LAUNCH(true, kFastMid, true, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
     else MGS_TS_LAUNCH(true, kFastLong, true, group_offsets, staging, group_shift, const_cast<int32_t*>(tile_offsets));
   } else {
     if (short_lists) MGS_TS_LAUNCH(false, kFastShort, false, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
+    else if (mid_lists) MGS_TS_LAUNCH(false, kFastMid, true, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
     else MGS_TS_LAUNCH(false, kFastLong, true, tile_offsets, (const uint32_t*)nullptr, 0, (int32_t*)nullptr);
   }
 #undef MGS_TS_LAUNCH

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_plain_python_bench_gpus_2_launches_its_ranks_and_prints_one_json_line():
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_WATCHDOG_S"] = "420"       # a stuck run dumps every process's stacks and ends before the timeout below
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-single-device-gloo",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-stress", "--min-seconds", "0"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
