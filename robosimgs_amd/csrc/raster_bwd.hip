@@ -440,8 +440,11 @@ __device__ __forceinline__ void raster_bwd_unit(const int unit,
       // (as text, see below: the compiler sinks the last add into the storing lanes' branch and unfolds its DPP move)
       asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                    "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(t));
-      float* rec = records + rslot * RSP;
-      if ((lane & 3) == 0 && (int)(lane >> 2) < NV) rec[lane >> 2] = t;      // one store: NV consecutive words
+      // (as text: the record's address is uniform + the lane's word, and the store takes the uniform part from an SGPR
+      //  pair -- the compiler formed a 64-bit address per lane with a quarter-rate v_mad_i64_i32 per pair)
+      const float* rec = records + rslot * RSP;
+      if ((lane & 3) == 0 && (int)(lane >> 2) < NV)                          // one store: NV consecutive words
+        asm volatile("global_store_dword %0, %1, %2" : : "v"((unsigned)(lane >> 2) * 4u), "v"(t), "s"(rec) : "memory");
       if (lane == 0) flags[rslot] = 1;
       return;
     }
