@@ -21,6 +21,8 @@
 // only global traffic is the id load, the depth gather and the final store.  Longer lists, and the
 // heavy buckets of any list, run the generic loop whose elements live in two global scratch buffers
 // (L2-resident for the workgroup) -- only the 1024 counters are in LDS, so any length is handled.
+#include <type_traits>
+
 #include "mgs_common.h"
 
 namespace mgs {
@@ -51,6 +53,9 @@ constexpr int kSmallLong = MGS_TSORT_SMALL_LONG;   // ... in the kernel of the l
 constexpr int kStack = 96;          // pending heavy buckets; beyond it a bucket is rank-counted whatever its size
 #ifndef MGS_TSORT_STOP
 #define MGS_TSORT_STOP 0      // measurement only: leave the kernel after phase 1..4 (filter / keys / scan / scatter)
+#endif
+#ifndef MGS_TSORT_LDS_LEVELS
+#define MGS_TSORT_LDS_LEVELS 1     // popped heavy buckets that fit the LDS list take a level out of LDS (sort_one_tile)
 #endif
 #ifndef MGS_TSORT_FAST
 #define MGS_TSORT_FAST 2048
@@ -207,10 +212,17 @@ __device__ __forceinline__ void sort_one_tile(
     if (GROUPED && e - s == 1 && tid == 0) ids_final[s] = li[0];
     return;
   }
-  const int n = e - s;
+  const int n_list = e - s;
 
-  if (n <= kFast) {
-    // ---- fast path: registers + LDS ------------------------------------------------------------
+  // ---- one bucketing level out of registers + LDS: the n <= kFast composites of [s, s + n) -----------------------
+  // FIRST: the tile's whole list (ids out of the group filter's LDS list or flatten_ids, depths gathered); otherwise a
+  // heavy bucket the generic loop popped (keys and ids out of the scratch buffer it lies in: one coalesced load instead
+  // of the four passes over global memory that a level of the generic path is -- round 5: a clustered scene's lists hold
+  // dozens of buckets of a few hundred near-identical depths each).  Light buckets are ranked out of LDS and stored;
+  // heavy ones go to buffer (hk, hi) with stack slots from stack_base on.  Returns the number of heavy buckets.
+  auto lds_level = [&](auto first_tag, const int s, const int n, const uint32_t* sk, const uint32_t* si, uint32_t* hk, uint32_t* hi,
+                       const uint8_t hsrc, const int stack_base) -> uint32_t {
+    constexpr bool FIRST = decltype(first_tag)::value;
     uint32_t rk[kItems], ri[kItems];
     // (every item loop below stops, wave-uniformly, at the first item no thread of the workgroup owns:
     //  a 455-entry list executes two of the eight unrolled trips)
@@ -221,17 +233,18 @@ __device__ __forceinline__ void sort_one_tile(
       ri[it] = 0u;
       if (it * kTS >= n) continue;
       const int idx = min(it * kTS + tid, n - 1);
-      ri[it] = GROUPED ? li[idx] : ids_final[s + idx];
+      if constexpr (FIRST) ri[it] = GROUPED ? li[idx] : ids_final[s + idx];
+      else ri[it] = si[s + idx];
     }
     // highest bit in which two composites (depth bits << 32 | id) differ: the bits where the depth keys are not
     // all alike are OR & ~AND over the list (32-bit reductions); only a list of identical depths looks at the ids
     uint32_t kor = 0u, kand = ~0u;
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
-      const int idx = it * kTS + tid;
       rk[it] = 0u;
       if (it * kTS >= n) continue;
-      rk[it] = __float_as_uint(depths[ri[it]]);
+      if constexpr (FIRST) rk[it] = __float_as_uint(depths[ri[it]]);
+      else rk[it] = sk[s + min(it * kTS + tid, n - 1)];
     }
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
@@ -245,7 +258,6 @@ __device__ __forceinline__ void sort_one_tile(
     if ((tid & 63) == 0) { red_or[tid >> 6] = kor; red_and[tid >> 6] = kand; }
 #pragma unroll
     for (int k = 0; k < kBuckets / kTS; ++k) cnt[tid + k * kTS] = 0;
-    if (tid == 0) stack_n = 0;
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < kTS / 64; ++w) { kor |= red_or[w]; kand &= red_and[w]; }
@@ -267,7 +279,7 @@ __device__ __forceinline__ void sort_one_tile(
       hb = 31 - __clz((int)(ior ^ iand));
     }
 #if MGS_TSORT_STOP == 2
-    if (hb >= 0) { if (tid == 0) ids_final[s] = (uint32_t)hb; return; }
+    if (hb >= 0) { if (tid == 0) ids_final[s] = (uint32_t)hb; return 0u; }
 #endif
     const int shift = hb > kDigitBits - 1 ? hb - (kDigitBits - 1) : 0;
     // shift >= 32 (the depths differ above their lowest kDigitBits - 1 bits: nearly always): the digit is a bit
@@ -302,9 +314,10 @@ __device__ __forceinline__ void sort_one_tile(
       for (int k = 0; k < kBuckets / kTS; ++k) {
         const int d = tid * (kBuckets / kTS) + k;
         cur[d] = ex;
-        if (c4[k] > (uint32_t)kSm) {            // the generic loop below takes it from buffer 1
-          if ((int)hx < kStack) {
-            stack_lo[hx] = s + (int)ex; stack_hi[hx] = s + (int)(ex + c4[k]); stack_src[hx] = 1;
+        if (c4[k] > (uint32_t)kSm) {            // the generic loop below takes it from buffer (hk, hi)
+          const int slot = stack_base + (int)hx;
+          if (slot < kStack) {
+            stack_lo[slot] = s + (int)ex; stack_hi[slot] = s + (int)(ex + c4[k]); stack_src[slot] = hsrc;
           } else {
             cnt[d] = c4[k] | kBrute;
           }
@@ -312,11 +325,11 @@ __device__ __forceinline__ void sort_one_tile(
         }
         ex += c4[k];
       }
-      if (tid == 0) stack_n = (int)htot < kStack ? (int)htot : kStack;
+      if (tid == 0) stack_n = stack_base + (int)htot < kStack ? stack_base + (int)htot : kStack;
     }
     __syncthreads();
 #if MGS_TSORT_STOP == 3
-    if (n > 0) { if (tid == 0) ids_final[s] = cur[3]; return; }
+    if (n > 0) { if (tid == 0) ids_final[s] = cur[3]; return 0u; }
 #endif
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
@@ -328,7 +341,7 @@ __device__ __forceinline__ void sort_one_tile(
     }
     __syncthreads();
 #if MGS_TSORT_STOP == 4
-    if (n > 0) { if (tid == 0) ids_final[s] = (uint32_t)lc[3]; return; }
+    if (n > 0) { if (tid == 0) ids_final[s] = (uint32_t)lc[3]; return 0u; }
 #endif
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
@@ -341,8 +354,8 @@ __device__ __forceinline__ void sort_one_tile(
         const uint32_t craw = cnt[d];
         const uint32_t b = craw & ~kBrute;
         if (b > (uint32_t)kSm && !(craw & kBrute)) {   // heavy: hand it to the generic loop
-          key1[s + i] = k;
-          id1[s + i] = id;
+          hk[s + i] = k;
+          hi[s + i] = id;
         } else {
           const int be = (int)cur[d], bs = be - (int)b;
           int c = 0;
@@ -351,6 +364,13 @@ __device__ __forceinline__ void sort_one_tile(
         }
       }
     }
+    return htot;
+  };
+
+  const int n = n_list;
+  if (n <= kFast) {
+    // ---- fast path: the whole list is one level out of LDS ---------------------------------------
+    const uint32_t htot = lds_level(std::true_type{}, s, n, (const uint32_t*)nullptr, (const uint32_t*)nullptr, key1, id1, (uint8_t)1, 0);
     if (htot == 0) return;                          // uniform
     __syncthreads();
   } else {
@@ -431,6 +451,15 @@ __device__ __forceinline__ void sort_one_tile(
     uint32_t* di = src ? id0 : id1;
     const int m = hi - lo;
 
+    // (the long lists' kernel only: a second copy of the level takes the main kernel from 47-53 to 64-86 VGPRs, a
+    //  workgroup per CU less for every scene, and its heavy buckets are few)
+    if constexpr (LONG && MGS_TSORT_LDS_LEVELS != 0) {
+      if (m > kSm && m <= kFast) {              // fits the LDS list: one level out of LDS (heavy sub-buckets to the other buffer)
+        (void)lds_level(std::false_type{}, lo, m, sk, si, dk, di, (uint8_t)(src ^ 1), sn - 1);
+        __syncthreads();
+        continue;
+      }
+    }
     if (m <= kSm) {                             // whole segment by rank counting
       for (int i = lo + tid; i < hi; i += kTS) {
         const uint32_t k = sk[i], id = si[i];
