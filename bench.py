@@ -1189,12 +1189,18 @@ def heavy_tailed_leg(a, dev, deg, n_fl, frames=20):
     dt = (time.perf_counter() - t0) / (5 * frames)
     status = fr.isect_status_max()
     step = bench_fwd_bwd(a, t, vm[None], K[None], W, H, deg, cap, dev)
+    # the same step on the renderer's Morton-ordered copy: the generator APPENDS its 4,006 large rectangles, so "as given"
+    # has them contiguous in index -- a handful of workgroups of the index-partitioned kernels (tile histogram, scatter,
+    # record reduce) own most of the pairs; robosimgs_amd.reorder_parameters is what a trainer does about it
+    step_m = bench_fwd_bwd(a, fr.t, vm[None], K[None], W, H, deg, cap, dev)
     return {"workload": f"NOT a BASELINE config: {n} Gaussians, heavy-tailed synthetic scene (synthetic_scene_heavy_tailed, seed 0), SH degree "
                         f"{deg}, {W}x{H} ({MODE}), theta = 0.3",
             "n_visible": n_vis, "n_isect": n_isect, "n_isect_binned": n_binned, "list_length": stats,
             "stages_by_raster_schedule": out, "frames_per_s": round(1.0 / dt, 2), "ms_per_frame": round(dt * 1e3, 4),
             "frames_in_flight": n_fl, "isect_overflow": bool(status),
-            "fwd_bwd": {"ms_per_step": step["ms_per_step"], "launch": step["launch"], "scene_order": "as given"},
+            "fwd_bwd": {"ms_per_step": step["ms_per_step"], "launch": step["launch"],
+                        "scene_order": "as given (the large rectangles contiguous at the end of the index range)",
+                        "morton_order": {"ms_per_step": step_m["ms_per_step"]}},
             "note": "the raster is a tile's serial walk: the launch lasts as long as its longest lists (the tile-time tail), "
                     "which is what the two schedules' raster_ms against the 1080p headline's show"}
 
