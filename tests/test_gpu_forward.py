@@ -152,6 +152,42 @@ def test_tile_depth_order_long_lists_and_depth_ties(ops, n, span, kind):
     np.testing.assert_array_equal(tl.tile_ids[:cnt].cpu().numpy(), (r_ids >> 32).astype(np.int32))
 
 
+@pytest.mark.parametrize("per_list,tiles_w,kind", [(9_000, 16, "clustered"), (12_000, 16, "clustered"), (3_000, 4, "uniform"),
+                                                   (12_000, 4, "clustered"), (1_700, 2, "ties")])
+def test_tile_depth_order_uneven_lists_under_each_capacity_rule(ops, per_list, tiles_w, kind):
+    """Two full tiles among empty ones: the AVERAGE the capacity allows picks the per-tile sort's variant (1,024-entry LDS
+    list and no second launch up to 640 per tile, 1,536 entries up to 1,000, 2,048 beyond), the two lists are far longer
+    than any of them -- the main kernel's own generic path under the short rule, the long-list kernel under the others
+    (its LDS fast path up to 8,192 entries; beyond it the levels through global scratch with heavy buckets finished out of
+    LDS).  Lists bit-identical to the stable sort whatever the variant."""
+    rng = np.random.default_rng(per_list + tiles_w)
+    n = 2 * per_list
+    tw, th = tiles_w, 2
+    means2d = np.empty((n, 2), np.float32)
+    means2d[:per_list] = (8.0, 8.0)                        # tile (0, 0)
+    means2d[per_list:] = (16.0 * (tw - 1) + 8.0, 24.0)     # tile (tw - 1, 1)
+    means2d += rng.uniform(-2, 2, size=(n, 2)).astype(np.float32)
+    radii = np.full(n, 3, np.int32)
+    if kind == "clustered":
+        base = rng.choice(np.array([4.0, 4.0001, 4.0002, 6.5], np.float32), size=n)
+        depths = (base + rng.integers(0, 300, size=n).astype(np.float32) * np.float32(4.76837158203125e-07)).astype(np.float32)
+        depths[0], depths[1] = 0.011, 9.0e9
+    elif kind == "ties":
+        depths = rng.choice(np.array([1.5, 2.0, 2.0000002, 7.25], np.float32), size=n)
+    else:
+        depths = rng.uniform(0.5, 20.0, size=n).astype(np.float32)
+    cap = n + 16
+    assert {(16, 9_000): cap <= 640 * tw * th, (16, 12_000): 640 * tw * th < cap <= 1000 * tw * th}.get((tiles_w, per_list), cap > 640 * tw * th)
+    tl = ops.isect_tiles_raw(_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), tw, th, cap, want_isect_ids=True)
+    cnt = int(tl.n_isect.item())
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, tw, th, dtype=np.float32)
+    assert cnt == len(r_flat) == n and int(tl.status.item()) == 0
+    np.testing.assert_array_equal(tl.flatten_ids[:cnt].cpu().numpy(), r_flat)
+    np.testing.assert_array_equal(tl.isect_ids[:cnt].cpu().numpy(), r_ids)
+    np.testing.assert_array_equal(tl.tile_offsets[:tw * th].cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th).reshape(-1))
+    assert int(tl.tile_offsets[tw * th]) == n
+
+
 def test_isect_tiles_empty_and_overflow(ops):
     from robosimgs_amd import _lib
     w = h = 64
