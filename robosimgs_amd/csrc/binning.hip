@@ -257,6 +257,12 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
 // tile_sort.hip then lets every tile pick its entries out of its group's segment.
 // Device-scope atomics were measured for the same job and are no option: ~25 G atomics/s on 8160 hot counters
 // (scripts/ubench/atomic_rate.hip), i.e. 108 us per pass at config 2.
+#ifndef MGS_DIRECT_DEAL
+#define MGS_DIRECT_DEAL 1        // runs of Gaussians dealt round-robin to the histogram / scatter workgroups (DealtIndex)
+#endif
+#ifndef MGS_DIRECT_DEAL_RUN
+#define MGS_DIRECT_DEAL_RUN 256
+#endif
 #ifndef MGS_DIRECT_THREADS
 #define MGS_DIRECT_THREADS 512
 #endif
@@ -307,9 +313,34 @@ __device__ __forceinline__ void for_each_tile(uint32_t pack, uint32_t cnt, uint3
   }
 }
 
+// Which Gaussian thread t of workgroup w takes as item i of the pass that starts at `base`.  DEALT (deal_nb = the number
+// of workgroups; the default): runs of MGS_DIRECT_DEAL_RUN consecutive Gaussians go round-robin to the workgroups -- run
+// ((pass * per-thread + i) * runs-per-pass + t / R) * deal_nb + w -- instead of one run of `chunk` per workgroup.  On a
+// Morton-ordered scene the workgroups' shares of the pairs differed by 2.7 x (near Gaussians are neighbours in memory AND
+// cover many tiles), and a scene whose large rectangles are contiguous in index (appended by a densifier, a background
+// block) left two workgroups with most of the pairs; dealt, both even out: binning 77 -> 68 us at 1080p, 417 -> 357 us at
+// 4K, a clustered scene's training step 1.70 -> 1.54 ms (profiles/r5/00_experiments.md 18, 20).  Runs of 128 ... 512
+// measure alike, 64 loses (a wave's stores of a bin stop being one run).  deal_nb == 0: the consecutive runs.
+// -1: no such Gaussian.
+struct DealtIndex {
+  int g0, g1, n, deal_nb;
+  __device__ __forceinline__ int operator()(int base, int i) const {
+    if (deal_nb > 0) {
+      const int pass = (base - g0) / (kDirectThreads * kDirectPerThread);
+      constexpr int R = MGS_DIRECT_DEAL_RUN, kSub = kDirectThreads / R;      // runs of R consecutive Gaussians
+      const int sub = (int)threadIdx.x / R, within = (int)threadIdx.x % R;
+      const long long g = (((long long)(pass * kDirectPerThread + i) * kSub + sub) * deal_nb + blockIdx.x) * R + within;
+      return g < n ? (int)g : -1;
+    }
+    const int g = base + i * kDirectThreads + (int)threadIdx.x;
+    return g < g1 ? g : -1;
+  }
+};
+
 __global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
     int n, int chunk, const uint2* __restrict__ ginfo, int tile_w, int n_tiles, int shift,
-    uint32_t* __restrict__ table, int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ scan_sums, uint32_t n_sums) {
+    uint32_t* __restrict__ table, int32_t* __restrict__ tiles_per_gauss, uint32_t* __restrict__ scan_sums, uint32_t n_sums,
+    int deal_nb) {
   extern __shared__ uint32_t hist[];
   if (scan_sums && blockIdx.x == gridDim.x - 1) {
     // training only, one workgroup more than the histogram needs: the per-64 sums of the tile counts scanned in place
@@ -324,17 +355,19 @@ __global__ __launch_bounds__(kDirectThreads) void direct_hist_kernel(
   const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
   // the workgroup's rectangles are fetched kDirectPerThread at a time, all loads in flight together: at 1 M Gaussians
   // the launch is 245 workgroups -- two waves per SIMD -- and a load per trip was one exposed round trip per trip
-  for (int base = g0; base < g1; base += kDirectThreads * kDirectPerThread) {
+  const DealtIndex gi{g0, g1, n, deal_nb};
+  const int g_end = deal_nb > 0 ? g0 + chunk : g1;            // (dealt: every workgroup makes every pass)
+  for (int base = g0; base < g_end; base += kDirectThreads * kDirectPerThread) {
     uint2 info[kDirectPerThread];
 #pragma unroll
     for (int i = 0; i < kDirectPerThread; ++i) {
-      const int g = base + i * kDirectThreads + (int)threadIdx.x;
-      info[i] = g < g1 ? ginfo[g] : make_uint2(kEmptyTileRect, 0u);
+      const int g = gi(base, i);
+      info[i] = g >= 0 ? ginfo[g] : make_uint2(kEmptyTileRect, 0u);
     }
 #pragma unroll
     for (int i = 0; i < kDirectPerThread; ++i) {
-      const int g = base + i * kDirectThreads + (int)threadIdx.x;
-      if (g < g1 && tiles_per_gauss) tiles_per_gauss[g] = (int32_t)info[i].y;
+      const int g = gi(base, i);
+      if (g >= 0 && tiles_per_gauss) tiles_per_gauss[g] = (int32_t)info[i].y;
       for_each_tile(info[i].x, info[i].y, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t) { atomicAdd(&hist[tile >> shift], 1u); });
     }
   }
@@ -439,7 +472,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     uint32_t* __restrict__ flatten_ids, int32_t* __restrict__ tile_offsets,
     uint32_t* __restrict__ n_isect, uint32_t* __restrict__ status, int32_t* __restrict__ group_order,
     const uint32_t* __restrict__ scanned_sums, int4* __restrict__ pair_info, uint32_t* __restrict__ zero_word,
-    float* __restrict__ splat_slots) {
+    float* __restrict__ splat_slots, int deal_nb) {
   extern __shared__ uint32_t cursor[];
   n_tiles = (n_tiles + (1 << shift) - 1) >> shift;           // bins (see direct_hist_kernel)
   if (group_order && blockIdx.x == gridDim.x - 1) {
@@ -491,24 +524,26 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
   }
   __syncthreads();
   const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
-  for (int base = g0; base < g1; base += kDirectThreads * kDirectPerThread) {      // (loads in flight together: direct_hist_kernel)
+  const DealtIndex gi{g0, g1, n, deal_nb};                                        // (the histogram launch's assignment)
+  const int g_end = deal_nb > 0 ? g0 + chunk : g1;
+  for (int base = g0; base < g_end; base += kDirectThreads * kDirectPerThread) {   // (loads in flight together: direct_hist_kernel)
     uint2 info[kDirectPerThread];
 #pragma unroll
     for (int i = 0; i < kDirectPerThread; ++i) {
-      const int g = base + i * kDirectThreads + (int)threadIdx.x;
-      info[i] = g < g1 ? ginfo[g] : make_uint2(kEmptyTileRect, 0u);
+      const int g = gi(base, i);
+      info[i] = g >= 0 ? ginfo[g] : make_uint2(kEmptyTileRect, 0u);
     }
     if (PAIRS) {
       // (a wave's 64 lanes are 64 consecutive Gaussians starting at a multiple of 64: chunk and the pass are multiples of 512)
       uint32_t sbase[kDirectPerThread];
 #pragma unroll
       for (int i = 0; i < kDirectPerThread; ++i) {
-        const int g = base + i * kDirectThreads + (int)threadIdx.x;
-        sbase[i] = g < g1 ? scanned_sums[g / kSum] : 0u;
+        const int g = gi(base, i);
+        sbase[i] = g >= 0 ? scanned_sums[g / kSum] : 0u;
       }
 #pragma unroll
       for (int i = 0; i < kDirectPerThread; ++i) {
-        const int g = base + i * kDirectThreads + (int)threadIdx.x;
+        const int g = gi(base, i);
         const uint32_t cnt = info[i].y;
         uint32_t incl = cnt;
 #pragma unroll
@@ -516,7 +551,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
           const uint32_t t = __shfl_up(incl, d);
           if (lane >= (unsigned)d) incl += t;
         }
-        if (g < g1) {
+        if (g >= 0) {
           const uint32_t w = info[i].x >> 20;
           pair_info[g] = cnt ? make_int4((int)(sbase[i] + incl - cnt), (int)(info[i].x & 1023u), (int)((info[i].x >> 10) & 1023u),
                                          (int)(w | ((cnt / w) << 16)))
@@ -527,7 +562,7 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     }
 #pragma unroll
     for (int i = 0; i < kDirectPerThread; ++i) {
-      const int g = base + i * kDirectThreads + (int)threadIdx.x;
+      const int g = gi(base, i);
       for_each_tile(info[i].x, info[i].y, (uint32_t)g, tile_w, [&](uint32_t tile, uint32_t gs) {
         const uint32_t p = atomicAdd(&cursor[tile >> shift], 1u);
         // grouped: the entry carries its tile's place in the group above the id (ids < 2^(32 - shift))
@@ -731,8 +766,10 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
       const unsigned nb = direct_blocks((unsigned)n);
       const int bins = (n_tiles + (1 << gshift) - 1) >> gshift;
       const size_t lds = (size_t)bins * sizeof(uint32_t);
+      // runs of Gaussians are dealt round-robin to the workgroups (DealtIndex)
+      const int deal_nb = MGS_DIRECT_DEAL ? (int)nb : 0;
       hipLaunchKernelGGL(direct_hist_kernel, dim3(nb + (pair_info ? 1 : 0)), dim3(kDirectThreads), lds, s, n, chunk, ginfo, tile_w,
-                         n_tiles, gshift, u32(ws.table), tiles_per_gauss, pair_info ? sums : nullptr, nsum);
+                         n_tiles, gshift, u32(ws.table), tiles_per_gauss, pair_info ? sums : nullptr, nsum, deal_nb);
       if (pair_info)
         hipLaunchKernelGGL(direct_colscan_kernel<MGS_COLSCAN_KEEP>, dim3(div_up((unsigned)bins, (unsigned)kColBins)), dim3(kColThreads), 0, s,
                            (int)nb, bins, u32(ws.table), u32(ws.tile_count));
@@ -747,7 +784,7 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
                          gshift ? u32(ws.id_alt) : reinterpret_cast<uint32_t*>(flatten_ids),                             \
                          gshift ? reinterpret_cast<int32_t*>(w + ws.group_offsets) : tile_offsets, n_isect, status,      \
                          order_in_scatter ? tile_group_order : nullptr, sums, reinterpret_cast<int4*>(pair_info),           \
-                         tile_depth_sort_long_list(w + ws.tsort, cap), pair_info ? splat_slots : nullptr)
+                         tile_depth_sort_long_list(w + ws.tsort, cap), pair_info ? splat_slots : nullptr, deal_nb)
       if (pair_info) MGS_SCATTER(true);
       else MGS_SCATTER(false);
 #undef MGS_SCATTER
