@@ -55,8 +55,21 @@ __device__ __forceinline__ float rect_min_sigma(float mx, float my, float a, flo
 __device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float a, float b, float c,
                                                   float opac, float tile_x, float tile_y) {
   if (!(opac >= kAlphaMin)) return 0u;           // alpha <= opac < 1/255 everywhere
+#if defined(MGS_CULL_IEEE_DIV)
   float thr = __logf(255.0f * opac);
+#else
+  // (one v_log_f32: __logf compiles to the denormal-safe sequence of fourteen; 255 opac >= 1 here, and the slack below
+  //  is five orders above the instruction's error)
+  float thr = 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * opac);
+#endif
+  // (v_rcp_f32, not the IEEE divide's eleven instructions each: the reciprocals only place the clamped minimiser on an
+  //  edge, where the quadratic is flat to second order -- a 1-ulp reciprocal moves sigma by ~1e-13 relative, the test
+  //  below carries a slack of 0.05)
+#if defined(MGS_CULL_IEEE_DIV)      // measurement: the divides
   float inv_a = 1.0f / a, inv_c = 1.0f / c;
+#else
+  float inv_a = __builtin_amdgcn_rcpf(a), inv_c = __builtin_amdgcn_rcpf(c);
+#endif
   float fx = fmaxf(fabsf(tile_x - mx), fabsf(tile_x + 16.f - mx));
   float fy = fmaxf(fabsf(tile_y - my), fabsf(tile_y + 16.f - my));
   float slack = 0.05f + 4e-6f * (fabsf(a) + fabsf(c) + 2.f * fabsf(b)) * (fx * fx + fy * fy);
