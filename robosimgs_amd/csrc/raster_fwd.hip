@@ -659,11 +659,20 @@ __global__ __launch_bounds__(256) void raster_fwd_q_kernel(    // (bounded to 64
       if (cull) {
         keep_me = false;
         if (c_op >= kAlphaMin) {
+          // (single v_log_f32 / v_rcp_f32, as in quadrant_mask: the slack is orders above their error)
+#ifdef MGS_Q_CULL_IEEE      // measurement: the divides and the denormal-safe logf
           const float thr = __logf(255.0f * c_op);
+#else
+          const float thr = 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * c_op);
+#endif
           const float fx = fmaxf(fabsf(tile_x - c_xy.x), fabsf(tile_x + 16.f - c_xy.x));
           const float fy = fmaxf(fabsf(tile_y - c_xy.y), fabsf(tile_y + 16.f - c_xy.y));
           const float slack = 0.05f + 4e-6f * (fabsf(c_ca) + fabsf(c_cc) + 2.f * fabsf(c_cb)) * (fx * fx + fy * fy);
+#ifdef MGS_Q_CULL_IEEE
           const float smin = rect_min_sigma(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, 1.0f / c_ca, 1.0f / c_cc, rect);
+#else
+          const float smin = rect_min_sigma(c_xy.x, c_xy.y, c_ca, c_cb, c_cc, __builtin_amdgcn_rcpf(c_ca), __builtin_amdgcn_rcpf(c_cc), rect);
+#endif
           keep_me = !(smin > thr + slack);
         }
       }
