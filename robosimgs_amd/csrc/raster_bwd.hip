@@ -911,6 +911,9 @@ __global__ __launch_bounds__(256) void reduce_records_kernel(
 #ifndef MGS_REDUCE_TRIP
 #define MGS_REDUCE_TRIP 4       // slots of a row fetched together (reduce_records_rows_kernel)
 #endif
+#ifndef MGS_REDUCE_RUN
+#define MGS_REDUCE_RUN 16       // reduce_records_rows_kernel: consecutive Gaussians per run of a wave (four runs; 0: 64 consecutive)
+#endif
 #ifndef MGS_REDUCE_ROWS
 // 1: reduce_records_rows_kernel (below) for up to 4 channels and one slot per pair; 0: reduce_records_kernel everywhere
 #define MGS_REDUCE_ROWS 1
@@ -938,7 +941,22 @@ __global__ __launch_bounds__(256) void reduce_records_rows_kernel(
   __shared__ float2 s_mean[4][64];
   __shared__ float s_rows[4][64 * PITCH];
   const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  // Which 64 Gaussians a wave owns: four RUNS of MGS_REDUCE_RUN consecutive ones, a whole launch of waves apart (run r
+  // of wave W is run r * n_waves + W of the index space) instead of 64 consecutive.  Large rectangles that sit together
+  // in the index range -- appended by a densifier, neighbours in a Morton order -- then land in many waves, each with a
+  // few, instead of a few waves with 64 each (a wave's time is its row tasks; profiles/r5/00_experiments.md 18, 22).
+  // A run still reads whole lines of pair_info and writes whole sectors of the outputs.  Training step, ms (runs of
+  // 64 = consecutive / 32 / 16 / 8): configs[2] as given 0.823 / 0.823 / 0.824 / 0.827, in Morton order 0.786 / 0.780 /
+  // 0.779 / 0.777; a clustered scene as given 1.526 / 1.460 / 1.397 / 1.376, in Morton order 1.082 / 1.056 / 1.002 / 0.998.
+#if MGS_REDUCE_RUN > 0
+  constexpr int kRun = MGS_REDUCE_RUN, kRunsPerWave = 64 / kRun;
+  const int wave_global = blockIdx.x * 4 + wv, n_waves = (int)gridDim.x * 4;
+  const long long g_ll = ((long long)(lane / kRun) * n_waves + wave_global) * kRun + lane % kRun;
+  const int g = g_ll < n ? (int)g_ll : n;
+  static_assert(64 % kRun == 0 && kRunsPerWave >= 1, "runs of a power of two up to 64");
+#else
   const int g = blockIdx.x * 256 + (int)threadIdx.x;
+#endif
   int4 info = make_int4(0, 0, 0, 0);
   int h = 0;
   float mean_x = 0.f, mean_y = 0.f, ca = 1.f, cb = 0.f, cc = 1.f, op = 1.f;
