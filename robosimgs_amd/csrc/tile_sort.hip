@@ -35,8 +35,11 @@ constexpr int kTSMain = 256;        // threads per tile
 // kernel appends such tiles to a list.  The second launch costs 4.6 us even when the list is empty, so it exists only where
 // the capacity says lists are long (tile_depth_sort below).
 constexpr int kTSLong = 1024, kFastXL = 8192, kLongGrid = 256;
+#ifndef MGS_TSORT_LONG_BUCKETS
+#define MGS_TSORT_LONG_BUCKETS 2048    // buckets per level in the long lists' kernel (the main kernel: 1024); clustered scene 206 / 186 / 203 us at 1024 / 2048 / 4096
+#endif
 // buckets of one MSD level
-constexpr int buckets_for(int) { return 1024; }   // (256 for the short-list variant: fewer counters to zero / scan, but ~2 entries per
+constexpr int buckets_for(int fast) { return fast > 2048 ? MGS_TSORT_LONG_BUCKETS : 1024; }   // (256 for the short-list variant: fewer counters to zero / scan, but ~2 entries per
                                                   //  bucket make the wave's rank loop as long as its fullest bucket: 22.6 M VALU against 21.8 M)
 constexpr int log2i(int v) { return v <= 1 ? 0 : 1 + log2i(v >> 1); }
 #ifndef MGS_TSORT_SMALL
