@@ -5,7 +5,7 @@ counts, needle / screen-filling shares, resolutions and cameras) through what th
   * classic against tightened rectangles: same image, same gradients (whole-list walk), bit for bit;
   * the forward against the fp64 port relative to its fp32 instantiation (check_frame_against_fp32_port);
   * gradients finite and bit-reproducible.
-    python scripts/soak_heavy.py [n_scenes]"""
+    python scripts/soak_heavy.py [n_scenes [first_seed]]"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,7 +16,8 @@ DEV = "cuda"
 def _t(a): return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 bad, longest, worst = 0, 0, 0.0
-for seed in range(n_scenes):
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # python scripts/soak_heavy.py n_scenes [first_seed]
+for seed in range(first, first + n_scenes):
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.integers(60_000, 400_000)); W = int(rng.integers(300, 1300)); H = int(rng.integers(200, 800)); deg = int(rng.integers(0, 4))
     g = synthetic_scene_heavy_tailed(n, math.log(float(rng.uniform(0.004, 0.03))), deg, seed, n_clusters=int(rng.integers(3, 120)),
