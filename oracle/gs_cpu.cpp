@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -337,18 +339,20 @@ long long render_impl(int n, const float* means, const float* quats, const float
     n_thr = omp_get_max_threads();
 #endif
     std::vector<long long> hist((size_t)n_thr * n_tiles_sz, 0);
-#pragma omp parallel num_threads(n_thr)
+    // The keys are cut into n_thr SLICES and the slices are dealt to whatever team the runtime really starts
+    // (`omp for schedule(static, 1)` over the slices): with fewer threads than omp_get_max_threads() promised
+    // (OMP_THREAD_LIMIT, OMP_DYNAMIC, a nested region) a thread takes several slices and none is left uncounted.
+    long long scattered = 0;
+#pragma omp parallel num_threads(n_thr) reduction(+ : scattered)
     {
-      int k = 0;
-#ifdef _OPENMP
-      k = omp_get_thread_num();
-#endif
-      const long long i0 = n_isect * k / n_thr, i1 = n_isect * (k + 1) / n_thr;
-      long long* h = hist.data() + (size_t)k * n_tiles_sz;
-      for (long long i = i0; i < i1; ++i) ++h[keys[i] >> 32];
-#pragma omp barrier
+#pragma omp for schedule(static, 1)
+      for (int k = 0; k < n_thr; ++k) {
+        const long long i0 = n_isect * k / n_thr, i1 = n_isect * (k + 1) / n_thr;
+        long long* h = hist.data() + (size_t)k * n_tiles_sz;
+        for (long long i = i0; i < i1; ++i) ++h[keys[i] >> 32];
+      }                                                                   // (implicit barrier)
 #pragma omp for schedule(static)
-      for (long long t = 0; t < (long long)n_tiles_sz; ++t) {          // per tile: total, and every thread's share turned into its offset
+      for (long long t = 0; t < (long long)n_tiles_sz; ++t) {          // per tile: total, and every slice's share turned into its offset
         long long run = 0;
         for (int kk = 0; kk < n_thr; ++kk) {
           const long long c = hist[(size_t)kk * n_tiles_sz + t];
@@ -359,10 +363,20 @@ long long render_impl(int n, const float* means, const float* quats, const float
       }
 #pragma omp single
       for (size_t t = 0; t < n_tiles_sz; ++t) tstart[t + 1] += tstart[t];
-      for (long long i = i0; i < i1; ++i) {
-        const size_t t = (size_t)(keys[i] >> 32);
-        perm[tstart[t] + h[t]++] = i;
+#pragma omp for schedule(static, 1)
+      for (int k = 0; k < n_thr; ++k) {
+        const long long i0 = n_isect * k / n_thr, i1 = n_isect * (k + 1) / n_thr;
+        long long* h = hist.data() + (size_t)k * n_tiles_sz;
+        for (long long i = i0; i < i1; ++i) {
+          const size_t t = (size_t)(keys[i] >> 32);
+          perm[tstart[t] + h[t]++] = i;
+          ++scattered;
+        }
       }
+    }
+    if (scattered != n_isect || tstart[n_tiles_sz] != n_isect) {        // every entry of `perm` (uninitialised storage) was written
+      std::fprintf(stderr, "gs_cpu: counting sort placed %lld of %lld keys\n", scattered, n_isect);
+      std::abort();
     }
   }
 #pragma omp parallel for schedule(dynamic, 16)

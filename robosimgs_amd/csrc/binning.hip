@@ -272,6 +272,9 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(
 // frames' raster waves hold the slots: with three frames in flight 1024 x 4 renders 3,281 frames/s, 512 x 8 3,669,
 // 256 x 8 3,561 (the radix partition: 3,585).
 constexpr int kDirectThreads = MGS_DIRECT_THREADS;
+// DealtIndex covers the index range without holes, and the PAIRS path's "a wave is 64 consecutive Gaussians", only then:
+static_assert(MGS_DIRECT_DEAL_RUN % 64 == 0 && kDirectThreads % MGS_DIRECT_DEAL_RUN == 0 && kDirectThreads >= MGS_DIRECT_DEAL_RUN,
+              "MGS_DIRECT_THREADS must be a multiple of MGS_DIRECT_DEAL_RUN, and the run a multiple of the wave");
 #ifndef MGS_DIRECT_PER_THREAD
 // Round 4: 4 (was 8).  At 1 M Gaussians 512 x 8 is 245 workgroups -- fewer than CUs, two waves per SIMD -- and on a
 // Morton-ordered scene their shares of the pairs differ by 2.7 x (15 k on average, 40 k at most: near Gaussians are

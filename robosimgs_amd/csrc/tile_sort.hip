@@ -124,6 +124,9 @@ __device__ __forceinline__ void sort_one_tile(
     uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out,
     uint32_t* __restrict__ long_list) {
   constexpr int kBuckets = buckets_for(kFast), kDigitBits = log2i(kBuckets);
+  // lds_level's packed scan carries the running entry count in 16 bits and the heavy-bucket count above it
+  static_assert(kFast < 65536 && kBuckets < 65536, "the packed bucket scan holds counts below 2^16");
+  static_assert(kBuckets % kTS == 0 && kFast % kTS == 0, "buckets and list entries are dealt evenly to the threads");
   // buckets up to kSm entries are finished by rank counting.  The long lists' kernel takes far larger ones: its candidates
   // come out of LDS (the fast path's list, the generic path's windows), and every bucket it does NOT rank is one more
   // level taken by the whole 1024-thread workgroup, one bucket after the other -- a clustered scene's 31 k-entry list

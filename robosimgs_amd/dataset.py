@@ -82,7 +82,8 @@ class DatasetWriter:
     The files are zlib streams: at 1080p one frame is ~0.25 s of host time (level 6 PNG + level 9 gzip of the fp32 distance
     map), i.e. 4 frames/s on one thread behind a renderer that makes 4,300 (INTEGRATION.md has the measured table).
     workers > 0 encodes and writes on a thread pool (zlib releases the GIL): write() returns as soon as the frame is on
-    the host, flush() / close() wait for the files; at most `max_pending` frames are held in memory.  png_level /
+    the host, flush() / close() wait for the files; at most `max_pending` FILES (two per frame with a distance map) wait
+    in memory.  png_level /
     gz_level trade file size for time; the defaults give the very bytes of tests/golden/."""
 
     def __init__(self, root: str, image_dir: str = "images", depth_dir: str = "depth", stem: str = "frame",
@@ -110,15 +111,24 @@ class DatasetWriter:
         self._pending.append(self._pool.submit(job))
 
     def flush(self) -> None:
-        """Wait until every frame handed to write() is on disk (re-raises the first failure)."""
+        """Wait until every frame handed to write() is on disk.  Every pending file is waited for, whatever fails; the
+        first failure is re-raised afterwards."""
+        first = None
         while self._pending:
-            self._pending.pop(0).result()
+            try:
+                self._pending.pop(0).result()
+            except BaseException as e:          # noqa: BLE001 -- kept and re-raised once nothing is pending
+                first = first or e
+        if first is not None:
+            raise first
 
     def close(self) -> None:
-        self.flush()
-        if self._pool is not None:
-            self._pool.shutdown()
-            self._pool = None
+        try:
+            self.flush()
+        finally:                                # a failed file must not leak the executor and its threads
+            if self._pool is not None:
+                self._pool.shutdown()
+                self._pool = None
 
     def __enter__(self):
         return self
@@ -138,14 +148,16 @@ class DatasetWriter:
         a = _to_numpy(rgba)
         if a.ndim != 3 or a.shape[2] != 4:
             raise ValueError(f"expected uint8 [H,W,4], got {a.shape}")
+        d = None
+        if distance is not None:               # both arrays are validated before either file is queued
+            d = _to_numpy(distance)
+            if d.ndim == 2:
+                d = d[:, :, None]
+            if d.ndim != 3 or d.shape[2] != 1:
+                raise ValueError(f"distance must be [H,W] or [H,W,1], got {d.shape}")
         self._put(img_path, lambda x: encode_png_rgba(x, self.png_level), a)
-        if distance is None:
+        if d is None:
             return img_path, None
-        d = _to_numpy(distance)
-        if d.ndim == 2:
-            d = d[:, :, None]
-        if d.ndim != 3 or d.shape[2] != 1:
-            raise ValueError(f"distance must be [H,W] or [H,W,1], got {d.shape}")
         self._put(dep_path, lambda x: encode_npy_gz(x, self.gz_level), d)
         return img_path, dep_path
 

@@ -97,6 +97,8 @@ def project_color_fwd_raw(means, quats, scales, opacities, sh_degree, sh_coeffs,
     depths = torch.empty(n, dtype=torch.float32, device=dev)
     opac = torch.empty(n, dtype=torch.float32, device=dev) if antialiased else None
     splats = torch.empty(n, 12, dtype=torch.float32, device=dev) if want_splats else None
+    if splats is not None:
+        _splat_annotation.pop(splats.data_ptr(), None)     # fresh records: no binning's slot words in them
     seed = None
     if bin_seed is not None and n > 0:
         seed = (torch.empty(n, 2, dtype=torch.int32, device=dev),
@@ -124,6 +126,13 @@ class TileLists:
 
 _workspaces: dict = {}
 
+# mgs_isect_tiles(splat_slots=) writes a binning's record slots into words 10-11 of the caller's splat records IN PLACE:
+# the records then belong to THAT binning.  data_ptr of an annotated record tensor -> the generation of the binning that
+# annotated it last; a TileLists remembers (data_ptr, generation) and rasterize_bwd_det_raw trusts the records' slot words
+# only while the pair still matches (otherwise it gathers pair_info, which every TileLists owns).
+_splat_annotation: dict = {}
+_splat_generation = [0]
+
 
 def _workspace(nbytes: int, device) -> Tensor:
     """One growing scratch tensor per (device, stream).  Stream-ordered reuse is safe because
@@ -147,8 +156,9 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
     there (means2d / radii / conics / opacities are then not read and may be None; seed_sums is consumed).
     radii: [N], or planar [2,N] per-axis extents (gsplat >= 1.5's rule).
     splats (with want_pair_info): the packed records [N,12] of project_color_fwd_raw; the pairs' record slots are left in
-    their padding words (include/mgs.h: splat_slots) and the lists say so (`splat_slots`): rasterize_bwd_det_raw then
-    gathers nothing but the record."""
+    their padding words IN PLACE (include/mgs.h: splat_slots) -- the records are tied to this binning from then on -- and the
+    lists remember which tensor they annotated (`splat_slots`): rasterize_bwd_det_raw gathers nothing but the record while
+    that pairing holds, and falls back to pair_info when the records were re-projected or binned again since."""
     n = depths.shape[0]
     dev = depths.device
     L = _lib.lib()
@@ -173,7 +183,11 @@ def isect_tiles_raw(means2d, radii, depths, tile_w, tile_h, capacity: int, cam_i
             ptr(out.flatten_ids), ptr(out.isect_ids), ptr(out.tile_offsets), ptr(out.pair_info),
             ptr(out.group_order), ptr(out.status), ptr(seed[0]) if seed else None, ptr(seed[1]) if seed else None,
             ptr(splats) if (splats is not None and want_pair_info) else None]
-    out.splat_slots = splats is not None and want_pair_info
+    out.splat_slots = False
+    if splats is not None and want_pair_info:
+        _splat_generation[0] += 1
+        _splat_annotation[splats.data_ptr()] = _splat_generation[0]
+        out.splat_slots = (splats.data_ptr(), _splat_generation[0])
     check(L.mgs_isect_tiles(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_isect_tiles(size query)")
     ws = _workspace(nbytes.value, dev)
@@ -441,6 +455,18 @@ def rasterize_bwd_raw(means2d, conics, feats, opacities, background, width, heig
     return v_means2d, v_conics, v_feats, v_opac, v_abs
 
 
+def _splat_slots_valid(tl, splats) -> bool:
+    """The records `splats` carry the record slots of the binning that made `tl` (see _splat_annotation): True for the
+    train-state lists (mgs_render_frames_train annotates its own state), else only when `splats` is the very tensor that
+    binning annotated and no later binning (or projection) has rewritten it."""
+    tag = getattr(tl, "splat_slots", False)
+    if splats is None or not tag:
+        return False
+    if tag is True:
+        return True
+    return tag[0] == splats.data_ptr() and _splat_annotation.get(tag[0]) == tag[1]
+
+
 def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, height, tile_w,
                           tile_h, tl: "TileLists", alphas, last_ids, v_render, v_alphas,
                           absgrad=False, splats=None, canary_bytes=0, expected_render=None,
@@ -467,7 +493,7 @@ def rasterize_bwd_det_raw(means2d, conics, feats, opacities, background, width, 
             ptr(last_ids), ptr(v_render), ptr(v_alphas), ptr(expected_render), ptr(tl.pair_info),
             ptr(getattr(tl, "group_order", None)), tl.capacity,
             ptr(render_out), ptr(checkpoints), int(checkpoint_interval),
-            int(bool(records_only)) | (2 if (splats is not None and getattr(tl, "splat_slots", False)) else 0),
+            int(bool(records_only)) | (2 if _splat_slots_valid(tl, splats) else 0),
             ptr(v_means2d), ptr(v_abs), ptr(v_conics), ptr(v_feats), ptr(v_opac)]
     check(L.mgs_rasterize_bwd_det(*args, None, ctypes.byref(nbytes), stream_handle()),
           "mgs_rasterize_bwd_det(size query)")

@@ -241,7 +241,9 @@ class FrameRenderer:
                     colors, alphas, meta = body(schedule)
                 pool = graph.pool()
             torch.cuda.synchronize(self.dev)
-            variants[schedule] = {"graph": graph, "colors": colors, "alphas": alphas, "meta": meta}
+            # "replayed": a captured graph has recorded its kernels, not run them -- until its first replay its outputs
+            # (the overflow word among them) are whatever the graph pool's memory held
+            variants[schedule] = {"graph": graph, "colors": colors, "alphas": alphas, "meta": meta, "replayed": False}
         first = variants[self.kw["raster_schedule"]]
         return {"stream": stream, "vm": vm, "K": K, "cam": cam, "pose": pose, "variants": variants, "variant": self.kw["raster_schedule"],
                 "graph": first["graph"], "colors": first["colors"], "alphas": first["alphas"], "meta": first["meta"],
@@ -310,6 +312,7 @@ class FrameRenderer:
                 if r is not None:
                     s["pose"]["r"].copy_(torch.from_numpy(r), non_blocking=True)
             s["graph"].replay()
+            s["variants"][s["variant"]]["replayed"] = True
             s["done"].record(s["stream"])
         s["state"] = "submitted"
         return slot
@@ -341,8 +344,10 @@ class FrameRenderer:
 
     def isect_status_max(self) -> int:
         """Largest overflow status word over every slot and both of its graphs (reads them back: call it outside timed
-        regions).  0 = no frame rendered so far needed more tile intersections than the capacity."""
-        return max(int(v["meta"]["isect_status"].max().item()) for s in self._slots for v in s["variants"].values())
+        regions).  0 = no frame rendered so far needed more tile intersections than the capacity.  Only graphs that have
+        been replayed are read: a variant that never ran has never written its status word."""
+        return max((int(v["meta"]["isect_status"].max().item()) for s in self._slots for v in s["variants"].values()
+                    if v["replayed"]), default=0)
 
     def release(self, ticket: int) -> None:
         """Hand the slot back: its next frame will start after everything enqueued so far on the

@@ -222,3 +222,27 @@ def test_heavy_tailed_scene_generator_and_the_fp32_restatement_gate():
     worse[::7, ::5, 0] += 3e-4                                                    # a frame that is farther off than the restatement
     with pytest.raises(AssertionError):
         O.check_frame_against_fp32_port(worse, a32, ref, ra, r32, a32, info["margins"], O.EPS_PATH, info["edge_mask"], what="corrupted")
+
+
+def test_counting_sort_does_not_depend_on_the_team_the_runtime_starts():
+    """The port's parallel counting sort cuts the keys into omp_get_max_threads() slices; when the runtime starts fewer
+    threads than that (OMP_THREAD_LIMIT) every slice must still be counted and scattered: same frame, same counters."""
+    import subprocess
+    import sys
+    code = ("import math, numpy as np\n"
+            "from oracle import cpu_ref\n"
+            "from robosimgs_amd import camera_ring, synthetic_scene\n"
+            "g = synthetic_scene(20_000, math.log(0.05), 3, 0)\n"
+            "cam = camera_ring(1, 256, 256, thetas=[0.3])[0]\n"
+            "r, a, info = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, cam.viewmat(), cam.K, 256, 256, 3)\n"
+            "print(repr(float(np.abs(r).sum())), repr(float(a.sum())), info['n_isect'], info['pair_evals'])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for limit in (None, "3"):
+        env = dict(os.environ, OMP_NUM_THREADS="8", PYTHONPATH=root)
+        env.pop("OMP_THREAD_LIMIT", None)
+        if limit:
+            env["OMP_THREAD_LIMIT"] = limit
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, cwd=root, check=True, capture_output=True,
+                                   text=True).stdout.strip())
+    assert outs[0] == outs[1] and outs[0]
