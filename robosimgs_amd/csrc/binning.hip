@@ -523,7 +523,9 @@ __global__ __launch_bounds__(kDirectThreads) void direct_scatter_kernel(
     tile_offsets[n_tiles] = (int32_t)(total < capacity ? (uint32_t)total : capacity);
     *n_isect = total > 0xffffffffull ? 0xffffffffu : (uint32_t)total;
     *status = total > capacity ? MGS_STATUS_ISECT_OVERFLOW : 0u;
-    if (zero_word) *zero_word = 0u;            // the per-tile sort's count of long lists (tile_sort.hip), instead of a memset
+    // the header of the per-tile sort's list of long tiles (tile_sort.hip: counts of long lists, giant descriptors, pool
+    // entries), instead of a memset
+    if (zero_word) reinterpret_cast<uint4*>(zero_word)[0] = reinterpret_cast<uint4*>(zero_word)[1] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
   const int g0 = blockIdx.x * chunk, g1 = min(n, g0 + chunk);
@@ -816,7 +818,9 @@ extern "C" int mgs_isect_tiles(int n, const float* means2d, const int32_t* radii
   if (n > 0) {        // depth order inside every tile's list (the direct path's lists get their tile ids here)
     const bool grouped = direct && gshift > 0;
     rc = tile_depth_sort(n_tiles, tile_offsets, depths, cap, reinterpret_cast<uint32_t*>(flatten_ids),
-                         direct && (want_tile_ids || isect_ids) ? tile_ids : nullptr, w + ws.tsort, s, grouped ? u32(ws.id_alt) : nullptr,
+                         direct && (want_tile_ids || isect_ids) ? tile_ids : nullptr, w + ws.tsort, s,
+                         /*scratch: the radix ping-pong buffers, dead by now (the direct path's staging is id_alt)*/ u32(ws.tile_alt), u32(ws.id_alt),
+                         grouped ? u32(ws.id_alt) : nullptr,
                          grouped ? reinterpret_cast<const int32_t*>(w + ws.group_offsets) : nullptr, gshift, /*long_list_zeroed=*/direct);
     if (rc) return rc;
   }

@@ -78,14 +78,18 @@ int radix_sort_pairs(const uint32_t* n_dev, uint32_t capacity, int key_bits, uin
 // Orders flatten_ids[offsets[t] .. offsets[t+1]) of every tile by (depth bits, Gaussian id)
 // (tile_sort.hip).  temp: tile_depth_sort_temp_bytes(capacity).
 size_t tile_depth_sort_temp_bytes(uint32_t capacity, int n_tiles);
-// first word of the list of long tiles inside `temp` (a counter: it must be zero when tile_depth_sort starts)
+// first word of the list of long tiles inside `temp` (a header of eight counters, 16-byte aligned: they must be zero when
+// tile_depth_sort starts)
 uint32_t* tile_depth_sort_long_list(void* temp, uint32_t capacity);
 // tile_ids_fill (may be null): also stores every entry's tile id (the direct binning path has not written them).
 // staging / group_offsets / group_shift (staging may be null): the lists arrive grouped, 2^group_shift tiles per
 // segment of `staging`, and the kernel also WRITES tile_offsets (see tile_sort.hip).
-// long_list_zeroed: an earlier kernel of the caller has stored the zero (otherwise a 4-byte memset is enqueued).
+// long_list_zeroed: an earlier kernel of the caller has stored the zeros (otherwise a 32-byte memset is enqueued).
+// scratch_k / scratch_i: two more arrays of `capacity` words that nobody reads once the per-tile sort's first launch is
+// done (scratch_i may be `staging`): scratch of the kernel that sorts the units of long lists; null: no list is deferred.
 int tile_depth_sort(int n_tiles, const int32_t* tile_offsets, const float* depths, uint32_t capacity,
                     uint32_t* flatten_ids, uint32_t* tile_ids_fill, void* temp, hipStream_t stream,
+                    uint32_t* scratch_k, uint32_t* scratch_i,
                     const uint32_t* staging = nullptr, const int32_t* group_offsets = nullptr, int group_shift = 0,
                     bool long_list_zeroed = false);
 

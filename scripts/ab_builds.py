@@ -2,6 +2,7 @@
 with extra flags): kernel-alone times of the forward stages and frames/s with three frames in flight, the two builds
 taking turns so that clock drift hits both alike.
     python scripts/ab_builds.py raster_fwd.hip "-DMGS_RASTER_CLOSE_BRANCH=1" [tile_sort.hip "-D..."]
+VARIANT_LIB=<path of a libmgs.so built from another tree>: that library is B (nothing is compiled); SCENE=4k | heavy.
 """
 import math, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,10 @@ for src, fl in pairs:
     subprocess.run([B._hipcc(), *B.FLAGS, *B.PER_SOURCE_FLAGS.get(src, []), *fl.split(), "-c", os.path.join(B.HERE, src), "-o", obj], check=True)
     objs[src] = obj
 VAR = os.path.join(B.HERE, "libmgs_variant.so")
-subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs.values(), "-o", VAR], check=True)
+if os.environ.get("VARIANT_LIB"):
+    VAR = os.path.abspath(os.environ["VARIANT_LIB"])
+else:
+    subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs.values(), "-o", VAR], check=True)
 libs = {"A (shipped)": _lib._load(), "B (variant)": _lib._load(VAR)}
 
 # (SCENE=4k: configs[4] -- 5 M Gaussians at 3840x2160, the capacity bench.py's leg uses there)
@@ -27,7 +31,11 @@ if os.environ.get("SCENE") == "4k":
 else:
     n, mu, W, H, deg = 1_000_000, 0.012, 1920, 1080, 3
 dev = "cuda"
-g = synthetic_scene(n, math.log(mu), deg, 0)
+if os.environ.get("SCENE") == "heavy":
+    from robosimgs_amd import synthetic_scene_heavy_tailed
+    g = synthetic_scene_heavy_tailed(n, sh_degree=deg, seed=0)
+else:
+    g = synthetic_scene(n, math.log(mu), deg, 0)
 if os.environ.get("MORTON", "1") != "0":
     g = g.sorted_by_locality()
 cam = camera_ring(1, W, H, thetas=[0.3])[0]
@@ -35,7 +43,7 @@ t = g.to_torch(dev, deg)
 vm = torch.from_numpy(cam.viewmat().astype(np.float32)).to(dev)
 K = torch.from_numpy(cam.K.astype(np.float32)).to(dev)
 tw, th = -(-W // 16), -(-H // 16)
-CAP = int(os.environ.get("CAP", 30_100_000 if os.environ.get("SCENE") == "4k" else 4_700_000))
+CAP = int(os.environ.get("CAP", 30_100_000 if os.environ.get("SCENE") == "4k" else (6_400_000 if os.environ.get("SCENE") == "heavy" else 4_700_000)))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 def timed(fn, reps):

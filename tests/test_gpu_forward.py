@@ -188,6 +188,53 @@ def test_tile_depth_order_uneven_lists_under_each_capacity_rule(ops, per_list, t
     assert int(tl.tile_offsets[tw * th]) == n
 
 
+@pytest.mark.parametrize("n,tw,th,kind,opts", [(30_000, 7, 6, "uniform", 0), (30_000, 7, 6, "clustered", 0), (9_500, 9, 5, "bimodal", 0),
+                                               (20_000, 3, 2, "clustered", 4), (20_000, 3, 2, "outliers", 0), (70_000, 2, 1, "equal", 0)])
+def test_giant_lists_are_spread_over_the_chip(ops, n, tw, th, kind, opts):
+    """Lists over 8,192 entries take the cooperative path of csrc/tile_sort.hip (descriptor + pool, collect kernel, units of
+    whole buckets in the long kernel).  Cases: 42 giant tiles of 28 k entries (more than the 32 descriptors and more than
+    the 1 M-entry pool: the rest falls back to the long kernel's generic path), 45 giant tiles of which 32 get a descriptor,
+    two depth clusters far apart (most buckets empty), the radix partition (debug knob 4: ungrouped lists), a
+    sample that misses the outliers (the bucket function clamps) and 70 k identical depths (one bucket holds everything:
+    the unit is the whole list, ordered by index).  Lists bit-identical to the stable sort on (tile, depth bits)."""
+    from robosimgs_amd import _lib
+    rng = np.random.default_rng(n + tw + len(kind))
+    w, h = 16 * tw, 16 * th
+    means2d = rng.uniform(0, 1, size=(n, 2)).astype(np.float32) * np.float32([w, h])
+    radii = np.full(n, 16 * max(tw, th), np.int32)         # every Gaussian covers every tile
+    radii[rng.random(n) < 0.05] = 0
+    if kind == "uniform":
+        depths = rng.uniform(0.5, 20.0, size=n).astype(np.float32)
+    elif kind == "clustered":
+        base = rng.choice(np.array([4.0, 4.0001, 4.0002, 6.5], np.float32), size=n)
+        depths = (base + rng.integers(0, 300, size=n).astype(np.float32) * np.float32(4.76837158203125e-07)).astype(np.float32)
+        depths[0], depths[1] = 0.011, 9.0e9
+    elif kind == "bimodal":
+        depths = np.where(rng.random(n) < 0.4, rng.normal(2.0, 0.01, n), rng.normal(9000.0, 3.0, n)).astype(np.float32)
+    elif kind == "outliers":
+        depths = rng.uniform(3.0, 3.5, size=n).astype(np.float32)
+        depths[n - 200:] = rng.uniform(0.02, 4.0e8, size=200).astype(np.float32)      # none among a list's first entries
+    else:
+        depths = np.full(n, 3.25, np.float32)
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, tw, th, dtype=np.float32)
+    total = len(r_flat)
+    assert total > 8192 * tw * th
+    _dbg = _lib.use_debug_lib()
+    lib = _dbg.__enter__()
+    try:
+        lib.mgs_debug_set_sort_opts(opts)
+        for _ in range(2):                                  # (the second call finds the first one's descriptors in the workspace)
+            tl = ops.isect_tiles_raw(_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), tw, th, total + 16, want_isect_ids=True)
+            assert int(tl.n_isect.item()) == total and int(tl.status.item()) == 0
+            np.testing.assert_array_equal(tl.flatten_ids[:total].cpu().numpy(), r_flat)
+            np.testing.assert_array_equal(tl.isect_ids[:total].cpu().numpy(), r_ids)
+            np.testing.assert_array_equal(tl.tile_ids[:total].cpu().numpy(), (r_ids >> 32).astype(np.int32))
+            np.testing.assert_array_equal(tl.tile_offsets[:tw * th].cpu().numpy(), O.isect_offsets(r_ids, 1, tw, th).reshape(-1))
+    finally:
+        lib.mgs_debug_set_sort_opts(0)
+        _dbg.__exit__(None, None, None)
+
+
 def test_isect_tiles_empty_and_overflow(ops):
     from robosimgs_amd import _lib
     w = h = 64
