@@ -747,6 +747,57 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
 #undef MGS_RB_ARGS
 }
 
+// ---- rectangles of kBigPairs tiles and more (round 6) ---------------------------------------------------------------------
+// reduce_records_rows_kernel hands a wave 64 Gaussians and deals their rectangles' rows to its lanes: fine for rectangles
+// of a dozen tiles, but a needle's bounding box of 50 x 50 tiles or a screen-filling Gaussian's 120 x 68 are thousands of
+// slots, and where an export keeps such Gaussians together in the index range a few hundred waves own all of them (a
+// clustered scene: 410 us as given, 185 us in Morton order, against 49 us for the uniform scene).  Such a Gaussian is
+// ONE WAVE's job instead, wherever it sits: a launch that runs before the raster lists them (big_discover: extra
+// workgroups of unit_table_kernel, kBigLists lists so that no counter is hot), the reduce launch starts with kBigWaves
+// waves that take them one at a time -- lanes = rows, the rows then added in row order by NV lanes -- and its other waves
+// skip them.  The order of the additions is the one of the rows kernel (within a row by column, then the rows): the same
+// bits.
+#ifndef MGS_REDUCE_BIG
+#define MGS_REDUCE_BIG 256
+#endif
+#ifndef MGS_REDUCE_BIG_WGS
+#define MGS_REDUCE_BIG_WGS 1024
+#endif
+constexpr int kBigPairs = MGS_REDUCE_BIG, kBigLists = 64, kBigWGs = MGS_REDUCE_BIG_WGS, kDiscoverPerThread = 16;
+__host__ __device__ inline uint32_t big_list_room(uint32_t capacity) { return capacity / (uint32_t)kBigPairs + 1u; }
+__host__ __device__ inline size_t big_lists_bytes(uint32_t capacity) { return (size_t)kBigLists * big_list_room(capacity) * sizeof(uint32_t); }
+
+// counts: kBigLists words (zeroed by the caller's memset); items: kBigLists lists of big_list_room(capacity) Gaussian ids
+__device__ __forceinline__ void big_discover(int wg, int n, const int4* __restrict__ pair_info, uint32_t capacity,
+                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ items) {
+  const int t = threadIdx.x;
+  const uint32_t list = (uint32_t)(wg * 4 + (t >> 6)) % kBigLists, room = big_list_room(capacity);
+  int4 info[kDiscoverPerThread];
+#pragma unroll
+  for (int j = 0; j < kDiscoverPerThread; ++j) {
+    const int g = (wg * kDiscoverPerThread + j) * 256 + t;
+    info[j] = g < n ? pair_info[g] : make_int4(0, 0, 0, 0);
+  }
+  // one returning atomic per wave, whatever it found (sixteen dependent ones took the kernel from 6 to 16 us)
+  unsigned long long mm[kDiscoverPerThread];
+  uint32_t run[kDiscoverPerThread], wave_total = 0;
+#pragma unroll
+  for (int j = 0; j < kDiscoverPerThread; ++j) {
+    mm[j] = ballot((info[j].w & 0xffff) * (int)((unsigned)info[j].w >> 16) >= kBigPairs);
+    run[j] = wave_total;
+    wave_total += (uint32_t)__popcll(mm[j]);
+  }
+  if (wave_total == 0u) return;                         // (uniform; nearly every wave)
+  uint32_t base = 0;
+  if ((t & 63) == 0) base = atomicAdd(&counts[list], wave_total);
+  base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+  for (int j = 0; j < kDiscoverPerThread; ++j) {
+    const uint32_t at = base + run[j] + mask_rank(mm[j]);
+    if (((mm[j] >> (t & 63)) & 1ull) && at < room) items[(size_t)list * room + at] = (uint32_t)((wg * kDiscoverPerThread + j) * 256 + t);
+  }
+}
+
 // SPLIT: the units of the segmented launch, one thread per tile: the segments some pixel of the tile reaches (the forward
 // left the end of the tile's walk in the checkpoint header).  WHOLE segments go to one table (a cursor per workgroup
 // scan), every tile's last, partly walked segment to the table of its length class (32 classes, longest first); the
@@ -754,10 +805,17 @@ __global__ __launch_bounds__(64 * MGS_RASTER_BWD_WG_WAVES, (CHT <= 4 && RECORDS 
 // whole segments cost about the same, so with the short ones at the end of the launch the chip drains in the time of
 // a short unit instead of a whole one (a unit is one wave's serial job; scripts/dbg/bwd_timeline.py).
 // counts[0] = whole segments, counts[1 + c] = partial segments of class c: zeroed by the caller's memset.
+// Workgroups past the tiles' (n_big_wgs of them): big_discover.
 __global__ __launch_bounds__(256) void unit_table_kernel(int n_tiles, const int32_t* __restrict__ tile_offsets,
                                                          const int32_t* __restrict__ tile_hi, int shift, uint32_t capacity,
-                                                         int32_t* __restrict__ tables) {
+                                                         int32_t* __restrict__ tables, int n, const int4* __restrict__ pair_info,
+                                                         uint32_t* __restrict__ big_counts, uint32_t* __restrict__ big_items) {
   __shared__ uint32_t wave_tot[4], base, cls_n[kUnitClasses], cls_at[kUnitClasses];
+  const int n_tile_wgs = (n_tiles + 255) / 256;
+  if ((int)blockIdx.x >= n_tile_wgs) {
+    big_discover((int)blockIdx.x - n_tile_wgs, n, pair_info, capacity, big_counts, big_items);
+    return;
+  }
   const UnitTables ut = unit_tables(tables, n_tiles, shift, capacity);
   const int tile = blockIdx.x * 256 + threadIdx.x, t = threadIdx.x;
   if (t < kUnitClasses) cls_n[t] = 0u;
@@ -797,6 +855,11 @@ __global__ __launch_bounds__(256) void unit_table_kernel(int n_tiles, const int3
   at += base;
   for (int sg = 0; sg + 1 < n_seg; ++sg) ut.whole[at + sg] = make_int4(tile, sg, u_start, u_hi);
   if (n_seg > 0) ut.part[(size_t)c * n_tiles + cls_at[c] + rank] = make_int4(tile, n_seg - 1, u_start, u_hi);
+}
+// (the whole-list walk has no unit tables: the discovery alone)
+__global__ __launch_bounds__(256) void big_discover_kernel(int n, const int4* __restrict__ pair_info, uint32_t capacity,
+                                                           uint32_t* __restrict__ big_counts, uint32_t* __restrict__ big_items) {
+  big_discover((int)blockIdx.x, n, pair_info, capacity, big_counts, big_items);
 }
 
 // Sum the records of each Gaussian's slots (its tile rectangle, emit order) into the outputs.  A record holds the
@@ -933,7 +996,8 @@ __global__ __launch_bounds__(256) void reduce_records_rows_kernel(
     const float* __restrict__ conics, const float* __restrict__ opacities,
     const float4* __restrict__ splats, int channels, float* __restrict__ v_means2d,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
-    float* __restrict__ v_feats, float* __restrict__ v_opacities) {
+    float* __restrict__ v_feats, float* __restrict__ v_opacities,
+    const uint32_t* __restrict__ big_counts, const uint32_t* __restrict__ big_items) {
   constexpr int RSP = record_floats(CHT, ABSGRAD), R4 = RSP / 4, NV = 6 + CHT + (ABSGRAD ? 2 : 0);
   constexpr int PITCH = NV | 1;                       // odd pitch: the lanes' row sums fall into different banks
   __shared__ int s_row0[4][64];                       // first row (task) of each Gaussian of the wave
@@ -941,6 +1005,117 @@ __global__ __launch_bounds__(256) void reduce_records_rows_kernel(
   __shared__ float2 s_mean[4][64];
   __shared__ float s_rows[4][64 * PITCH];
   const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+  const float4* rec4 = reinterpret_cast<const float4*>(records);
+  // one row of a rectangle: its slots' moments about the mean and colour gradients, added column by column
+  auto row_sum = [&](const int4 oi, const float2 om, const int r, float (&rs)[NV]) {
+    const int ow = oi.w & 0xffff;
+    const uint32_t slot0 = (uint32_t)oi.x + (uint32_t)(r * ow);
+    const float my = om.y - ((float)((oi.z + r) * 16) + 8.f);     // m exactly as the raster kernel formed it
+    constexpr int TR = MGS_REDUCE_TRIP;
+    // the flags of a trip out of the two aligned words that hold them (slots at or past the capacity -- overflowed lists --
+    // do not exist and lie outside the workspace); fetched one trip AHEAD: a trip is then one round trip (its records)
+    // instead of two dependent ones -- a 120-tile row of a screen-filling Gaussian is 30 trips
+    auto trip_flags = [&](const uint32_t s0) -> uint32_t {
+      const uint32_t a0 = s0 & ~3u, sh = (s0 & 3u) * 8u;
+      const uint32_t w0 = a0 < capacity ? *reinterpret_cast<const uint32_t*>(flags + a0) : 0u;
+      const uint32_t w1 = (sh && a0 + 4u < capacity) ? *reinterpret_cast<const uint32_t*>(flags + a0 + 4u) : 0u;
+      return sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
+    };
+    uint32_t fw_next = trip_flags(slot0);
+    for (int c0 = 0; c0 < ow; c0 += TR) {
+      const uint32_t s0 = slot0 + (uint32_t)c0;
+      const uint32_t fw = fw_next;
+      if (c0 + TR < ow) fw_next = trip_flags(s0 + (uint32_t)TR);
+      bool on[TR];
+      float rr[TR][RSP];
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        on[i] = c0 + i < ow && s0 + (uint32_t)i < capacity && ((fw >> (8 * i)) & 0xffu) != 0;
+#pragma unroll
+        for (int k = 0; k < R4; ++k) {
+          const float4 v = on[i] ? rec4[(size_t)(s0 + (uint32_t)i) * R4 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+          rr[i][4 * k] = v.x; rr[i][4 * k + 1] = v.y; rr[i][4 * k + 2] = v.z; rr[i][4 * k + 3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TR; ++i) {
+        const float mx = om.x - ((float)((oi.y + c0 + i) * 16) + 8.f);
+        float P, Q, Vaa, Vab, Vbb;
+        moments_to_mean(mx, my, rr[i][0], rr[i][1], rr[i][2], rr[i][3], rr[i][4], rr[i][5], P, Q, Vaa, Vab, Vbb);
+        rs[0] += P; rs[1] += Q; rs[2] += Vaa; rs[3] += Vab; rs[4] += Vbb; rs[5] += rr[i][0];
+#pragma unroll
+        for (int c = 0; c < CHT; ++c) rs[6 + c] += rr[i][6 + c];
+        if constexpr (ABSGRAD) { rs[6 + CHT] += rr[i][6 + CHT]; rs[7 + CHT] += rr[i][7 + CHT]; }
+      }
+    }
+  };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  if ((int)blockIdx.x < kBigWGs) {
+    // ---- the big rectangles: one wave each ------------------------------------------------------------------------------
+    const uint32_t room = big_list_room(capacity);
+    uint32_t cnt = lane < kBigLists ? big_counts[lane] : 0u;      // (kBigLists == 64: one list per lane)
+    cnt = cnt < room ? cnt : room;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    for (uint32_t k = (uint32_t)blockIdx.x * 4u + (uint32_t)wv; k < total; k += (uint32_t)kBigWGs * 4u) {
+      const int l = __ffsll((long long)ballot(incl > k)) - 1;      // the list that holds item k
+      const uint32_t first = __shfl(incl - cnt, l);
+      const int g = (int)big_items[(size_t)l * room + (k - first)];
+      const int4 oi = pair_info[g];
+      const int h = (int)((unsigned)oi.w >> 16);
+      float2 om;
+      float ca, cb, cc, op;
+      if (splats) {
+        const float4 p0 = splats[3 * (size_t)g], p1 = splats[3 * (size_t)g + 1];
+        om = make_float2(p0.x, p0.y); ca = p0.z; cb = p0.w; cc = p1.x; op = p1.y;
+      } else {
+        om = make_float2(means2d[2 * (size_t)g], means2d[2 * (size_t)g + 1]);
+        ca = conics[3 * (size_t)g]; cb = conics[3 * (size_t)g + 1]; cc = conics[3 * (size_t)g + 2];
+        op = opacities[g];
+      }
+      float acc = 0.f;                                              // lane i < NV: component i, the rows in row order
+      for (int base = 0; base < h; base += 64) {
+        float rs[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rs[i] = 0.f;
+        if (base + lane < h) row_sum(oi, om, base + lane, rs);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s_rows[wv][lane * PITCH + i] = rs[i];
+        wave_sync();
+        const int rows = min(64, h - base);
+        if (lane < NV)
+          for (int t2 = 0; t2 < rows; ++t2) acc += s_rows[wv][t2 * PITCH + lane];
+        __builtin_amdgcn_wave_barrier();                            // the next round overwrites s_rows
+      }
+      float a[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) a[i] = __shfl(acc, i);
+      finish_geo(ca, cb, cc, a[0], a[1], a[2], a[4]);
+      a[5] = op > 0.f ? -a[5] / op : 0.f;
+      if (lane == 0) {
+        reinterpret_cast<float2*>(v_means2d)[g] = make_float2(a[0], a[1]);
+        v_conics[3 * (size_t)g + 0] = a[2];
+        v_conics[3 * (size_t)g + 1] = a[3];
+        v_conics[3 * (size_t)g + 2] = a[4];
+        v_opacities[g] = a[5];
+#pragma unroll
+        for (int c = 0; c < CHT; ++c)
+          if (c < channels) v_feats[(size_t)g * channels + c] = a[6 + c];
+        if constexpr (ABSGRAD) reinterpret_cast<float2*>(v_means2d_abs)[g] = make_float2(a[6 + CHT], a[7 + CHT]);
+      }
+    }
+    return;
+  }
+  const int block = (int)blockIdx.x - kBigWGs, n_blocks = (int)gridDim.x - kBigWGs;
   // Which 64 Gaussians a wave owns: four RUNS of MGS_REDUCE_RUN consecutive ones, a whole launch of waves apart (run r
   // of wave W is run r * n_waves + W of the index space) instead of 64 consecutive.  Large rectangles that sit together
   // in the index range -- appended by a densifier, neighbours in a Morton order -- then land in many waves, each with a
@@ -950,20 +1125,23 @@ __global__ __launch_bounds__(256) void reduce_records_rows_kernel(
   // 0.779 / 0.777; a clustered scene as given 1.526 / 1.460 / 1.397 / 1.376, in Morton order 1.082 / 1.056 / 1.002 / 0.998.
 #if MGS_REDUCE_RUN > 0
   constexpr int kRun = MGS_REDUCE_RUN, kRunsPerWave = 64 / kRun;
-  const int wave_global = blockIdx.x * 4 + wv, n_waves = (int)gridDim.x * 4;
+  const int wave_global = block * 4 + wv, n_waves = n_blocks * 4;
   const long long g_ll = ((long long)(lane / kRun) * n_waves + wave_global) * kRun + lane % kRun;
   const int g = g_ll < n ? (int)g_ll : n;
   static_assert(64 % kRun == 0 && kRunsPerWave >= 1, "runs of a power of two up to 64");
 #else
-  const int g = blockIdx.x * 256 + (int)threadIdx.x;
+  const int g = block * 256 + (int)threadIdx.x;
 #endif
   int4 info = make_int4(0, 0, 0, 0);
   int h = 0;
+  bool is_big = false;
   float mean_x = 0.f, mean_y = 0.f, ca = 1.f, cb = 0.f, cc = 1.f, op = 1.f;
   if (g < n) {
     info = pair_info[g];
     h = (int)((unsigned)info.w >> 16);
     if ((info.w & 0xffff) == 0) h = 0;
+    is_big = (info.w & 0xffff) * h >= kBigPairs;        // (a wave of the launch's first workgroups takes it)
+    if (is_big) h = 0;
     if (h > 0) {
       if (splats) {
         const float4 p0 = splats[3 * (size_t)g], p1 = splats[3 * (size_t)g + 1];
@@ -988,7 +1166,6 @@ __global__ __launch_bounds__(256) void reduce_records_rows_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const float4* rec4 = reinterpret_cast<const float4*>(records);
   float acc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0.f;
@@ -1002,41 +1179,7 @@ __global__ __launch_bounds__(256) void reduce_records_rows_kernel(
 #pragma unroll
       for (int step = 32; step >= 1; step >>= 1)
         if (s_row0[wv][o + step] <= t) o += step;     // (o + step <= 63)
-      const int4 oi = s_info[wv][o];
-      const float2 om = s_mean[wv][o];
-      const int ow = oi.w & 0xffff, r = t - s_row0[wv][o];
-      const uint32_t slot0 = (uint32_t)oi.x + (uint32_t)(r * ow);
-      const float my = om.y - ((float)((oi.z + r) * 16) + 8.f);     // m exactly as the raster kernel formed it
-      constexpr int TR = MGS_REDUCE_TRIP;
-      for (int c0 = 0; c0 < ow; c0 += TR) {
-        // the flags of the trip out of the two aligned words that hold them (slots at or past the capacity --
-        // overflowed lists -- do not exist and lie outside the workspace)
-        const uint32_t s0 = slot0 + (uint32_t)c0, a0 = s0 & ~3u, sh = (s0 & 3u) * 8u;
-        const uint32_t w0 = a0 < capacity ? *reinterpret_cast<const uint32_t*>(flags + a0) : 0u;
-        const uint32_t w1 = (sh && a0 + 4u < capacity) ? *reinterpret_cast<const uint32_t*>(flags + a0 + 4u) : 0u;
-        const uint32_t fw = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
-        bool on[TR];
-        float rr[TR][RSP];
-#pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          on[i] = c0 + i < ow && s0 + (uint32_t)i < capacity && ((fw >> (8 * i)) & 0xffu) != 0;
-#pragma unroll
-          for (int k = 0; k < R4; ++k) {
-            const float4 v = on[i] ? rec4[(size_t)(s0 + (uint32_t)i) * R4 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-            rr[i][4 * k] = v.x; rr[i][4 * k + 1] = v.y; rr[i][4 * k + 2] = v.z; rr[i][4 * k + 3] = v.w;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          const float mx = om.x - ((float)((oi.y + c0 + i) * 16) + 8.f);
-          float P, Q, Vaa, Vab, Vbb;
-          moments_to_mean(mx, my, rr[i][0], rr[i][1], rr[i][2], rr[i][3], rr[i][4], rr[i][5], P, Q, Vaa, Vab, Vbb);
-          rs[0] += P; rs[1] += Q; rs[2] += Vaa; rs[3] += Vab; rs[4] += Vbb; rs[5] += rr[i][0];
-#pragma unroll
-          for (int c = 0; c < CHT; ++c) rs[6 + c] += rr[i][6 + c];
-          if constexpr (ABSGRAD) { rs[6 + CHT] += rr[i][6 + CHT]; rs[7 + CHT] += rr[i][7 + CHT]; }
-        }
-      }
+      row_sum(s_info[wv][o], s_mean[wv][o], t - s_row0[wv][o], rs);
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) s_rows[wv][lane * PITCH + i] = rs[i];
@@ -1051,7 +1194,7 @@ __global__ __launch_bounds__(256) void reduce_records_rows_kernel(
     }
     __builtin_amdgcn_wave_barrier();                  // the next round overwrites s_rows
   }
-  if (g >= n) return;
+  if (g >= n || is_big) return;
   if (h > 0) {      // apply the Gaussian's conic once, here; opacity * d/d opacity = -sum v_sigma
     finish_geo(ca, cb, cc, acc[0], acc[1], acc[2], acc[4]);
     acc[5] = op > 0.f ? -acc[5] / op : 0.f;
@@ -1164,7 +1307,13 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   // counters first: zeroed together with the flags)
   const size_t order_bytes = align_up(std::max((size_t)tile_w * tile_h * sizeof(int32_t),
                                                checkpoints ? unit_tables_bytes(tile_w * tile_h, ckpt_shift, (uint32_t)cap) : 0), 256);
-  const size_t need = rec_bytes + flag_bytes + order_bytes;
+  // the lists of big rectangles (reduce_records_rows_kernel): their kBigLists counters right behind the flags (zeroed with
+  // them), the items at the end
+  constexpr size_t big_hdr = 256;
+  static_assert(kBigLists * sizeof(uint32_t) <= big_hdr, "the big lists' counters fit their header");
+  const bool big_path = MGS_REDUCE_ROWS && channels <= 4 && kSlots == 1;
+  const size_t big_bytes = big_path ? align_up(big_lists_bytes((uint32_t)cap), 256) : 0;
+  const size_t need = rec_bytes + flag_bytes + big_hdr + order_bytes + big_bytes;
   if (!workspace) {
     *workspace_bytes = need;
     return MGS_OK;
@@ -1188,24 +1337,30 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   hipStream_t s = (hipStream_t)stream;
   float* records = static_cast<float*>(workspace);
   uint8_t* flags = static_cast<uint8_t*>(workspace) + rec_bytes;
-  hipError_t e = hipMemsetAsync(flags, 0, flag_bytes + (split ? 256 : 0), s);
+  uint32_t* big_counts = reinterpret_cast<uint32_t*>(flags + flag_bytes);
+  uint32_t* big_items = reinterpret_cast<uint32_t*>(flags + flag_bytes + big_hdr + order_bytes);
+  hipError_t e = hipMemsetAsync(flags, 0, flag_bytes + big_hdr + (split ? 256 : 0), s);
   if (e != hipSuccess) return set_error((int)e, "rasterize_bwd_det: memset: %s", hipGetErrorString(e));
   const int4* info = reinterpret_cast<const int4*>(pair_info);
   const int32_t* order = nullptr;
   int32_t* seg_table = nullptr;
   if (split) {
-    seg_table = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes);
-    hipLaunchKernelGGL(unit_table_kernel, dim3(div_up(n_tiles, 256)), dim3(256), 0, s, n_tiles, tile_offsets,
-                       reinterpret_cast<const int32_t*>(checkpoints), ckpt_shift, (uint32_t)cap, seg_table);
+    seg_table = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes + big_hdr);
+    // (+ the workgroups that list the big rectangles for the reduce)
+    const unsigned n_disc = big_path && !records_only ? div_up(n, 256 * kDiscoverPerThread) : 0;
+    hipLaunchKernelGGL(unit_table_kernel, dim3(div_up(n_tiles, 256) + n_disc), dim3(256), 0, s, n_tiles, tile_offsets,
+                       reinterpret_cast<const int32_t*>(checkpoints), ckpt_shift, (uint32_t)cap, seg_table, n, info, big_counts, big_items);
   } else if (!kHalf && MGS_RASTER_BWD_ORDER) {
     order = tile_group_order;
     if (!order) {       // the caller's lists came without one (mgs_isect_tiles writes it): compute it here
-      int32_t* mine = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes);
+      int32_t* mine = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(workspace) + rec_bytes + flag_bytes + big_hdr);
       const int rc = launch_tile_group_order(n_tiles, tile_offsets, mine, s);
       if (rc) return rc;
       order = mine;
     }
   }
+  if (!split && big_path && !records_only)
+    hipLaunchKernelGGL(big_discover_kernel, dim3(div_up(n, 256 * kDiscoverPerThread)), dim3(256), 0, s, n, info, (uint32_t)cap, big_counts, big_items);
   // (segmented: whole blocks of the XCD-aware unit numbering; units past the live count leave at once)
   const int n_units = split ? (int)((n_seg_units + 8 * MGS_RASTER_BWD_XCD_RUN - 1) / (8 * MGS_RASTER_BWD_XCD_RUN)) * 8 * MGS_RASTER_BWD_XCD_RUN
                             : order ? (n_tiles + 3) / 4 * 4 : n_tiles * (int)kSlots;
@@ -1221,10 +1376,10 @@ extern "C" int mgs_rasterize_bwd_det(int n, const float* means2d, const float* c
   if (split) MGS_RD_RASTER(C, A, ((C) <= 4 && !kHalf)); else MGS_RD_RASTER(C, A, false);        \
   if (!records_only) {                                                                          \
     if constexpr (MGS_REDUCE_ROWS && (C) <= 4 && kSlots == 1)                                   \
-      hipLaunchKernelGGL((reduce_records_rows_kernel<((C) <= 4 ? (C) : 4), A>), dim3(div_up(n, 256)), dim3(256), 0, s, n, \
+      hipLaunchKernelGGL((reduce_records_rows_kernel<((C) <= 4 ? (C) : 4), A>), dim3(kBigWGs + div_up(n, 256)), dim3(256), 0, s, n, \
                          info, records, flags, (uint32_t)cap, means2d, conics, opacities,      \
                          reinterpret_cast<const float4*>(splats),                              \
-                         channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities);  \
+                         channels, v_means2d, v_means2d_abs, v_conics, v_feats, v_opacities, big_counts, big_items);  \
     else                                                                                        \
       hipLaunchKernelGGL((reduce_records_kernel<C, A, (int)kSlots>), dim3(div_up(n, 256)), dim3(256), 0, s, n,   \
                          info, records, flags, (uint32_t)cap, means2d, conics, opacities,      \
