@@ -37,6 +37,8 @@ def _bind(path):
     L = ctypes.CDLL(path)
     L.gs_cpu_render.restype = ctypes.c_longlong
     L.gs_cpu_render_f64.restype = ctypes.c_longlong
+    L.gs_cpu_blend_f64.restype = ctypes.c_longlong
+    L.gs_cpu_blend_f32.restype = ctypes.c_longlong
     L.gs_cpu_max_threads.restype = ctypes.c_int
     return L
 
@@ -170,3 +172,80 @@ def render_f64(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, he
     if want_projected:
         info.update(means2d=om, conics=oc, feats=of_, radii=orad)
     return out, alpha, info
+
+
+def blend_f64(means2d, conics, opacities, feats, flatten_ids, tile_offsets, width, height, depths=None, background=None,
+              n_threads=0, margins=True, flip_eps=None, v_render=None, v_alpha=None, want_budget=False, thresholds=None):
+    """STAGE-ISOLATED blend: SURVEY.md A.2 steps 9-10 in fp64 on GIVEN fp32 projected quantities and depth-ordered tile
+    lists -- e.g. the GPU's own means2d / conics / opacities / feats / flatten_ids / tile_offsets, read back -- so that a
+    blend kernel can be held to zero unexplained pixels whatever rounding the projection did upstream.
+    feats [N,ch] (ch = 3 or 4; the fourth channel is the plain depth sum, not divided), flatten_ids [n_isect] int32,
+    tile_offsets [tiles + 1] int32 (tiles of 16 px, row-major).  depths [N]: only for the depth-tie margin (None: no such
+    margin; with given lists the order is given).  Returns (render [H,W,ch] f32, alpha [H,W] f32, info) with info as
+    render_f64's: margins [4,H,W], flip_weight [H,W] + feat_max (flip_eps), edge_mask (all False: membership is given),
+    noise_weight [H,W] (what sigma's rounding alone can move the pixel by, as a blend weight: gs_cpu.cpp Extras),
+    g_means2d / g_conics / g_feats / g_opacities (v_render), touched / budget (want_budget)."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    m2d, con, opa, fe = f(means2d), f(conics), f(opacities), f(feats)
+    n, ch = m2d.shape[0], fe.shape[1]
+    ids = np.ascontiguousarray(flatten_ids, dtype=np.int32)
+    offs = np.ascontiguousarray(tile_offsets, dtype=np.int32)
+    tw, th = -(-width // 16), -(-height // 16)
+    if offs.shape[0] != tw * th + 1 or int(offs[-1]) > ids.shape[0]:
+        raise ValueError("tile_offsets must hold tiles + 1 entries and end inside flatten_ids")
+    if ids.size and (ids[:int(offs[-1])].min() < 0 or ids[:int(offs[-1])].max() >= n):
+        raise ValueError("flatten_ids outside 0..N-1")
+    dep = f(depths) if depths is not None else None
+    out = np.empty((height, width, ch), np.float32)
+    alpha = np.empty((height, width), np.float32)
+    counters = np.zeros(2, np.int64)
+    bg = f(background) if background is not None else None
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    marg = np.empty((4, height, width), np.float32) if margins else None
+    fw = np.empty((height, width), np.float32) if (margins and flip_eps is not None) else None
+    nw = np.empty((height, width), np.float32) if margins else None
+    fe_arr = (np.array([flip_eps["alpha"], flip_eps["T"], flip_eps["sigma"], flip_eps.get("depth", 0.0) if dep is not None else 0.0],
+                       np.float32) if fw is not None else None)
+    edge = np.zeros((height, width), np.uint8) if (want_budget and fw is not None) else None
+    tch = np.zeros(n, np.uint8) if edge is not None else None
+    bwd = v_render is not None
+    if want_budget and (tch is None or not bwd):
+        raise ValueError("want_budget needs margins, flip_eps and v_render")
+    bud = np.zeros((n, 4), np.float64) if want_budget else None
+    vr = f(v_render).reshape(height, width, ch) if bwd else None
+    va = f(v_alpha if v_alpha is not None else np.zeros((height, width))).reshape(height, width) if bwd else None
+    gm, gc, gf, go = ((np.empty((n, 2)), np.empty((n, 3)), np.empty((n, ch)), np.empty(n)) if bwd else (None, None, None, None))
+    n_isect = lib().gs_cpu_blend_f64(
+        n, p(m2d), p(con), p(opa), p(fe), p(dep), p(ids), p(offs), int(width), int(height), ch, p(bg), int(n_threads),
+        p(out), p(alpha), p(counters), p(marg), p(vr), p(va), p(gm), p(gc), p(gf), p(go), p(fw), p(fe_arr), p(edge), p(tch), p(bud),
+        p(np.array(thresholds, np.float32)) if thresholds is not None else None, p(nw))
+    info = {"n_isect": int(n_isect), "pair_evals": int(counters[1])}
+    if margins:
+        info.update(margins=marg, edge_mask=np.zeros((height, width), bool), noise_weight=nw)
+        if fw is not None:
+            listed = np.zeros(n, bool)
+            listed[ids[:int(offs[-1])]] = True
+            info.update(flip_weight=fw, feat_max=(np.abs(fe[listed]).max(axis=0) if listed.any() else np.zeros(ch)))
+            if tch is not None:
+                info["touched"] = tch.astype(bool)
+            if bud is not None:
+                info["budget"] = bud
+    if bwd:
+        info.update(g_means2d=gm, g_conics=gc, g_feats=gf, g_opacities=go)
+    return out, alpha, info
+
+
+def blend_f32(means2d, conics, opacities, feats, flatten_ids, tile_offsets, width, height, background=None, n_threads=0):
+    """blend_f64's inputs through the port's FLOAT instantiation (the reference's formulas in plain fp32): (render, alpha)."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    m2d, con, opa, fe = f(means2d), f(conics), f(opacities), f(feats)
+    ids = np.ascontiguousarray(flatten_ids, dtype=np.int32)
+    offs = np.ascontiguousarray(tile_offsets, dtype=np.int32)
+    ch = fe.shape[1]
+    out = np.empty((height, width, ch), np.float32)
+    alpha = np.empty((height, width), np.float32)
+    bg = f(background) if background is not None else None
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    lib().gs_cpu_blend_f32(m2d.shape[0], p(m2d), p(con), p(opa), p(fe), p(ids), p(offs), int(width), int(height), ch, p(bg),
+                           int(n_threads), p(out), p(alpha))
+    return out, alpha

@@ -211,6 +211,22 @@ struct Extras {            // optional outputs of the double build (all may be n
   double* o_feats = nullptr;       // [N,ch]
   int32_t* o_radii = nullptr;      // [N]  (the x extents under the per-axis rule)
   int radius_rule = 0;             // 0: A.2 step 5; 1: SURVEY.md A.4 (per axis, opacity-aware; classic rasterize mode)
+  // STAGE-ISOLATED BLEND (gs_cpu_blend_f64): the projected quantities and the depth-ordered tile lists are GIVEN (e.g. the
+  // GPU's own fp32 means2d / conics / opacities / feats and its lists, read back): A.2 steps 1-8 are skipped and steps
+  // 9-10 run in F on exactly those inputs -- the answer a blend kernel must reproduce whatever the projection's rounding
+  // did upstream (on an ill-conditioned scene the whole path is only gated relative to an fp32 restatement; this is not).
+  const float* in_means2d = nullptr;       // [N,2]
+  const float* in_conics = nullptr;        // [N,3]
+  const float* in_opac = nullptr;          // [N]
+  const float* in_feats = nullptr;         // [N,ch]
+  const float* in_depths = nullptr;        // [N] (depth-tie margins only; null: none)
+  const int32_t* in_flatten_ids = nullptr; // [n_isect]
+  const int32_t* in_tile_offsets = nullptr;// [tw*th + 1]
+  // noise_weight [H,W] (with margins): sum over the pixel's contributors of SIGMA_ABS S_k alpha_k T_k / (1 - alpha_k) -- what
+  // the rounding of sigma alone (d alpha / alpha = SIGMA_ABS S, see the conditioned margins) can move the pixel by, as a
+  // blend weight (x 2 max|feature|): the SMOOTH part of an fp32 blend's error, next to the flips.  ~1e-6 on a
+  // well-conditioned scene; up to 1e-3 where needle-like Gaussians are seen hundreds of pixels from their means.
+  float* noise_weight = nullptr;
 };
 
 template <typename F>
@@ -229,12 +245,27 @@ long long render_impl(int n, const float* means, const float* quats, const float
   std::vector<F> feat((size_t)n * channels);
   std::vector<long long> cnt(n, 0);
   const float* V = viewmat;
-  F campos[3];
-  for (int i = 0; i < 3; ++i)
+  F campos[3] = {0, 0, 0};
+  for (int i = 0; i < 3 && V; ++i)             // (no camera in the stage-isolated blend)
     campos[i] = -((F)V[0 + i] * (F)V[3] + (F)V[4 + i] * (F)V[7] + (F)V[8 + i] * (F)V[11]);
   long long n_vis = 0, n_edge = 0;
+  const bool given = ex.in_flatten_ids != nullptr;
+  if (given) {
+#pragma omp parallel for schedule(static)
+    for (int g = 0; g < n; ++g) {
+      Splat<F> s{};
+      s.mx = ex.in_means2d[2 * g]; s.my = ex.in_means2d[2 * g + 1];
+      s.ca = ex.in_conics[3 * g]; s.cb = ex.in_conics[3 * g + 1]; s.cc = ex.in_conics[3 * g + 2];
+      s.opac = ex.in_opac[g];
+      s.depth = ex.in_depths ? (F)ex.in_depths[g] : F(1);
+      s.depth32 = ex.in_depths ? ex.in_depths[g] : 1.f;
+      s.radius = s.radius_y = 1;                    // (listed or not is the lists' business)
+      for (int c = 0; c < channels; ++c) feat[(size_t)g * channels + c] = ex.in_feats[(size_t)g * channels + c];
+      sp[g] = s;
+    }
+  }
 #pragma omp parallel for schedule(static) reduction(+ : n_vis, n_edge)
-  for (int g = 0; g < n; ++g) {
+  for (int g = 0; g < (given ? 0 : n); ++g) {
     F comp;
     F edge[7];
     Splat<F> s{};
@@ -303,13 +334,28 @@ long long render_impl(int n, const float* means, const float* quats, const float
       if (ex.o_conics) { ex.o_conics[3 * g] = v ? sp[g].ca : 0; ex.o_conics[3 * g + 1] = v ? sp[g].cb : 0; ex.o_conics[3 * g + 2] = v ? sp[g].cc : 0; }
       if (ex.o_feats) for (int c = 0; c < channels; ++c) ex.o_feats[(size_t)g * channels + c] = v ? feat[(size_t)g * channels + c] : 0;
     }
+  // A.2 steps 7-8 (or the given lists): ids[perm[i]] is the Gaussian of list entry i, tstart the tiles' ranges
+  const size_t n_tiles_sz = (size_t)tw * th;
+  std::vector<long long> tstart(n_tiles_sz + 1, 0);
+  long long n_isect = 0;
+  std::unique_ptr<uint64_t[]> keys_buf;
+  std::unique_ptr<int[]> ids_buf;
+  std::unique_ptr<long long[]> perm_buf;
+  if (given) {
+    for (size_t t = 0; t <= n_tiles_sz; ++t) tstart[t] = ex.in_tile_offsets[t];
+    n_isect = tstart[n_tiles_sz];
+    ids_buf.reset(new int[(size_t)n_isect + 1]);
+    perm_buf.reset(new long long[(size_t)n_isect + 1]);
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < n_isect; ++i) { ids_buf[i] = ex.in_flatten_ids[i]; perm_buf[i] = i; }
+  } else {
   // A.2 step 7: keys in Gaussian-index order
   std::vector<long long> off(n + 1, 0);
   for (int g = 0; g < n; ++g) off[g + 1] = off[g] + cnt[g];
-  const long long n_isect = off[n];
+  n_isect = off[n];
   // (uninitialised: a std::vector would zero 100 MB on one thread before the parallel loops fill every entry)
-  std::unique_ptr<uint64_t[]> keys_buf(new uint64_t[(size_t)n_isect + 1]);
-  std::unique_ptr<int[]> ids_buf(new int[(size_t)n_isect + 1]);
+  keys_buf.reset(new uint64_t[(size_t)n_isect + 1]);
+  ids_buf.reset(new int[(size_t)n_isect + 1]);
   uint64_t* keys = keys_buf.get();
   int* ids = ids_buf.get();
 #pragma omp parallel for schedule(dynamic, 4096)
@@ -326,13 +372,11 @@ long long render_impl(int n, const float* means, const float* quats, const float
       }
   }
   // A.2 step 8: stable sort by key (permutation sort), tile ranges
-  std::unique_ptr<long long[]> perm_buf(new long long[(size_t)n_isect + 1]);
+  perm_buf.reset(new long long[(size_t)n_isect + 1]);
   long long* perm = perm_buf.get();
   // parallel: bucket by tile (counting sort, STABLE: every thread owns a contiguous run of the keys, counts it, takes its
   // place behind the lower threads' shares of each tile and drops its keys there in order), then sort each tile's slice by
   // depth.  (Serial, this pass and the histogram before it were a third of the frame on a 128-thread host.)
-  const size_t n_tiles_sz = (size_t)tw * th;
-  std::vector<long long> tstart(n_tiles_sz + 1, 0);
   {
     int n_thr = 1;
 #ifdef _OPENMP
@@ -384,6 +428,9 @@ long long render_impl(int n, const float* means, const float* quats, const float
     std::stable_sort(perm + tstart[t], perm + tstart[t + 1],
                      [&](long long a, long long b) { return keys[a] < keys[b]; });
 
+  }
+  const int* ids = ids_buf.get();
+  const long long* perm = perm_buf.get();
   const bool want_margins = ex.margins != nullptr;
   const bool want_bwd = ex.v_render != nullptr;
   const double thr_alpha = (ex.thresholds ? (double)ex.thresholds[0] : 1.0) / 255.0, thr_T = (ex.thresholds ? (double)ex.thresholds[1] : 1.0) * 1e-4;
@@ -408,7 +455,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
         F Tr = 1, C[4] = {0, 0, 0, 0};
         const F fx = px + F(0.5), fy = py + F(0.5);
         F m_a = inf, m_t = inf, m_s = inf, m_z = inf, z_prev = -1;
-        double fw = 0, loose = 0, wt_prev = 0, t_min = 0;
+        double fw = 0, loose = 0, wt_prev = 0, t_min = 0, noise = 0;
         long long last = -1;
         for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
           const int g = ids[perm[i]];
@@ -419,12 +466,15 @@ long long render_impl(int n, const float* means, const float* quats, const float
           F alpha = std::min(F(0.999), s.opac * std::exp(-sigma));
           F nT = Tr * (1 - alpha);
           if (want_margins) {
-            const F ma = std::abs(alpha * 255 - 1);
+            // conditioned margins (oracle/gs_oracle_np.py:rasterize): alpha's and T''s distance from their thresholds less
+            // what any fp32 evaluation of the pair can be off by -- SIGMA_ABS S on sigma, times alpha / (1 - alpha) on T'
+            const F S = F(0.5) * (std::abs(s.ca) * dx * dx + std::abs(s.cc) * dy * dy) + std::abs(s.cb * dx * dy);
+            const F cS = F(1e-6) * S, r_amp = alpha / std::max(1 - alpha, F(1e-3));
+            const F ma = std::max(std::abs(alpha * 255 - 1) - cS, F(0));
             m_a = std::min(m_a, ma);
             bool toggle = want_fw && (double)ma < fe_a;
             if (alpha >= F(0.5 / 255.0)) {
-              const F mt = std::abs(nT / F(1e-4) - 1);
-              F S = F(0.5) * (std::abs(s.ca) * dx * dx + std::abs(s.cc) * dy * dy) + std::abs(s.cb * dx * dy);
+              const F mt = std::max(std::abs(nT / F(1e-4) - 1) - cS * r_amp, F(0)) / (1 + r_amp);
               if (S > 0) {
                 const F ms = std::abs(sigma) / S;
                 m_s = std::min(m_s, ms);
@@ -449,6 +499,10 @@ long long render_impl(int n, const float* means, const float* quats, const float
           }
           if (nT <= F(thr_T)) break;
           F wgt = alpha * Tr;
+          if (want_margins && ex.noise_weight) {
+            const double S = 0.5 * (std::abs((double)s.ca) * dx * dx + std::abs((double)s.cc) * dy * dy) + std::abs((double)(s.cb * dx * dy));
+            noise += 1e-6 * S * (double)wgt / std::max(1.0 - (double)alpha, 1e-3);
+          }
           for (int c = 0; c < channels; ++c) C[c] += wgt * feat[(size_t)g * channels + c];
           Tr = nT;
           last = i;
@@ -463,6 +517,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
           ex.margins[2 * n_px + p] = (float)m_s;
           ex.margins[3 * n_px + p] = (float)m_z;
           if (want_fw) { ex.flip_weight[p] = (float)fw; t_at_min[p] = (float)t_min; }
+          if (ex.noise_weight) ex.noise_weight[p] = (float)noise;
         }
         if (want_bwd) { last_idx[p] = last; t_final[p] = (double)Tr; }
       }
@@ -542,7 +597,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
                 // goes -- |d loss / d alpha_g| <= T_g vabs with T_g <= flip_weight / alpha_g (its alpha_g T_g is in the
                 // weight), so the factors are flip_weight vabs x {geometry, 1 / opacity}, not ov times that
                 const double S_abs = 0.5 * (std::abs((double)s.ca) * dx * dx + std::abs((double)s.cc) * dy * dy) + std::abs((double)(s.cb * dx * dy));
-                const bool self = std::abs((double)ov * 255.0 - 1.0) < (double)ex.flip_eps[0] ||
+                const bool self = std::max(std::abs((double)ov * 255.0 - 1.0) - 1e-6 * S_abs, 0.0) < (double)ex.flip_eps[0] ||
                                   (S_abs > 0 && std::abs((double)sigma) / S_abs < (double)ex.flip_eps[2]);
                 const double ra = 1.0 / (1.0 - std::min(0.999, (double)ov)), A = fwp * vabs * ra;
                 const double bs = (self ? 1.0 : (double)ov) * A, bo = self ? A / std::max(1e-30, (double)s.opac) : (double)vis * A;
@@ -695,6 +750,43 @@ extern "C" long long gs_cpu_render_f64(int n, const float* means, const float* q
   return render_impl<double>(n, means, quats, scales, opacities, sh_degree, coeff_stride, sh, viewmat,
                              K, width, height, eps2d, near_p, far_p, radius_clip, channels,
                              background, n_threads, render, alphas, counters, ex);
+}
+
+// A.2 steps 9-10 alone, in fp64, on GIVEN projected quantities and depth-ordered tile lists (Extras: stage-isolated blend):
+// means2d [N,2], conics [N,3], opacities [N], feats [N,ch], depths [N] (nullable), flatten_ids [tile_offsets[tiles]],
+// tile_offsets [ceil(W/16) ceil(H/16) + 1].  Optional outputs as gs_cpu_render_f64 (no edge mask: list membership is given).
+extern "C" long long gs_cpu_blend_f64(int n, const float* means2d, const float* conics, const float* opacities,
+                                      const float* feats, const float* depths, const int32_t* flatten_ids,
+                                      const int32_t* tile_offsets, int width, int height, int channels,
+                                      const float* background, int n_threads, float* render, float* alphas,
+                                      long long* counters, float* margins, const float* v_render, const float* v_alpha,
+                                      double* g_means2d, double* g_conics, double* g_feats, double* g_opac,
+                                      float* flip_weight, const float* flip_eps, uint8_t* edge_mask, uint8_t* touched,
+                                      double* budget, const float* thresholds, float* noise_weight) {
+  Extras ex;
+  ex.noise_weight = noise_weight;
+  ex.in_means2d = means2d; ex.in_conics = conics; ex.in_opac = opacities; ex.in_feats = feats; ex.in_depths = depths;
+  ex.in_flatten_ids = flatten_ids; ex.in_tile_offsets = tile_offsets;
+  ex.thresholds = thresholds;
+  ex.margins = margins; ex.flip_weight = flip_weight; ex.flip_eps = flip_eps;
+  ex.edge_mask = edge_mask; ex.touched = touched; ex.budget = budget;
+  ex.v_render = v_render; ex.v_alpha = v_alpha;
+  ex.g_means2d = g_means2d; ex.g_conics = g_conics; ex.g_feats = g_feats; ex.g_opac = g_opac;
+  return render_impl<double>(n, nullptr, nullptr, nullptr, opacities, 0, 0, nullptr, nullptr, nullptr, width, height, 0.f,
+                             0.f, 0.f, 0.f, channels, background, n_threads, render, alphas, counters, ex);
+}
+
+// ... and the same blend in plain fp32 (the reference's formulas, float arithmetic) on the same given inputs: what "an fp32
+// blend" makes of them, for telling a kernel's own rounding from what any fp32 evaluation does.
+extern "C" long long gs_cpu_blend_f32(int n, const float* means2d, const float* conics, const float* opacities,
+                                      const float* feats, const int32_t* flatten_ids, const int32_t* tile_offsets, int width,
+                                      int height, int channels, const float* background, int n_threads, float* render,
+                                      float* alphas) {
+  Extras ex;
+  ex.in_means2d = means2d; ex.in_conics = conics; ex.in_opac = opacities; ex.in_feats = feats;
+  ex.in_flatten_ids = flatten_ids; ex.in_tile_offsets = tile_offsets;
+  return render_impl<float>(n, nullptr, nullptr, nullptr, opacities, 0, 0, nullptr, nullptr, nullptr, width, height, 0.f,
+                            0.f, 0.f, 0.f, channels, background, n_threads, render, alphas, nullptr, ex);
 }
 
 extern "C" int gs_cpu_max_threads() {

@@ -380,8 +380,11 @@ def test_heavy_tailed_scene_training_step_gradients(heavy):
     """The timed training step (RGB+ED, L1 cotangent, fixed capacity = the batched calls, segments of 256) on the
     heavy-tailed scene: lists of up to 39 k entries are 150 segments of the backward's walk, the screen-filling Gaussians own
     8,160 record slots each.  Fixed-capacity and per-camera paths bit-identical; gradients against the fp64 oracle chain
-    with the fraction rule (at most 1 % of the rows over the row tolerance, cosine >= 0.999) -- the per-row flip budgets are
-    printed, not asserted: on this scene fp32 itself is the noise (see the forward test)."""
+    with the fraction rule (at most 1 % of the rows over the row tolerance, cosine >= 0.999) AND the per-row flip budgets
+    asserted with a stated exemption: at most MAX_EXEMPT of the 1 M rows of a tensor may exceed rounding + 1.5 x budget
+    (round 5 printed the count: 1) -- on this scene the projection's fp32 noise is part of the whole path and no budget
+    prices it; the blend STAGE is held to its budgets without exemption (tests/test_gpu_heavy.py)."""
+    MAX_EXEMPT = 8
     from robosimgs_amd import rasterization, l1_loss
     from oracle import gs_oracle_torch as OT
     from grad_gate import compare, oracle_budgets
@@ -421,7 +424,12 @@ def test_heavy_tailed_scene_training_step_gradients(heavy):
         rb = np.asarray(ref_b, np.float64).reshape(len(b), -1)
         scale = np.abs(rb).max(axis=1, keepdims=True) + 1e-3 * np.abs(rb).max() + 1e-30
         over = (np.abs(gb - rb) / (2.0 * 5e-3 * scale + 1.5 * b.reshape(-1, 1))).max(axis=1) > 1.0
-        print(f"\nheavy-tailed v_{name} (blend): {st}; rows over rounding + 1.5 x flip budget: {int(over.sum())}")
+        print(f"\nheavy-tailed v_{name} (blend): {st}; rows over rounding + 1.5 x flip budget: {int(over.sum())} {np.flatnonzero(over)[:8].tolist()}")
+        # the WHOLE path on this scene carries the projection's fp32 noise into sigma (the forward test's docstring), which no
+        # flip budget prices; the blend stage on its own inputs is held to its budgets row by row
+        # (tests/test_gpu_heavy.py::test_full_size_heavy_tailed_blend_stage_backward: 0 of 1 M).  Here: at most
+        # MAX_EXEMPT rows per tensor may exceed theirs.
+        assert int(over.sum()) <= MAX_EXEMPT, f"heavy-tailed v_{name}: {int(over.sum())} rows over rounding + 1.5 x their flip budget (allowed: {MAX_EXEMPT})"
     compare("heavy-tailed v_opacities", got["opacities"], info["g_opacities"].reshape(-1, 1), row_tol=5e-3, bad_frac=1e-2,
             cos_min=0.999, verbose=False)
     d = lambda x, grad=False: torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=grad)

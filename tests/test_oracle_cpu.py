@@ -246,3 +246,45 @@ def test_counting_sort_does_not_depend_on_the_team_the_runtime_starts():
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, cwd=root, check=True, capture_output=True,
                                    text=True).stdout.strip())
     assert outs[0] == outs[1] and outs[0]
+
+
+def test_stage_isolated_blend_equals_the_numpy_blend_on_the_same_inputs():
+    """cpu_ref.blend_f64 (A.2 steps 9-10 in fp64 on GIVEN fp32 projected quantities and lists) against
+    gs_oracle_np.rasterize on the very same arrays: image, alpha, margins, flip weights; and the blend's backward against
+    the whole-path entry fed the same scene (there the inputs are fp64: gradients agree to the inputs' fp32 rounding)."""
+    g = synthetic_scene(3_000, math.log(0.08), 1, 3)
+    W, H = 112, 80
+    cam = camera_ring(1, W, H, thetas=[1.1])[0]
+    vm, K = cam.viewmat().astype(np.float32).astype(np.float64), cam.K.astype(np.float32).astype(np.float64)
+    p = O.project(g.means, g.quats, g.scales, vm, K, W, H)
+    rgb = O.sh_colors(1, g.means, O.campos_from_viewmat(vm), g.sh_coeffs)
+    feats = np.concatenate([rgb, p["depths"][:, None]], axis=1)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    m2d, con, opa, fe, dep = f32(p["means2d"]), f32(p["conics"]), f32(g.opacities), f32(feats), f32(p["depths"])
+    tw, th = -(-W // 16), -(-H // 16)
+    tpg, isect_ids, flat = O.isect_tiles(m2d, p["radii"], dep, 16, tw, th, dtype=np.float32)
+    offs = O.isect_offsets(isect_ids, 1, tw, th)[0]
+    img, alpha, last, st = O.rasterize(m2d.astype(np.float64), con.astype(np.float64), fe.astype(np.float64), opa.astype(np.float64),
+                                       flat, offs, W, H, margins=True, depths=dep.astype(np.float64), flip_eps=O.EPS_STAGE)
+    offsets = np.concatenate([offs.reshape(-1), [len(flat)]]).astype(np.int32)
+    rng = np.random.default_rng(5)
+    v_render, v_alpha = rng.normal(size=(H, W, 4)).astype(np.float32), rng.normal(size=(H, W)).astype(np.float32)
+    out, a, info = cpu_ref.blend_f64(m2d, con, opa, fe, flat, offsets, W, H, depths=dep, flip_eps=O.EPS_STAGE, n_threads=4,
+                                     v_render=v_render, v_alpha=v_alpha, want_budget=True)
+    assert info["n_isect"] == len(flat) and not info["edge_mask"].any()
+    np.testing.assert_allclose(out, img, atol=3e-7)
+    np.testing.assert_allclose(a, alpha, atol=3e-7)
+    fin = np.isfinite(st["margins"])
+    assert np.array_equal(fin, np.isfinite(info["margins"]))
+    np.testing.assert_allclose(info["margins"][fin], st["margins"][fin], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(info["flip_weight"], st["flip_weight"], atol=2e-6)
+    # backward: the whole-path fp64 entry on the same scene blends fp64 inputs; on the fp32-rounded ones the gradients
+    # agree to that rounding wherever no decision sits on a threshold
+    r64, a64, i64 = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vm, K, W, H, 1, with_depth=True,
+                                       n_threads=4, v_render=v_render, v_alpha=v_alpha, flip_eps=O.EPS_PATH, want_budget=True)
+    for k in ("g_means2d", "g_conics", "g_feats", "g_opacities"):
+        ref, got = i64[k], info[k]
+        scale = np.abs(ref).max() + 1e-12
+        close = np.abs(got - ref) <= 2e-4 * scale + 1e-3 * np.abs(ref)
+        assert close.mean() > 0.995, (k, close.mean())
+    assert info["budget"].shape == (3_000, 4) and np.isfinite(info["budget"]).all() and info["touched"].any()
