@@ -87,6 +87,33 @@ def root_bound_frames_per_s(mode, W, H, world):
         return None
     inbound = XGMI_LINK_GBS * 1e9 * min(world - 1, 7)
     return inbound / (PAYLOAD_BYTES_PER_PX[mode] * W * H * (world - 1) / world)
+
+
+def scaling_prediction(rate_by_payload, W, H, worlds=(2, 4, 8)):
+    """What the first SCALE record can be read against: per payload and world size N, the ring's predicted frames/s
+        min(N x this rank's measured rate with that payload, the single root's ceiling root_bound_frames_per_s)
+    rate_by_payload: {payload: frames/s of ONE rank rendering AND delivering that payload, measured in this run} (a world of
+    one: the float frame for "fp32", the dataset frames written by the raster for the dataset payloads where that leg ran,
+    otherwise the fp32 rate as a stand-in, flagged).  Not in the model: the root also renders while RCCL's receive kernels
+    write (N - 1) / N of every frame into its HBM (a world of one with --force-gather reads 4-5 % for dataset frames, 9-10 % for
+    fp32 frames), and the assumed link rate XGMI_LINK_GBS.  speedup = predicted / the fp32 one-rank rate."""
+    base = rate_by_payload.get("fp32")
+    out = {}
+    for m, bpp in PAYLOAD_BYTES_PER_PX.items():
+        r1 = rate_by_payload.get(m) or base
+        if not r1:
+            continue
+        rows = {}
+        for n in worlds:
+            rb = root_bound_frames_per_s(m, W, H, n)
+            pred = min(n * r1, rb)
+            rows[str(n)] = {"render_bound": round(n * r1, 0), "root_bound": round(rb, 0), "predicted_frames_per_s": round(pred, 0),
+                            "limited_by": "root" if rb < n * r1 else "render", "speedup_vs_one_rank_fp32": round(pred / base, 2) if base else None}
+        out[m] = {"bytes_per_frame": bpp * W * H, "one_rank_frames_per_s": round(r1, 1),
+                  "one_rank_rate_measured_with_this_payload": m in rate_by_payload, "by_world_size": rows}
+    return out
+
+
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -580,6 +607,19 @@ def main():
             nccl_ver = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:
             nccl_ver = "unknown"
+        assert dist.get_backend() == "nccl" and nccl_ver, "an N > 1 run on GPUs goes over RCCL (backend nccl) and says which"
+    # the ring's prediction for N = 2 / 4 / 8 from this run's one-rank rates (per rank: frames of this rank per second)
+    one_rank = {}
+    if not ring:
+        one_rank["fp32"] = frames_per_s
+    elif world == 1:
+        one_rank["fp32"] = frames_per_s if g_mode == "fp32" else None
+        for leg_name, leg in (alternates or {}).items():
+            if leg_name in PAYLOAD_BYTES_PER_PX:
+                one_rank[leg_name] = leg["frames_per_s"]
+    else:                                           # N ranks measured: per-rank shares of the measured legs
+        one_rank["fp32"] = frames_per_s / world if g_mode == "fp32" else None
+    one_rank = {k: v for k, v in one_rank.items() if v}
     all_ranks = None
     if do_gather:                                  # every rank's split of its last region, by payload
         all_ranks = [None] * world
@@ -609,6 +649,10 @@ def main():
                    "root_bound_note": (f"rank 0's inbound xGMI at {XGMI_LINK_GBS:g} GB/s per link (assumed, not measured) carries "
                                        "(N - 1) / N of every frame: the ceiling of a single-root gather whatever the renderers do"
                                        if (ring and world > 1) else None),
+                   "scaling_prediction": scaling_prediction(one_rank, W, H) if one_rank.get("fp32") else None,
+                   "scaling_prediction_note": ("min(N x this run's one-rank rate, the single root's ceiling) per payload at N = 2 / 4 / "
+                                               "8: what the driver's SCALE record can be read against; the root's receive load on its "
+                                               f"own rendering and the assumed {XGMI_LINK_GBS:g} GB/s per link are not in it"),
                    "gather": ((PAYLOADS[g_mode]
                                + f" to rank 0 (RCCL), {shard['GB']} frames per collective, "
                                  f"{n_collectives} collectives issued") if do_gather else "none"),

@@ -41,9 +41,9 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
     if name in ("FrameRenderer", "locality_order"):
         from . import pipeline
         return getattr(pipeline, name)
-    if name == "reorder_parameters":
+    if name in ("reorder_parameters", "Trainer"):
         from . import training
-        return training.reorder_parameters
+        return getattr(training, name)
     if name in ("render_sharded", "gather_frames", "shard_cameras"):
         from . import distributed
         return getattr(distributed, name)

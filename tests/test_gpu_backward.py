@@ -618,3 +618,40 @@ def test_reordering_a_trainers_parameters_changes_nothing_but_memory_order():
         step(pa, oa); step(pb, ob)
     for k in names:       # same trajectory up to the summation order of a Gaussian's pixels (depth ties, float re-association)
         torch.testing.assert_close(pb[k], pa[k][order], rtol=2e-4, atol=2e-6)
+
+
+def test_trainer_helper_renders_in_morton_order_by_itself_on_the_same_trajectory():
+    """robosimgs_amd.Trainer: the INTEGRATION.md loop with one object -- the parameters go into Morton order at the first render
+    and every `auto_reorder_every` steps without the caller doing anything, the run follows the plain rasterization() loop
+    (up to the summation order of a Gaussian's pixels), original_index maps back."""
+    from robosimgs_amd import Trainer, l1_loss, rasterization
+    g = synthetic_scene(8000, math.log(0.08), 2, 12)
+    cam = camera_ring(1, 160, 112, thetas=[0.5])[0]
+    vm, K = _t(cam.viewmat())[None], _t(cam.K)[None]
+    names = ("means", "quats", "scales", "opacities", "colors")
+    target = torch.rand(1, 112, 160, 4, device=DEV, generator=torch.Generator(DEV).manual_seed(2))
+
+    def make():
+        t = g.to_torch(DEV, 2)
+        p = {k: t[k].detach().clone().requires_grad_(True) for k in names}
+        return p, torch.optim.Adam(list(p.values()), lr=1e-3)
+
+    pa, oa = make()
+    for _ in range(5):
+        oa.zero_grad(set_to_none=True)
+        c, a, _ = rasterization(pa["means"], pa["quats"], pa["scales"], pa["opacities"], pa["colors"], vm, K, 160, 112, sh_degree=2,
+                                render_mode="RGB+ED", isect_capacity=400_000)
+        l1_loss(c, target).backward()
+        oa.step()
+    pb, ob = make()
+    tr = Trainer(pb, ob, 160, 112, auto_reorder_every=2, sh_degree=2, render_mode="RGB+ED", isect_capacity=400_000)
+    losses = []
+    for _ in range(5):
+        c, a, meta = tr.render(vm, K)
+        loss = l1_loss(c, target)
+        losses.append(float(loss))
+        tr.step(loss)
+    assert tr.reorders == 3 and losses[-1] < losses[0]
+    assert not torch.equal(tr.original_index, torch.arange(8000, device=DEV))
+    for k in names:
+        torch.testing.assert_close(tr.in_original_order(pb[k].detach()), pa[k].detach(), rtol=2e-4, atol=2e-6)
