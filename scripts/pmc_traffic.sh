@@ -3,9 +3,9 @@
 # prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (kernel trace only), FETCH_SIZE doubled
 # (gfx950 tallies 128-byte requests at 64 B), both in KiB.  Writes profiles/pmc_traffic.json keyed to the
 # build stamp of libmgs.so; bench.py prints `roofline.traffic` only when the stamp matches.
-#   gpurun -- bash scripts/pmc_traffic.sh        (results also under gpurun_out/pmc_r5/)
+#   gpurun -- bash scripts/pmc_traffic.sh        (results also under gpurun_out/pmc_r6/)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/pmc_r5
+OUT=$REPO/gpurun_out/pmc_r6
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for stage in raster_inf raster_inf_q raster_bwd_split project binning; do

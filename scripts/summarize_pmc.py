@@ -1,4 +1,4 @@
-"""profiles/pmc_traffic.json (scripts/pmc_traffic.sh) -> trimmed json + profiles/r5/06_pmc_counters.md"""
+"""profiles/pmc_traffic.json (scripts/pmc_traffic.sh) -> trimmed json + profiles/r6/06_pmc_counters.md"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -25,7 +25,7 @@ for k, v in keep.items():
     lines.append("| %s | %.0f | %.0f | %.1f | %s | %s | %s | %s | %s | %.0f | %s |" % (
         k[:80].replace("mgs::(anonymous namespace)::", "").replace("void ", ""), f, w, (2 * f + w) * 1024 / 1e6, g("SQ_INSTS_VALU"),
         g("SQ_INSTS_SALU"), g("SQ_INSTS_LDS"), g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY"), gui / 1e3, cpi))
-open(os.path.join(ROOT, "profiles", "r5", "06_pmc_counters.md"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(ROOT, "profiles", "r6", "06_pmc_counters.md"), "w").write("\n".join(lines) + "\n")
 sys.path.insert(0, ROOT)
 from robosimgs_amd.csrc import build
 print("\n".join(l[:160] for l in lines[7:12]))
