@@ -55,7 +55,13 @@ constexpr int kTSMain = 256;        // threads per tile
 #ifndef MGS_TSORT_UNIT_THREADS
 #define MGS_TSORT_UNIT_THREADS 512
 #endif
-constexpr int kUnit = MGS_TSORT_UNIT, kTSUnit = MGS_TSORT_UNIT_THREADS, kFastUnit = 4096, kUnitGrid = 512;
+#ifndef MGS_TSORT_UNIT_GRID
+#define MGS_TSORT_UNIT_GRID 512
+#endif
+#ifndef MGS_TSORT_COLLECT_GRID
+#define MGS_TSORT_COLLECT_GRID 2048
+#endif
+constexpr int kUnit = MGS_TSORT_UNIT, kTSUnit = MGS_TSORT_UNIT_THREADS, kFastUnit = 4096, kUnitGrid = MGS_TSORT_UNIT_GRID;
 constexpr int kMaxUnits = 256;                        // units per list (a list over kMaxUnits * kUnit entries: larger units)
 constexpr int kUnitSample = 256;                      // sample a unit's own bucket function is taken from (lds_level) ...
 #ifndef MGS_TSORT_ADAPT
@@ -67,7 +73,7 @@ constexpr int kAdapt = MGS_TSORT_ADAPT;               // ... when the bit field 
 #endif
 constexpr int kSamplePerUnit = 24;                    // ... of which this many per unit are ranked
 constexpr int kSample = 512;                          // entries the splitters are taken from at most: every 2^k-th of the list
-constexpr int kCollectThreads = 256, kCollectPer = 8, kCollectGrid = 2048;   // unit_collect_kernel
+constexpr int kCollectThreads = 256, kCollectPer = 8, kCollectGrid = MGS_TSORT_COLLECT_GRID;   // unit_collect_kernel
 // header of the deferred lists (two 16-byte stores zero it): [0] descriptors claimed, [1] units claimed from the bottom of the
 // unit tables (lists of kBigList entries and more: their units read the whole list, the units' kernel starts with them),
 // [2] collect chunks claimed, [3] units handed out by the units' kernel beyond its workgroups' first ones, [4] units
