@@ -655,3 +655,33 @@ def test_trainer_helper_renders_in_morton_order_by_itself_on_the_same_trajectory
     assert not torch.equal(tr.original_index, torch.arange(8000, device=DEV))
     for k in names:
         torch.testing.assert_close(tr.in_original_order(pb[k].detach()), pa[k].detach(), rtol=2e-4, atol=2e-6)
+
+
+def test_splat_slot_words_of_another_binning_are_not_trusted():
+    """mgs_isect_tiles(splat_slots=) writes a binning's record slots into the splat records in place; rasterize_bwd_det_raw takes
+    them from there only while the records still belong to THAT binning (ops._splat_slots_valid): binned again under another
+    rule -- other slots in the same words -- an older TileLists falls back to its own pair_info and gives the same gradients."""
+    from robosimgs_amd import ops
+    g, cam = _scene(6000, 0.1, 1, 160, 112)
+    t = g.to_torch(DEV, 1)
+    vm, K = _t(cam.viewmat()), _t(cam.K)
+    W, H, tw, th = 160, 112, 10, 7
+    radii, m2d, dep, con, _, feats, splats = ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], 1, t["colors"], vm, K, W, H,
+                                                                       0.3, 0.01, 1e10, 0.0, False, True, want_splats=True)
+    cap = ops._upper_bound_isects(radii, tw, th) + 1
+    tl_tight = ops.isect_tiles_raw(m2d, radii, dep, tw, th, cap, want_pair_info=True, conics=con, opacities=t["opacities"], splats=splats)
+    assert ops._splat_slots_valid(tl_tight, splats)
+    r, a, last = ops.rasterize_fwd_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl_tight.tile_offsets, tl_tight.flatten_ids, splats=splats)
+    vr, va = torch.randn(H, W, 4, device=DEV), torch.randn(H, W, device=DEV)
+    want = ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl_tight, a, last, vr, va, splats=splats)[:4]
+    # the same records binned again with CLASSIC rectangles: their slot words now belong to that binning
+    tl_classic = ops.isect_tiles_raw(m2d, radii, dep, tw, th, cap, want_pair_info=True, splats=splats)
+    assert ops._splat_slots_valid(tl_classic, splats) and not ops._splat_slots_valid(tl_tight, splats)
+    assert not torch.equal(tl_classic.pair_info, tl_tight.pair_info)
+    got = ops.rasterize_bwd_det_raw(m2d, con, feats, t["opacities"], None, W, H, tw, th, tl_tight, a, last, vr, va, splats=splats)[:4]
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    # fresh records (a new projection into the same storage or not) carry nobody's slots
+    splats2 = ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], 1, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, True,
+                                        want_splats=True)[6]
+    assert not ops._splat_slots_valid(tl_classic, splats2)

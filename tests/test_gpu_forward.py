@@ -256,6 +256,41 @@ def test_isect_tiles_empty_and_overflow(ops):
     np.testing.assert_array_equal(tl.tile_ids.cpu().numpy(), np.arange(16))
 
 
+@pytest.mark.parametrize("cap_frac,opts", [(0.45, 0), (0.8, 0), (0.45, 4)])
+def test_deferred_lists_with_an_overflowed_capacity_stay_inside_their_buffers(ops, cap_frac, opts):
+    """Lists over the LDS list (split into units: csrc/tile_sort.hip) while the capacity is too small for the pairs: the
+    overflow is flagged, every offset lies inside the capacity, nothing is written past the buffers (canaries behind
+    flatten_ids and tile_ids), and the lists that fit whole are the stable sort's."""
+    from robosimgs_amd import _lib
+    rng = np.random.default_rng(7)
+    n, tw, th = 24_000, 3, 2
+    means2d = (rng.uniform(0, 1, size=(n, 2)) * np.float32([16 * tw, 16 * th])).astype(np.float32)
+    radii = np.full(n, 64, np.int32)                      # every Gaussian covers all six tiles: lists of 24 k entries
+    depths = rng.uniform(0.5, 20.0, size=n).astype(np.float32)
+    r_tpg, r_ids, r_flat = O.isect_tiles(means2d, radii, depths, 16, tw, th, dtype=np.float32)
+    total = len(r_flat)
+    cap = int(total * cap_frac)
+    _dbg = _lib.use_debug_lib()
+    lib = _dbg.__enter__()
+    try:
+        lib.mgs_debug_set_sort_opts(opts)
+        for _ in range(2):
+            tl = ops.isect_tiles_raw(_t(means2d), torch.from_numpy(radii).to(DEV), _t(depths), tw, th, cap)
+            torch.cuda.synchronize()
+            assert int(tl.n_isect.item()) == total and int(tl.status.item()) & _lib.MGS_STATUS_ISECT_OVERFLOW
+            off = tl.tile_offsets.cpu().numpy()
+            assert off.min() >= 0 and off.max() <= cap and np.all(np.diff(off) >= 0)
+            # tiles whose lists fit whole inside the capacity hold the stable sort's entries
+            ref_off = np.concatenate([O.isect_offsets(r_ids, 1, tw, th).reshape(-1), [total]])
+            got = tl.flatten_ids.cpu().numpy()
+            for t_ in range(tw * th):
+                if ref_off[t_ + 1] <= cap and off[t_] == ref_off[t_] and off[t_ + 1] == ref_off[t_ + 1]:
+                    np.testing.assert_array_equal(got[off[t_]:off[t_ + 1]], r_flat[ref_off[t_]:ref_off[t_ + 1]])
+    finally:
+        lib.mgs_debug_set_sort_opts(0)
+        _dbg.__exit__(None, None, None)
+
+
 def _raster_inputs(ops, g, cam, w, h, deg):
     t = g.to_torch(DEV, deg)
     vm, K = _t(cam.viewmat()), _t(cam.K)
