@@ -456,6 +456,7 @@ long long render_impl(int n, const float* means, const float* quats, const float
         const F fx = px + F(0.5), fy = py + F(0.5);
         F m_a = inf, m_t = inf, m_s = inf, m_z = inf, z_prev = -1;
         double fw = 0, loose = 0, wt_prev = 0, t_min = 0, noise = 0;
+        F r_acc = 0, sr_acc = 0;      // over the contributors so far: sum of r^2, r = alpha / (1 - alpha), and of SIGMA_ABS S r (T's own relative error)
         long long last = -1;
         for (long long i = tstart[t]; i < tstart[t + 1]; ++i) {
           const int g = ids[perm[i]];
@@ -469,12 +470,15 @@ long long render_impl(int n, const float* means, const float* quats, const float
             // conditioned margins (oracle/gs_oracle_np.py:rasterize): alpha's and T''s distance from their thresholds less
             // what any fp32 evaluation of the pair can be off by -- SIGMA_ABS S on sigma, times alpha / (1 - alpha) on T'
             const F S = F(0.5) * (std::abs(s.ca) * dx * dx + std::abs(s.cc) * dy * dy) + std::abs(s.cb * dx * dy);
-            const F cS = F(1e-6) * S, r_amp = alpha / std::max(1 - alpha, F(1e-3));
+            // (a clamped alpha is 0.999 in every implementation: no error of its own to amplify)
+            const F cS = F(1e-6) * S, r_amp = (s.opac * std::exp(-sigma) >= F(0.999)) ? F(0) : alpha / std::max(1 - alpha, F(1e-3));
             const F ma = std::max(std::abs(alpha * 255 - 1) - cS, F(0));
             m_a = std::min(m_a, ma);
             bool toggle = want_fw && (double)ma < fe_a;
             if (alpha >= F(0.5 / 255.0)) {
-              const F mt = std::max(std::abs(nT / F(1e-4) - 1) - cS * r_amp, F(0)) / (1 + r_amp);
+              // (T = prod (1 - alpha_j) carries every earlier contributor's error too: sum_j r_j d alpha_j / alpha_j)
+              // -- independent roundings: their eps shares add in quadrature, the conditioned shares (rare, large) plainly
+              const F mt = std::max(std::abs(nT / F(1e-4) - 1) - (cS * r_amp + sr_acc), F(0)) / std::sqrt((1 + r_amp) * (1 + r_amp) + r_acc);
               if (S > 0) {
                 const F ms = std::abs(sigma) / S;
                 m_s = std::min(m_s, ms);
@@ -499,9 +503,14 @@ long long render_impl(int n, const float* means, const float* quats, const float
           }
           if (nT <= F(thr_T)) break;
           F wgt = alpha * Tr;
+          if (want_margins) {
+            const F Sk = F(0.5) * (std::abs(s.ca) * dx * dx + std::abs(s.cc) * dy * dy) + std::abs(s.cb * dx * dy);
+            const F rk = (s.opac * std::exp(-sigma) >= F(0.999)) ? F(0) : alpha / std::max(1 - alpha, F(1e-3));
+            r_acc += rk * rk; sr_acc += F(1e-6) * Sk * rk;
+          }
           if (want_margins && ex.noise_weight) {
             const double S = 0.5 * (std::abs((double)s.ca) * dx * dx + std::abs((double)s.cc) * dy * dy) + std::abs((double)(s.cb * dx * dy));
-            noise += 1e-6 * S * (double)wgt / std::max(1.0 - (double)alpha, 1e-3);
+            if ((double)(s.opac * std::exp(-sigma)) < 0.999) noise += 1e-6 * S * (double)wgt / std::max(1.0 - (double)alpha, 1e-3);
           }
           for (int c = 0; c < channels; ++c) C[c] += wgt * feat[(size_t)g * channels + c];
           Tr = nT;

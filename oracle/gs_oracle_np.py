@@ -380,7 +380,7 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
             cur_last = np.zeros(px.shape, dtype=np.int32)
             tm = np.full((4,) + px.shape, np.inf) if margins else None
             z_prev = np.full(px.shape, -1.0)
-            fw, loose, wt_prev, t_min = (np.zeros(px.shape) for _ in range(4))
+            fw, loose, wt_prev, t_min, r_acc, sr_acc = (np.zeros(px.shape) for _ in range(6))
             for i in range(s, e):
                 if done.all():
                     break
@@ -404,11 +404,18 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
                     # opaque Gaussian at its centre: r ~ 100-1000).  With eps_alpha = eps_T = eps (both EPS sets):
                     #   |255 alpha - 1| < eps + c S             <=>  m_a = max(0, |255 alpha - 1| - c S) < eps
                     #   |T'/1e-4 - 1| < eps + (eps + c S) r     <=>  m_t = max(0, |T'/1e-4 - 1| - c S r) / (1 + r) < eps
+                    #   (with the earlier contributors' r and c S r added to this one's: below)
                     # On a well-conditioned scene S ~ sigma <= 10 and r <= a few: the old margins to within 1e-5.
-                    r_amp = a / np.maximum(one - a, dtype(1e-3))
+                    r_amp = np.where(opa[g] * exp(-sigma) >= dtype(ALPHA_MAX), 0, a / np.maximum(one - a, dtype(1e-3)))   # (a clamped alpha is exact)
                     cS = dtype(SIGMA_ABS) * S
                     m_a = np.maximum(np.abs(a * dtype(255.0) - one) - cS, 0)
-                    m_t = np.maximum(np.abs(Tn / dtype(T_STOP) - one) - cS * r_amp, 0) / (one + r_amp)
+                    # (T = prod (1 - alpha_j) carries every earlier contributor's error too: r_acc = sum r_j^2, sr_acc = sum c S_j r_j
+                    #  over the pixel's contributors so far -- 77 of them deep in a list make the stop test 4-6 x as uncertain
+                    #  as the last alpha alone: soak seed 59, profiles/r6/00_experiments.md section 2)
+                    #  The eps shares are independent roundings and add in quadrature (r_acc = sum r_j^2: added plainly they flagged
+                    #  5.9 % of configs[1] under EPS_PATH, whose eps already carries what accumulates on a well-conditioned scene);
+                    #  the conditioned shares -- rare, large -- add plainly.
+                    m_t = np.maximum(np.abs(Tn / dtype(T_STOP) - one) - (cS * r_amp + sr_acc), 0) / np.sqrt((one + r_amp) ** 2 + r_acc)
                     with np.errstate(divide="ignore", invalid="ignore"):
                         m_s = np.where(S > 0, np.abs(sigma) / S, np.inf)
                     could_count = a >= dtype(0.5 * ALPHA_MIN)     # a sigma flip only matters if alpha would count
@@ -432,6 +439,9 @@ def rasterize(means2d, conics, colors, opacities, flatten_ids, offsets, width, h
                 stop = ok & (Tn <= dtype(T_STOP))
                 done |= stop
                 acc = ok & ~stop
+                if margins:
+                    r_acc = r_acc + np.where(acc, r_amp * r_amp, 0)
+                    sr_acc = sr_acc + np.where(acc, cS * r_amp, 0)
                 w = np.where(acc, a * T, 0)
                 C += w[..., None] * col[g][None, None, :]
                 T = np.where(acc, Tn, T)
@@ -501,13 +511,15 @@ FLIP_SLACK = 1.5      # on the flip weight: the fp32 implementation's own alpha 
 
 
 def check_frame(got, got_alpha, ref, ref_alpha, margins, eps, edge_mask=None, tol=1e-4,
-                expected_depth=False, max_explained=0.03, what="frame", flip_weight=None, feat_max=None,
+                expected_depth=False, max_explained=0.05, what="frame", flip_weight=None, feat_max=None,
                 require_flip_bound=False, noise_weight=None):
     """THE forward parity gate.  got / ref [H,W,D], alphas [H,W].  Asserts
       * every pixel whose colour, depth-sum or alpha differs by more than `tol` (1e-4 abs, the
         north-star tolerance) is a pixel where the fp64 blend took a decision within `eps` of
         flipping (explained_pixels) -- ZERO unexplained pixels;
-      * such could-flip pixels are at most `max_explained` of the image (the gate is not vacuous).
+      * such could-flip pixels are at most `max_explained` of the image (the gate is not vacuous; 5 % since the stop test's
+        margin counts the error T has accumulated over the pixel's contributors: configs[4], lists of ~800 entries, reads
+        3.7 % under EPS_PATH, configs[1] 2-3 %).
       * with flip_weight [H,W] (rasterize(flip_eps=eps) / cpu_ref.render_f64(flip_eps=eps); for whole-path
         frames already including the edge pixels' share) and feat_max [D] (largest |feature| per channel over
         the visible Gaussians): a could-flip pixel may be off by at most what the near-flip decisions are worth,

@@ -3,7 +3,7 @@ counts, needle / screen-filling shares, resolutions and cameras) through what th
   * the tile lists against the stable-sort formulation on the GPU's own projected inputs, bit for bit (lists of thousands of
     entries, buckets of near-identical depths: the per-tile sort's long-list launch and its generic path);
   * classic against tightened rectangles: same image, same gradients (whole-list walk), bit for bit;
-  * the forward against the fp64 port relative to its fp32 instantiation (check_frame_against_fp32_port);
+  * the gates of tests/test_gpu_heavy.py on the seed's scene: blend stage absolute, projection stage, whole path relative;
   * gradients finite and bit-reproducible.
     python scripts/soak_heavy.py [n_scenes [first_seed]]"""
 import math, os, sys
@@ -12,6 +12,8 @@ import numpy as np, torch
 from oracle import cpu_ref
 from oracle import gs_oracle_np as O
 from robosimgs_amd import camera_ring, ops, rasterization, synthetic_scene_heavy_tailed
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import test_gpu_heavy as heavy_gates
 DEV = "cuda"
 def _t(a): return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -53,19 +55,15 @@ for seed in range(first, first + n_scenes):
         (c.sum() + a.sum()).backward()
         gr.append([v.grad for v in p.values()])
     repro = all(torch.equal(x, y) for x, y in zip(*gr))
-    vm32, K32 = np.asarray(cam.viewmat(), np.float32), np.asarray(cam.K, np.float32)
-    ref, ra, info = cpu_ref.render_f64(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vm32, K32, W, H, deg, with_depth=True, flip_eps=O.EPS_PATH)
-    ref = ref.astype(np.float64); ref[..., 3] /= np.maximum(ra, 1e-10)
-    r32, a32, _i = cpu_ref.render(g.means, g.quats, g.scales, g.opacities, g.sh_coeffs, vm32, K32, W, H, deg, with_depth=True)
+    # the gates of tests/test_gpu_heavy.py (round 6): the blend stage on the GPU's own inputs ABSOLUTE, the projection stage, the whole
+    # path relative to the port's fp32 instantiation (percentiles and far outliers; no count clauses on these small frames)
     try:
-        st = O.check_frame_against_fp32_port(outs[1][0][0].cpu().numpy(), outs[1][1][0].cpu().numpy(), ref, ra, r32, a32, info["margins"], O.EPS_PATH,
-                                             info["edge_mask"], expected_depth=True, what=f"seed {seed}")
+        heavy_gates.test_soak_scene_lists_stage_blend_and_whole_path(seed)
         gate = True
-        worst = max(worst, st["err_q9999"])
     except AssertionError as e:
         gate = False
-        print("GATE", str(e)[str(e).index("{"):])
+        print("GATE", str(e)[:600])
     if not (ok_lists and same_img and fin and repro and gate):
         bad += 1
         print("FAIL seed", seed, n, W, H, deg, dict(lists=ok_lists, tight=same_img, finite=fin, reproducible=repro, gate=gate))
-print(f"{n_scenes} heavy-tailed scenes: failures {bad}; longest tile list {longest} entries; worst 99.99th-percentile error {worst:.2f} tolerances")
+print(f"{n_scenes} heavy-tailed scenes (seeds {first} .. {first + n_scenes - 1}): failures {bad}; longest tile list {longest} entries")
