@@ -904,7 +904,7 @@ def pmc_valu(kernel_name, standard_workload, stage_prefix="raster_inf", floor=No
 
 
 def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
-    from robosimgs_amd import l1_loss
+    from robosimgs_amd import l1_loss, unit_gradient
     names = ("means", "quats", "scales", "opacities", "colors")
     params = {k: t[k].detach().clone().requires_grad_(True) for k in names}
     # L1 to a U(0,1) target (seed 1) on all four channels of the RGB+ED frame
@@ -917,7 +917,7 @@ def bench_fwd_bwd(a, t, vm, K, W, H, deg, cap, dev):
                                              params["opacities"], params["colors"], vm, K, W, H,
                                              sh_degree=deg, render_mode=MODE, isect_capacity=cap)
         loss = l1_loss(colors, target)      # fused HIP L1 (== (colors - target).abs().mean())
-        loss.backward()
+        loss.backward(gradient=unit_gradient(loss))      # what robosimgs_amd.Trainer.step does: no ones_like fill, no scale launch
         return loss
 
     for _ in range(3):

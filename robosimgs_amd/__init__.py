@@ -35,9 +35,9 @@ def __getattr__(name):  # lazy: keeps `import robosimgs_amd` torch-free for host
     if name == "transform_gaussians":
         from . import transform
         return transform.transform_gaussians
-    if name == "l1_loss":
+    if name in ("l1_loss", "unit_gradient"):
         from . import losses
-        return losses.l1_loss
+        return getattr(losses, name)
     if name in ("FrameRenderer", "locality_order"):
         from . import pipeline
         return getattr(pipeline, name)

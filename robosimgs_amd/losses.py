@@ -14,6 +14,20 @@ from ._lib import check, ptr, require_device, stream_handle
 from .ops import _f32c
 
 
+_ONES: dict = {}
+
+
+def unit_gradient(loss: torch.Tensor) -> torch.Tensor:
+    """A cached scalar 1.0 on `loss`'s device for `loss.backward(gradient=unit_gradient(loss))`: autograd then needs no
+    `ones_like` fill launch, and `l1_loss`'s backward, handed this very tensor, knows the cotangent is 1 without reading it
+    and skips its scale launch -- two launches less per training step (`Trainer.step` does this).  Never written to."""
+    key = (loss.device.type, loss.device.index)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), dtype=torch.float32, device=loss.device)
+    return one
+
+
 class _L1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -41,7 +55,9 @@ class _L1(torch.autograd.Function):
         g = _f32c(v_loss)
         v_a, ctx.v_a = ctx.v_a, None
         if v_a is not None:
-            check(_lib.lib().mgs_l1_loss_bwd_scale(v_a.numel(), ptr(g), ptr(v_a), stream_handle()), "mgs_l1_loss_bwd_scale")
+            one = _ONES.get((g.device.type, g.device.index))
+            if one is None or g.data_ptr() != one.data_ptr():      # (unit_gradient's tensor: the cotangent is 1, nothing to scale)
+                check(_lib.lib().mgs_l1_loss_bwd_scale(v_a.numel(), ptr(g), ptr(v_a), stream_handle()), "mgs_l1_loss_bwd_scale")
             return v_a, None
         # a second backward through a retained graph: autograd owns the first buffer by now
         a, b = ctx.saved_tensors

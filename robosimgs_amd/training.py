@@ -134,8 +134,13 @@ class Trainer:
                   **{**self.raster_kwargs, **kw})
 
     def step(self, loss: torch.Tensor) -> None:
-        """loss.backward(), optimiser step, zero_grad(set_to_none=True); counts the step towards the next reorder."""
-        loss.backward()
+        """loss.backward(), optimiser step, zero_grad(set_to_none=True); counts the step towards the next reorder.  A scalar loss
+        is differentiated with losses.unit_gradient (no fill launch; l1_loss's backward skips its scale launch)."""
+        if loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda:
+            from .losses import unit_gradient
+            loss.backward(gradient=unit_gradient(loss))
+        else:
+            loss.backward()
         if self.optimizer is not None:
             self.optimizer.step()
             self.optimizer.zero_grad(set_to_none=True)

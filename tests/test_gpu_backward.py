@@ -452,6 +452,13 @@ def test_fused_l1_loss_matches_torch(shape):
     torch.testing.assert_close(a3.grad * 3.0, a2.grad, rtol=1e-6, atol=0)
     l3.backward()
     torch.testing.assert_close(a3.grad * 1.5, a2.grad, rtol=1e-6, atol=0)
+    # unit_gradient: the cached 1.0 as the cotangent (no fill launch, no scale launch): the gradient of a plain backward()
+    from robosimgs_amd import unit_gradient
+    a4 = a.detach().clone().requires_grad_(True)
+    l4 = l1_loss(a4, b)
+    l4.backward(gradient=unit_gradient(l4))
+    assert torch.equal(a4.grad * 3.0, a.grad) or torch.allclose(a4.grad * 3.0, a.grad, rtol=1e-6, atol=0)
+    assert float(unit_gradient(l4)) == 1.0 and unit_gradient(l4) is unit_gradient(l4)
     # a contiguous view at an odd element offset
     if len(shape) == 1:
         v = torch.rand(9, device=DEV)[1:8]
@@ -685,3 +692,4 @@ def test_splat_slot_words_of_another_binning_are_not_trusted():
     splats2 = ops.project_color_fwd_raw(t["means"], t["quats"], t["scales"], t["opacities"], 1, t["colors"], vm, K, W, H, 0.3, 0.01, 1e10, 0.0, False, True,
                                         want_splats=True)[6]
     assert not ops._splat_slots_valid(tl_classic, splats2)
+
