@@ -936,8 +936,11 @@ __device__ __forceinline__ void sort_one_tile(
   }
 }
 
+#ifndef MGS_TSORT_MAIN_SGPRS
+#define MGS_TSORT_MAIN_SGPRS 96
+#endif
 template <bool GROUPED, int kFast, bool DEFER>
-__global__ __launch_bounds__(kTSMain) void tile_depth_sort_kernel(
+__global__ __launch_bounds__(kTSMain) __attribute__((amdgpu_num_sgpr(MGS_TSORT_MAIN_SGPRS))) void tile_depth_sort_kernel(
     int n_tiles, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
     uint32_t* ids_final, uint32_t* __restrict__ tile_ids, uint32_t* key0, uint32_t* id0, uint32_t* key1,
     uint32_t* id1, const uint32_t* __restrict__ staging, int shift, int32_t* __restrict__ offsets_out,

@@ -3,7 +3,9 @@ usage: run_stage.py {raster|raster_bwd|binning|project|frame} [reps]"""
 import math, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from robosimgs_amd import synthetic_scene, camera_ring, ops
+from robosimgs_amd import synthetic_scene, camera_ring, ops, _lib
+if os.environ.get("VARIANT_LIB"):      # another tree's libmgs.so (scripts/dbg/tsort_main_counters.sh)
+    _lib._lib = _lib._load(os.path.abspath(os.environ["VARIANT_LIB"]))
 stage = sys.argv[1] if len(sys.argv) > 1 else "raster"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n, mu, W, H, deg = int(os.environ.get("N", 1_000_000)), float(os.environ.get("MU", 0.012)), int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080)), 3
