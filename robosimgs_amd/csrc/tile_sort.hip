@@ -172,6 +172,9 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wave_s
 
 #ifdef MGS_TSORT_TIMING
 __device__ unsigned g_tsort_pops[4096];     // per workgroup: buckets popped off the stack (+ 0x10000 per bucket over the LDS list)
+constexpr unsigned kTsortLog = 16384;
+__device__ unsigned long long g_tsort_log[6 * kTsortLog];
+__device__ unsigned g_tsort_log_n;
 #endif
 
 // GROUPED: the binning's direct path has dropped the pairs of every 2^shift consecutive tiles into one segment
@@ -956,8 +959,22 @@ __global__ __launch_bounds__(kTSMain) __attribute__((amdgpu_num_sgpr(MGS_TSORT_M
     tile = ((blockIdx.x / (8 * G)) * 8 + (r & 7)) * G + (r >> 3);
   }
   if (tile >= n_tiles) return;
+#ifdef MGS_TSORT_TIMING            // measurement build: per tile {start, end} on the 100 MHz clock (scripts/dbg/main_sort_timeline.py)
+  const unsigned long long t_start = wall_clock64();
+#endif
   sort_one_tile<GROUPED, kFast, kTSMain, false, DEFER>(tile, n_tiles, offsets, depths, ids_final, tile_ids, key0, id0, key1, id1,
                                                        staging, shift, offsets_out, aux);
+#ifdef MGS_TSORT_TIMING
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned k = atomicAdd(&g_tsort_log_n, 1u);
+    if (k < kTsortLog) {
+      unsigned long long* r = g_tsort_log + 6 * (size_t)k;
+      r[0] = blockIdx.x; r[1] = 0ull; r[2] = (unsigned long long)tile; r[3] = 0xffffull;      // (3: marks a tile of the main kernel)
+      r[4] = t_start; r[5] = wall_clock64();
+    }
+  }
+#endif
 }
 
 // Deferred lists, second step: the entries of every described list out of its group's segment (GROUPED) or out of the list
@@ -1036,12 +1053,6 @@ __global__ __launch_bounds__(kCollectThreads) void unit_collect_kernel(
     if (tid < nb && lh[tid]) atomicAdd(&aux.unit_hist[toff + tid], lh[tid]);
   }
 }
-
-#ifdef MGS_TSORT_TIMING
-constexpr unsigned kTsortLog = 8192;
-__device__ unsigned long long g_tsort_log[6 * kTsortLog];
-__device__ unsigned g_tsort_log_n;
-#endif
 
 // Deferred lists, third step: one unit at a time per workgroup.  (key0, id0) here is the units' own scratch, the collected
 // lists are (ck, ci).
