@@ -50,13 +50,13 @@ constexpr int kTSMain = 256;        // threads per tile
 // (kTSUnit threads, an LDS list of kFastUnit entries, the same levels).  The launches cost a few microseconds even when
 // no list is long, so they exist only where the capacity says lists are long (tile_depth_sort below).
 #ifndef MGS_TSORT_UNIT
-#define MGS_TSORT_UNIT 1536            // entries per unit aimed at (the units' LDS list holds kFastUnit: room for an uneven split)
+#define MGS_TSORT_UNIT 2048            // entries per unit aimed at (the units' LDS list holds kFastUnit: room for an uneven split)
 #endif
 #ifndef MGS_TSORT_UNIT_THREADS
 #define MGS_TSORT_UNIT_THREADS 512
 #endif
 #ifndef MGS_TSORT_UNIT_GRID
-#define MGS_TSORT_UNIT_GRID 512
+#define MGS_TSORT_UNIT_GRID 768
 #endif
 #ifndef MGS_TSORT_COLLECT_GRID
 #define MGS_TSORT_COLLECT_GRID 2048
@@ -95,7 +95,7 @@ struct SortAux {
   unsigned long long* unit_split;    // per unit u of a list (but its last): the splitter between buckets u and u + 1
 };
 #ifndef MGS_TSORT_LONG_BUCKETS
-#define MGS_TSORT_LONG_BUCKETS 512     // buckets per level in the units' kernel (the main kernel: 1024): ~1,500 entries per unit
+#define MGS_TSORT_LONG_BUCKETS 512     // buckets per level in the units' kernel (the main kernel: 1024): ~2,000 entries per unit; 1,024 would cost the third workgroup per CU its LDS
 #endif
 // buckets of one MSD level
 constexpr int buckets_for(int fast) { return fast > 2048 ? MGS_TSORT_LONG_BUCKETS : 1024; }   // (256 for the short-list variant: fewer counters to zero / scan, but ~2 entries per
@@ -1056,7 +1056,12 @@ __global__ __launch_bounds__(kCollectThreads) void unit_collect_kernel(
 
 // Deferred lists, third step: one unit at a time per workgroup.  (key0, id0) here is the units' own scratch, the collected
 // lists are (ck, ci).
-__global__ __launch_bounds__(kTSUnit) void tile_sort_units_kernel(
+// (compiled for six waves per SIMD: 71 VGPRs without a spill where the launch bound alone let the compiler take 113 -- three
+//  workgroups per CU, which is what LDS allows, and with units of 2,048 entries the clustered scene's ~750 units are resident at once)
+#ifndef MGS_TSORT_UNIT_WAVES
+#define MGS_TSORT_UNIT_WAVES 6
+#endif
+__global__ __launch_bounds__(kTSUnit) __attribute__((amdgpu_waves_per_eu(MGS_TSORT_UNIT_WAVES, 8))) void tile_sort_units_kernel(
     int n_tiles, uint32_t* ids_final, const uint32_t* __restrict__ ck, const uint32_t* __restrict__ ci, uint32_t* key0,
     uint32_t* id0, uint32_t* key1, uint32_t* id1, const SortAux aux) {
   // units [0, n_big) of the tables belong to the big lists, the last n_small to the others: item i is unit i, or unit
