@@ -200,8 +200,12 @@ __device__ __forceinline__ void sort_one_tile(
   // come out of LDS (the fast path's list, the generic path's windows), and every bucket it does NOT rank is one more
   // level taken by the whole workgroup, one bucket after the other
   constexpr int kSm = LONG ? kSmallLong : kSmall;
+  // One word per bucket.  lds_level (n <= kFast < 2^15 entries) packs {running offset: 16 bits, size: 15 bits, kBrute} into it;
+  // the generic loop below (segments of any length) keeps sizes here and its offsets in `gcur`, the last kBuckets words of the
+  // LDS list (its windows are that much shorter): 4 KB of LDS less per workgroup -- a seventh workgroup per CU for the
+  // 2,048-entry instantiation (206 -> 194 us at configs[4]'s size); an eighth buys the 1,536-entry one nothing (it would need
+  // <= 80 SGPRs: scripts/ubench/sgpr_occupancy.hip).
   __shared__ uint32_t cnt[kBuckets];
-  __shared__ uint32_t cur[kBuckets];
   __shared__ unsigned long long red_min[kTS / 64], red_max[kTS / 64];
   __shared__ uint32_t red_or[kTS / 64], red_and[kTS / 64];
   __shared__ uint32_t wave_sums[kTS / 64];
@@ -213,6 +217,12 @@ __device__ __forceinline__ void sort_one_tile(
   // two barriers earlier -- the scattered composites {id, depth bits} as one 64-bit word each (lc), so that the rank loop
   // reads one ds_read_b64 and makes one 64-bit compare per candidate
   __shared__ unsigned long long lc[kFast];
+  static_assert(kFast < 32768 && kBuckets / 2 < kFast, "lds_level's packed bucket words; the generic loop's offsets fit the LDS list's tail");
+  // (the short-list instantiation walks whole long lists through the generic loop and is not short of LDS: its offsets keep an
+  //  array of their own and its windows the whole list)
+  constexpr bool kOwnCur = !UNIT && !DEFER;
+  __shared__ uint32_t gcur_own[kOwnCur ? kBuckets : 1];
+  uint32_t* const gcur = kOwnCur ? gcur_own : reinterpret_cast<uint32_t*>(lc + kFast) - kBuckets;
   uint32_t* li = reinterpret_cast<uint32_t*>(lc);
   // (UNIT) lds_level's splitters: a strided sample of the list, the same ranked, and every scattered entry's bucket
   __shared__ unsigned long long smp[UNIT ? kUnitSample : 1], spl[UNIT ? kUnitSample : 1];
@@ -596,16 +606,17 @@ __device__ __forceinline__ void sort_one_tile(
 #pragma unroll
       for (int k = 0; k < kBuckets / kTS; ++k) {
         const int d = tid * (kBuckets / kTS) + k;
-        cur[d] = ex;
+        uint32_t word = ex | (c4[k] << 16);
         if (commit && c4[k] > heavy_over) {      // the generic loop below takes it from buffer (hk, hi)
           const int slot = stack_base + (int)hx;
           if (slot < kStack) {
             stack_lo[slot] = s + (int)ex; stack_hi[slot] = s + (int)(ex + c4[k]); stack_src[slot] = hsrc;
           } else {
-            cnt[d] = c4[k] | kBrute;
+            word |= kBrute;
           }
           ++hx;
         }
+        cnt[d] = word;
         ex += c4[k];
       }
       if (tid == 0) stack_n = !commit ? stack_base : (stack_base + (int)heavy < kStack ? stack_base + (int)heavy : kStack);
@@ -644,7 +655,7 @@ __device__ __forceinline__ void sort_one_tile(
       htot = hist_and_scan((uint32_t)kSm, true);
     }
 #if MGS_TSORT_STOP == 3
-    if (n > 0) { if (tid == 0) ids_final[s] = cur[3]; return 0u; }
+    if (n > 0) { if (tid == 0) ids_final[s] = cnt[3]; return 0u; }
 #endif
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
@@ -652,7 +663,7 @@ __device__ __forceinline__ void sort_one_tile(
       if (it * kTS + tid < n) {
         unsigned d;
         if constexpr (FROM_LDS) d = rd[it]; else d = digit(rk[it], ri[it]);
-        const uint32_t p = atomicAdd(&cur[d], 1u);
+        const uint32_t p = atomicAdd(&cnt[d], 1u) & 0xffffu;       // (the offset half never carries: it ends at the bucket's end <= n)
         lc[p] = ((unsigned long long)rk[it] << 32) | ri[it];
         if constexpr (FROM_LDS) lb[p] = (uint16_t)d;
       }
@@ -670,13 +681,13 @@ __device__ __forceinline__ void sort_one_tile(
         const uint32_t k = (uint32_t)(me >> 32), id = (uint32_t)me;
         unsigned d;
         if constexpr (FROM_LDS) d = lb[i]; else d = digit(k, id);
-        const uint32_t craw = cnt[d];
-        const uint32_t b = craw & ~kBrute;
+        const uint32_t craw = cnt[d];                  // {the bucket's END by now, its size, kBrute}
+        const uint32_t b = (craw >> 16) & 0x7fffu;
         if (b > (uint32_t)kSm && !(craw & kBrute)) {   // heavy: hand it to the generic loop
           hk[s + i] = k;
           hi[s + i] = id;
         } else {
-          const int be = (int)cur[d], bs = be - (int)b;
+          const int be = (int)(craw & 0xffffu), bs = be - (int)b;
           int c = 0;
           for (int j = bs; j < be; ++j) c += lc[j] < me ? 1 : 0;
           ids_final[s + bs + c] = id;
@@ -875,7 +886,7 @@ __device__ __forceinline__ void sort_one_tile(
 #pragma unroll
       for (int k = 0; k < kBuckets / kTS; ++k) {
         const int d = tid * (kBuckets / kTS) + k;
-        cur[d] = ex;
+        gcur[d] = ex;
         if (c4[k] > (uint32_t)kSm) {
           const int slot = base + (int)hx;
           if (slot < kStack) {
@@ -902,18 +913,19 @@ __device__ __forceinline__ void sort_one_tile(
 #pragma unroll
       for (int j = 0; j < kIF; ++j)
         if (i0 + j * kTS + tid < hi) {
-          const uint32_t p = atomicAdd(&cur[digit(kk[j], ii[j])], 1u);
+          const uint32_t p = atomicAdd(&gcur[digit(kk[j], ii[j])], 1u);
           dk[lo + p] = kk[j];
           di[lo + p] = ii[j];
         }
     }
     __syncthreads();                               // the scattered segment is visible to the workgroup
 
-    // cur[d] is now the END of bucket d: every element of a light bucket ranks itself inside it.  The scattered
+    // gcur[d] is now the END of bucket d: every element of a light bucket ranks itself inside it.  The scattered
     // segment goes through the LDS list in windows of kFast - 2 kSm entries with kSm more on either side (a light
     // bucket holds at most kSm entries, so the whole bucket of every element of the window is in LDS): one coalesced
     // load per entry instead of a dependent global load per CANDIDATE -- a 31 k-entry list has ~30 of them per element.
-    constexpr int kWin = kFast - 2 * kSm;
+    constexpr int kWin = kFast - (kOwnCur ? 0 : kBuckets / 2) - 2 * kSm;      // (the list's last kBuckets words are gcur)
+    static_assert(kWin >= 64, "a window of the generic loop's ranking pass");
     for (int w0 = lo; w0 < hi; w0 += kWin) {
       const int wa = max(lo, w0 - kSm), wb = min(hi, w0 + kWin + kSm), we = min(hi, w0 + kWin);
       for (int i = wa + tid; i < wb; i += kTS) lc[i - wa] = ((unsigned long long)dk[i] << 32) | di[i];
@@ -925,7 +937,7 @@ __device__ __forceinline__ void sort_one_tile(
         const uint32_t craw = cnt[d];
         const uint32_t b = craw & ~kBrute;
         if (b > (uint32_t)kSm && !(craw & kBrute)) continue;     // on the stack
-        const int be = lo + (int)cur[d], bs = be - (int)b;
+        const int be = lo + (int)gcur[d], bs = be - (int)b;
         int c = 0;
         if (b <= (uint32_t)kSm) {
           for (int j = bs; j < be; ++j) c += lc[j - wa] < me ? 1 : 0;

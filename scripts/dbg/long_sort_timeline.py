@@ -9,10 +9,10 @@ here = os.path.dirname(os.path.abspath(__file__))
 runpy.run_path(os.path.join(here, "..", "run_stage.py"), run_name="__main__")
 from robosimgs_amd import _lib
 L = _lib.lib()
-buf = np.zeros((8192, 6), np.uint64)
+buf = np.zeros((16384, 6), np.uint64)
 L.mgs_debug_tsort_log.restype = ctypes.c_uint
-n = L.mgs_debug_tsort_log(ctypes.c_void_p(buf.ctypes.data), 8192)
-rows = [tuple(int(x) for x in r) for r in buf[:n]]
+n = L.mgs_debug_tsort_log(ctypes.c_void_p(buf.ctypes.data), 16384)
+rows = [tuple(int(x) for x in r) for r in buf[:n] if int(r[3]) != 0xffff]      # (0xffff: the main kernel's tiles, main_sort_timeline.py)
 pops = {(r[2], r[3]): r[0] >> 32 for r in rows}
 rows = [(r[0] & 0xffffffff,) + r[1:] for r in rows]
 if not rows:
