@@ -21,6 +21,8 @@ cp $R/heavy_training_step_kernels.txt $P/18_heavy_tailed_training_step_kernels_b
 cp $R/binning_kernels_at_4k.md $P/05_binning_kernels_at_4k.md
 cp $R/soak_pixel_cause.txt $P/02_soak_outliers_root_cause.txt
 cp $R/heavy_gates.txt $P/02_heavy_tailed_gates.txt
+cp $R/sgpr_occupancy.txt $P/19d_sgpr_occupancy_microbenchmark.txt
+cp $R/resident_waves_by_kernel.txt $P/19e_resident_waves_by_kernel.txt
 cp $R/pmc_traffic.json profiles/pmc_traffic.json
 python -c "
 import json; from robosimgs_amd.csrc import build as B

@@ -22,6 +22,8 @@ bash scripts/heavy_training_step_kernels.sh 2>&1 | grep -v "rocprofv3\]" > $OUT/
 N=5000000 MU=0.008 W=3840 H=2160 CAP=30100000 bash scripts/prof_stage.sh binning 8 > $OUT/binning_kernels_at_4k.md 2>&1
 timeout 600 python scripts/dbg/soak_pixel_cause.py 48 67 2>&1 | grep -v amdgpu.ids > $OUT/soak_pixel_cause.txt
 timeout 900 python -m pytest tests/test_gpu_heavy.py -q -s 2>&1 | grep -v "^$" | grep "^seed\|^heavy\|passed\|failed" > $OUT/heavy_gates.txt
+(cd scripts/ubench && hipcc --offload-arch=gfx950 -O3 -o sgpr_occupancy.bin sgpr_occupancy.hip 2> /dev/null && timeout 120 ./sgpr_occupancy.bin) > $OUT/sgpr_occupancy.txt 2>&1
+bash scripts/dbg/tsort_occupancy.sh 2>&1 | grep "^4k\|^1080" > $OUT/resident_waves_by_kernel.txt
 bash scripts/profile_bench.sh refresh_default
 bash scripts/profile_bench.sh refresh_inflight1 --inflight 1 --no-cpu-baseline --no-stress
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 600 python bench.py --force-gather --no-cpu-baseline --no-stress --steps 3 --warmup 1 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/ring_world_of_one.json
