@@ -175,6 +175,7 @@ __device__ unsigned g_tsort_pops[4096];     // per workgroup: buckets popped off
 constexpr unsigned kTsortLog = 16384;
 __device__ unsigned long long g_tsort_log[6 * kTsortLog];
 __device__ unsigned g_tsort_log_n;
+__device__ unsigned long long g_tsort_tf[1 << 16];      // per workgroup of the main kernel: the clock behind the group filter
 #endif
 
 // GROUPED: the binning's direct path has dropped the pairs of every 2^shift consecutive tiles into one segment
@@ -344,6 +345,9 @@ __device__ __forceinline__ void sort_one_tile(
     }
     if ((tid & 63) == 0 && below) atomicAdd(&gcount[0], below);
     __syncthreads();
+#ifdef MGS_TSORT_TIMING
+    if (!UNIT && tid == 0) g_tsort_tf[blockIdx.x & 0xffff] = wall_clock64();
+#endif
     s = gs + (int)gcount[0];
     e = s + (int)gcount[1];
     if (tid == 0) {
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(kTSMain) __attribute__((amdgpu_num_sgpr(MGS_TSORT_M
     const unsigned k = atomicAdd(&g_tsort_log_n, 1u);
     if (k < kTsortLog) {
       unsigned long long* r = g_tsort_log + 6 * (size_t)k;
-      r[0] = blockIdx.x; r[1] = 0ull; r[2] = (unsigned long long)tile; r[3] = 0xffffull;      // (3: marks a tile of the main kernel)
+      r[0] = blockIdx.x; r[1] = g_tsort_tf[blockIdx.x & 0xffff]; r[2] = (unsigned long long)tile; r[3] = 0xffffull;      // (3: marks a tile of the main kernel)
       r[4] = t_start; r[5] = wall_clock64();
     }
   }

@@ -32,9 +32,16 @@ for lo, hi in ((0, 1), (1, 128), (128, 512), (512, 1024), (1024, 2049), (2049, 6
         print(f"  lists of {lo:5d} .. {min(hi, int(tl_.max()) + 1) - 1:5d} entries: {int(m.sum()):5d} tiles, {int(tl_[m].sum()):8d} entries, duration median {np.median(dur[m]):6.1f} max {dur[m].max():6.1f} us, sum {dur[m].sum():8.0f}")
 for q in (0.5, 0.9, 0.99, 1.0):
     print(f"  {q:.2f} of the tiles have ended by {np.quantile(en, q):6.1f} us, started by {np.quantile(st, q):6.1f} us")
+tf = np.array([(r[1] - r[4]) / 100 for r in main])          # the group filter's share of the tile's time
+seg = np.array([int(off[min(4 * (r[2] // 4) + 4, len(off) - 1)] - off[4 * (r[2] // 4)]) for r in main])
+print("group filter: median %.1f us, p99 %.1f, max %.1f; sum %.0f of %.0f workgroup-microseconds" % (np.median(tf), np.quantile(tf, 0.99), tf.max(), tf.sum(), dur.sum()))
+for lo, hi in ((0, 2048), (2048, 4096), (4096, 8192), (8192, 16384), (16384, 1 << 30)):
+    m = (seg >= lo) & (seg < hi)
+    if m.any():
+        print(f"  segments of {lo:6d} .. {min(hi, int(seg.max()) + 1) - 1:6d} entries: {int(m.sum()):5d} tiles, filter median {np.median(tf[m]):6.1f} max {tf[m].max():6.1f} us, the rest median {np.median((dur - tf)[m]):6.1f} max {(dur - tf)[m].max():6.1f} us")
 print("the twelve tiles that end last:")
 for i in np.argsort(-en)[:12]:
-    print(f"  wg {main[i][0]:5d} tile {main[i][2]:5d} ({tl_[i]:5d} entries): {st[i]:6.1f} -> {en[i]:6.1f} us")
+    print(f"  wg {main[i][0]:5d} tile {main[i][2]:5d} ({tl_[i]:5d} entries, segment {seg[i]:6d}): {st[i]:6.1f} -> {en[i]:6.1f} us, filter {tf[i]:6.1f}")
 # resident workgroups over time
 ts = np.linspace(0, (end - t0) / 100, 13)[:-1]
 print("resident workgroups at", " ".join(f"{t:5.0f}" for t in ts), "us")
