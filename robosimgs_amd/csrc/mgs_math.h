@@ -41,6 +41,20 @@ MGS_HD void camera_position(const CameraParams& c, float pos[3]) {
   pos[2] = -(c.R[2] * c.t[0] + c.R[5] * c.t[1] + c.R[8] * c.t[2]);
 }
 
+#ifndef MGS_PROJ_FACTORED
+// project_gaussian: 0 = cov2d in the textbook order of A.2 steps 2-4 (the reference's, and what every parity statement is made
+// on); 1 = from the 2 x 3 factor J R Rq S (measurement, MGS_EXTRA_FLAGS=-DMGS_PROJ_FACTORED=1: profiles/r6/00_experiments.md 9)
+#define MGS_PROJ_FACTORED 0
+#endif
+
+// a b - c d with one rounding's worth of error (Kahan): the product c d is rounded, its error recovered by an FMA
+MGS_HD float diff_of_products(float a, float b, float c, float d) {
+  const float w = c * d;
+  const float e = fmaf(-c, d, w);     // w - c d exactly
+  const float f = fmaf(a, b, -w);
+  return f + e;
+}
+
 // C = A * B, all 3x3 row-major
 MGS_HD void mat3_mul(const float* A, const float* B, float* C) {
   for (int i = 0; i < 3; ++i)
@@ -111,32 +125,58 @@ MGS_HD Projected project_gaussian(const float mean[3], const float quat[4],
   float z = R[6] * mean[0] + R[7] * mean[1] + R[8] * mean[2] + cam.t[2];
   if (!(z >= near_plane) || !(z <= far_plane)) return out;
 
-  float Rq[9], M[9], cov[9], tmp[9], covc[9];
+  float rz = 1.0f / z, rz2 = rz * rz;
+  float tanx = 0.5f * W / cam.fx, tany = 0.5f * H / cam.fy;
+  float lim_xp = (W - cam.cx) / cam.fx + 0.3f * tanx, lim_xn = cam.cx / cam.fx + 0.3f * tanx;
+  float lim_yp = (H - cam.cy) / cam.fy + 0.3f * tany, lim_yn = cam.cy / cam.fy + 0.3f * tany;
+  float tx = z * fminf(lim_xp, fmaxf(-lim_xn, x * rz));
+  float ty = z * fminf(lim_yp, fmaxf(-lim_yn, y * rz));
+  float j00 = cam.fx * rz, j02 = -cam.fx * tx * rz2;
+  float j11 = cam.fy * rz, j12 = -cam.fy * ty * rz2;
+  float Rq[9];
   quat_to_rotmat(quat, Rq);
+#if MGS_PROJ_FACTORED
+  // cov2d = M2 M2^T with M2 = J R Rq diag(scale), a 2 x 3 matrix -- the same matrix as J (R (Rq S S Rq^T) R^T) J^T of A.2 steps
+  // 2-4 without ever forming a covariance: a, c are sums of squares and det(cov2d) is the sum of M2's squared 2 x 2 minors
+  // (Cauchy-Binet).  The textbook order's det = a c - b^2 cancels for a needle-like Gaussian (relative conic error up to 5e-3
+  // at 300 : 1, this order's 2e-6) -- but that error scales the WHOLE conic, which the blend forgives; what sigma = 1/2 d^T conic d
+  // does not forgive is independent noise in the three entries, and there the two orders differ by a factor of two
+  // (profiles/r6/00_experiments.md section 9: half the pixels over tolerance over 59 clustered scenes, worse on 10 of them).
+  float RR[9];
+  mat3_mul(R, Rq, RR);
+  float m0[3], m1[3];
+  for (int k = 0; k < 3; ++k) {
+    m0[k] = (j00 * RR[k] + j02 * RR[6 + k]) * scale[k];
+    m1[k] = (j11 * RR[3 + k] + j12 * RR[6 + k]) * scale[k];
+  }
+  float a = m0[0] * m0[0] + m0[1] * m0[1] + m0[2] * m0[2];
+  float b = m0[0] * m1[0] + m0[1] * m1[1] + m0[2] * m1[2];
+  float c = m1[0] * m1[0] + m1[1] * m1[1] + m1[2] * m1[2];
+  const float d01 = diff_of_products(m0[0], m1[1], m0[1], m1[0]);
+  const float d02 = diff_of_products(m0[0], m1[2], m0[2], m1[0]);
+  const float d12 = diff_of_products(m0[1], m1[2], m0[2], m1[1]);
+  float det0 = d01 * d01 + d02 * d02 + d12 * d12;
+  float det = det0 + eps2d * (a + c) + eps2d * eps2d;       // det(cov2d + eps2d I): positive terms only
+  a += eps2d;
+  c += eps2d;
+#else
+  float M[9], cov[9], tmp[9], covc[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) M[i * 3 + j] = Rq[i * 3 + j] * scale[j];
   mat3_mul_bt(M, M, cov);       // Sigma = M M^T
   mat3_mul(R, cov, tmp);        // R Sigma
   mat3_mul_bt(tmp, R, covc);    // R Sigma R^T
-
-  float tanx = 0.5f * W / cam.fx, tany = 0.5f * H / cam.fy;
-  float lim_xp = (W - cam.cx) / cam.fx + 0.3f * tanx, lim_xn = cam.cx / cam.fx + 0.3f * tanx;
-  float lim_yp = (H - cam.cy) / cam.fy + 0.3f * tany, lim_yn = cam.cy / cam.fy + 0.3f * tany;
-  float rz = 1.0f / z, rz2 = rz * rz;
-  float tx = z * fminf(lim_xp, fmaxf(-lim_xn, x * rz));
-  float ty = z * fminf(lim_yp, fmaxf(-lim_yn, y * rz));
-  float j00 = cam.fx * rz, j02 = -cam.fx * tx * rz2;
-  float j11 = cam.fy * rz, j12 = -cam.fy * ty * rz2;
   // cov2d = J covc J^T with J = [[j00,0,j02],[0,j11,j12]]
   float a = j00 * (j00 * covc[0] + j02 * covc[6]) + j02 * (j00 * covc[2] + j02 * covc[8]);
   float b = j00 * (j11 * covc[1] + j12 * covc[2]) + j02 * (j11 * covc[7] + j12 * covc[8]);
   float c = j11 * (j11 * covc[4] + j12 * covc[7]) + j12 * (j11 * covc[5] + j12 * covc[8]);
-  float mx = cam.fx * x * rz + cam.cx, my = cam.fy * y * rz + cam.cy;
-
   float det0 = a * c - b * b;
   a += eps2d;
   c += eps2d;
   float det = a * c - b * b;
+#endif
+  float mx = cam.fx * x * rz + cam.cx, my = cam.fy * y * rz + cam.cy;
+
   if (!(det > 0.f)) return out;
   float inv_det = 1.0f / det;
 
