@@ -96,6 +96,34 @@ def test_projection_forward_matches_oracle(hh):
     np.testing.assert_allclose(comp[both], ref["compensations"][both], rtol=3e-4, atol=1e-6)
 
 
+def test_projection_from_the_2x3_factor_is_the_same_function_and_tighter_on_needles(tmp_path):
+    """csrc/mgs_math.h -DMGS_PROJ_FACTORED=1 (a build knob, not the default: profiles/r6/00_experiments.md section 9): cov2d from
+    J R Rq S instead of the textbook order -- the same radii, means and compensation, and on needle-like Gaussians a conic whose
+    error does not grow with the axis ratio."""
+    from robosimgs_amd import synthetic_scene_heavy_tailed
+    libs = {}
+    for name, flag in (("textbook", "-DMGS_PROJ_FACTORED=0"), ("factored", "-DMGS_PROJ_FACTORED=1")):
+        so = tmp_path / f"libhh_{name}.so"
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", flag,
+                        os.path.join(HERE, "host_harness", "harness.cpp"), "-o", str(so)], check=True)
+        libs[name] = ctypes.CDLL(str(so))
+    g = synthetic_scene_heavy_tailed(40_000, sh_degree=0, seed=2)
+    w, h = 640, 360
+    cam = camera_ring(1, w, h, thetas=[0.3])[0]
+    ref = O.project(g.means.astype(np.float64), g.quats.astype(np.float64), g.scales.astype(np.float64),
+                    _f(cam.viewmat()).astype(np.float64), _f(cam.K).astype(np.float64), w, h)
+    out = {k: _run_project(L, g, cam, w, h) for k, L in libs.items()}
+    rt, rf = out["textbook"][0], out["factored"][0]
+    both = (rt > 0) & (rf > 0) & (ref["radii"] > 0)
+    assert both.sum() > 10_000 and ((rt > 0) != (rf > 0)).sum() <= 2 and (rt[both] != rf[both]).sum() <= 2
+    np.testing.assert_allclose(out["factored"][1][both], out["textbook"][1][both], rtol=0, atol=0)        # means2d: untouched code
+    np.testing.assert_allclose(out["factored"][4][both], ref["compensations"][both], rtol=2e-5, atol=1e-6)   # (the textbook order's det0 cancels too)
+    err = {k: (np.abs(v[3].astype(np.float64) - ref["conics"]).max(1) / np.abs(ref["conics"]).max(1).clip(1e-30))[both] for k, v in out.items()}
+    assert err["factored"].max() < 1e-5, err["factored"].max()
+    assert err["textbook"].max() > 20 * err["factored"].max()        # (the scene does hold needles: the textbook order shows them)
+    assert abs(np.median(err["factored"]) / np.median(err["textbook"]) - 1) < 0.5
+
+
 def test_projection_backward_matches_autograd(hh):
     g, cam, w, h = _scene(1500)
     n = len(g)
